@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by RUNNING THE REFERENCE (hazdzz/STGCN at /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's ``model.layers`` / ``model.models`` / ``script.utility``
+unmodified, drives them on seeded synthetic inputs and stores inputs, activations, loss
+and gradients as ``.npz`` files next to this script.  The committed ``.npz`` files are what
+``tests/`` replays on any machine.
+
+To keep the fixtures small the *parameters* are not stored: they are drawn by
+``oracle.stgcn_oracle.random_params(seed)`` (numpy RandomState stream, frozen) and loaded
+into the reference model with ``load_state_dict(strict=True)`` -- which also pins the
+state_dict key/shape contract.  Each fixture carries the parameter checksums so RNG drift
+is detected.  Library versions are recorded in ``meta_versions``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy
+import scipy.sparse as sp
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import stgcn_oracle as orc  # noqa: E402   (only for random_params / param_shapes)
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"{REF} not present: golden fixtures can only be regenerated in the build container")
+    sys.path.insert(0, REF)
+    from model import layers, models          # noqa: E402  (reference packages)
+    from script import utility                # noqa: E402
+    return layers, models, utility
+
+
+def versions():
+    return np.array([f"torch={torch.__version__}", f"numpy={np.__version__}", f"scipy={scipy.__version__}"])
+
+
+def make_args(cfg, gso):
+    a = types.SimpleNamespace()
+    a.Kt, a.Ks, a.act_func, a.graph_conv_type = cfg["Kt"], cfg["Ks"], cfg["act"], cfg["gct"]
+    a.gso, a.enable_bias, a.droprate, a.n_his = gso, True, cfg["droprate"], cfg["n_his"]
+    return a
+
+
+def synth_gso(n, seed):
+    """Dense, deliberately NON-symmetric operator with spectral radius <= 1
+    (transpose-detecting: an L vs L^T mix-up in backward must fail)."""
+    rs = np.random.RandomState(seed)
+    a = rs.uniform(-1.0, 1.0, size=(n, n)) * (rs.uniform(size=(n, n)) < 0.5)
+    a = a / max(1.0, np.abs(np.linalg.eigvals(a)).max())
+    return a.astype(np.float32)
+
+
+def synth_xy(B, n_his, n_vertex, seed):
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((B, 1, n_his, n_vertex))
+    y = rs.standard_normal((B, n_vertex))
+    return x, y
+
+
+def run_case(models, name, cfg, gso, B, seed, train_steps=0, double=False, store_gso=True,
+             full_grads=True, store_acts=("st_blocks",)):
+    n_vertex = gso.shape[0]
+    dt = torch.float64 if double else torch.float32
+    gso_t = torch.from_numpy(gso).to(dt)
+    ocfg = orc.OracleConfig(Kt=cfg["Kt"], Ks=cfg["Ks"], n_his=cfg["n_his"], act_func=cfg["act"],
+                            graph_conv_type=cfg["gct"], droprate=cfg["droprate"], blocks=cfg["blocks"])
+    params = orc.random_params(ocfg, n_vertex, seed=seed, dtype=dt)
+    cls = models.STGCNChebGraphConv if cfg["gct"] == "cheb_graph_conv" else models.STGCNGraphConv
+    model = cls(make_args(cfg, gso_t), cfg["blocks"], n_vertex).to(dt)
+    model.load_state_dict(params, strict=True)       # pins key names + shapes against the reference
+    xn, yn = synth_xy(B, cfg["n_his"], n_vertex, seed + 1)
+    x, y = torch.from_numpy(xn).to(dt), torch.from_numpy(yn).to(dt)
+
+    out = {"meta_versions": versions(), "seed": seed, "B": B, "n_vertex": n_vertex,
+           "param_checksum": np.array(orc.param_checksums(params)),
+           "cfg_Kt": cfg["Kt"], "cfg_Ks": cfg["Ks"], "cfg_act": cfg["act"], "cfg_gct": cfg["gct"],
+           "cfg_n_his": cfg["n_his"], "cfg_droprate": cfg["droprate"],
+           "cfg_blocks": np.array(repr(cfg["blocks"]))}
+    if store_gso:
+        out["gso"] = gso
+
+    acts = {}
+    hooks = []
+    for l, blk in enumerate(model.st_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, i, o, l=l: acts.__setitem__(f"act.st_blocks.{l}", o.detach())))
+        if "sub" in store_acts:
+            for sub in ("tmp_conv1", "graph_conv", "tmp_conv2"):
+                hooks.append(getattr(blk, sub).register_forward_hook(
+                    lambda m, i, o, l=l, sub=sub: acts.__setitem__(f"act.st_blocks.{l}.{sub}", o.detach())))
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x)
+    for h in hooks:
+        h.remove()
+    out["eval.out"] = y_eval.numpy()
+    for k, v in acts.items():
+        out[k] = v.contiguous().numpy()       # logical (B,C,T,N) order
+
+    if cfg["droprate"] == 0.0:
+        model.train()
+        model.zero_grad()
+        loss = torch.nn.MSELoss()(model(x).view(len(x), -1), y)      # main.py:166-167
+        loss.backward()
+        out["train.loss"] = np.array(loss.item())
+        nograd = []
+        for k, prm in model.named_parameters():
+            if prm.grad is None:
+                nograd.append(k)
+                continue
+            g = prm.grad.numpy()
+            out["gradsum." + k] = np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum()])
+            if full_grads or g.size <= 4096:
+                out["grad." + k] = g.copy()
+        out["nograd"] = np.array(nograd)
+        if train_steps:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3)   # main.py:148
+            losses = []
+            for _ in range(train_steps):
+                opt.zero_grad()
+                l = torch.nn.MSELoss()(model(x).view(len(x), -1), y)
+                l.backward()
+                opt.step()
+                losses.append(l.item())
+            out["steps.losses"] = np.array(losses)
+            for k, v in model.state_dict().items():
+                a = v.detach().numpy()
+                out["steps.paramsum." + k] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+                if a.size <= 4096:
+                    out["steps.param." + k] = a.copy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def real_gsos(utility):
+    """GSOs of the three real graphs exactly as main.py:97-101 builds them
+    (np.random.seed(42) immediately before calc_chebynet_gso: SURVEY.md section 8c hazard 1)."""
+    table = {"metr-la": 207, "pems-bay": 325, "pemsd7-m": 228}
+    out = {"meta_versions": versions()}
+    for ds, n in table.items():
+        adj = sp.load_npz(os.path.join(REF, "data", ds, "adj.npz")).tocsc()
+        assert adj.shape == (n, n)
+        lap = utility.calc_gso(adj, "sym_norm_lap")
+        np.random.seed(42)
+        cheb = utility.calc_chebynet_gso(lap).toarray().astype(np.float32)
+        renorm = utility.calc_gso(adj, "sym_renorm_adj").toarray().astype(np.float32)
+        key = ds.replace("-", "_")
+        out[key + ".cheb_sym_norm_lap"] = cheb
+        out[key + ".sym_renorm_adj"] = renorm
+    path = os.path.join(HERE, "gso_real.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+    return out
+
+
+def main():
+    layers, models, utility = import_reference()
+    torch.set_num_threads(1)       # bit-reproducible reductions
+    std_blocks = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
+    base = dict(Kt=3, Ks=3, act="glu", gct="cheb_graph_conv", n_his=12, droprate=0.0, blocks=std_blocks)
+
+    gsos = real_gsos(utility)
+
+    # 1. tiny standard-channel model, non-symmetric GSO: fwd, all sub-layer activations, full grads, 3 AdamW steps
+    run_case(models, "tiny_cheb_f32", base, synth_gso(20, 1), B=2, seed=10, train_steps=3, store_acts=("st_blocks", "sub"))
+    run_case(models, "tiny_cheb_f64", base, synth_gso(20, 1), B=2, seed=10, double=True, full_grads=False)
+    # 2. Kipf graph_conv (C1-like), N not a multiple of 16
+    run_case(models, "tiny_gc_f32", dict(base, gct="graph_conv"), synth_gso(23, 2), B=3, seed=11)
+    # 3. odd channel plan exercising Align conv inside temporal layers (c_in > c_out), gtu, Ks=2, Kt=2
+    odd = [[1], [8, 4, 8], [6, 4, 6], [16, 16], [1]]
+    run_case(models, "tiny_odd_f32", dict(base, blocks=odd, act="gtu", Ks=2, Kt=2, n_his=9), synth_gso(11, 3), B=2, seed=12)
+    # 4. Ks = 1 and Ks = 5 (C5 uses K = 5) on the standard channels
+    run_case(models, "tiny_ks1_f32", dict(base, Ks=1), synth_gso(17, 4), B=2, seed=13, full_grads=False)
+    run_case(models, "tiny_ks5_f32", dict(base, Ks=5), synth_gso(17, 5), B=2, seed=14, full_grads=False)
+    # 5. real METR-LA operator (C2 model), one window: eval forward, block outputs, loss, grads (dropout off)
+    run_case(models, "metrla_c2_f32", base, gsos["metr_la.cheb_sym_norm_lap"], B=1, seed=15, store_gso=False, full_grads=False)
+    # 6. real PeMSD7(M) operator with Kipf conv (C1 model), one window
+    run_case(models, "pemsd7m_c1_f32", dict(base, gct="graph_conv"), gsos["pemsd7_m.sym_renorm_adj"], B=1, seed=16,
+             store_gso=False, full_grads=False)
+
+
+if __name__ == "__main__":
+    main()
