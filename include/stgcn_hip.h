@@ -1,0 +1,136 @@
+/* stgcn_hip.h -- C ABI of the MI355X-native STGCN ST-Conv-block training path (libstgcn_hip.so).
+ *
+ * The reference (hazdzz/STGCN) has no FFI layer: its hot path sits behind Python nn.Modules whose
+ * arithmetic is delegated to ATen.  Each entry point below replaces the ATen call sequence of one
+ * reference method; the Python mirror of the reference's module API (stgcn_amd/layers.py, models.py)
+ * binds these symbols through ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ *   stgcn_stblock_forward   <- model/layers.py:250-258  STConvBlock.forward
+ *                              (= layers.py:87-120 TemporalConvLayer.forward x2, :14-23 Align.forward,
+ *                                 :222-231 GraphConvLayer.forward, :143-172 ChebGraphConv.forward or
+ *                                 :194-206 GraphConv.forward, nn.LayerNorm :246/255, nn.Dropout :248/256)
+ *   stgcn_stblock_backward  <- what autograd derives from the above when main.py:168 calls l.backward()
+ *   stgcn_gso_prepare       <- main.py:101-103 (dense fp32 GSO upload); pads/transposes it once
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless stated; the library never allocates or frees.
+ *   - activations are channels-last: a logical (B, C, T, N) tensor is stored (B, T, N, C) contiguous
+ *     (the memory layout the reference itself produces after its first graph conv).
+ *   - parameters are passed in the reference's native state_dict layouts.
+ *   - `stream` is a hipStream_t; all work is enqueued on it, nothing synchronises.
+ *   - every function returns STGCN_OK or an error code; stgcn_last_error() gives a message.
+ */
+#ifndef STGCN_HIP_H
+#define STGCN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STGCN_OK 0
+#define STGCN_ERR_UNSUPPORTED 1 /* shape outside what the kernels cover (message says which) */
+#define STGCN_ERR_INVALID 2     /* null pointer / bad enum / inconsistent sizes */
+#define STGCN_ERR_LAUNCH 3      /* HIP reported a launch error */
+
+#define STGCN_ACT_GLU 0 /* (P + R) * sigmoid(Q)       layers.py:105 */
+#define STGCN_ACT_GTU 1 /* tanh(P + R) * sigmoid(Q)   layers.py:109 */
+#define STGCN_GC_CHEB 0 /* cheb_graph_conv            layers.py:143-172 */
+#define STGCN_GC_KIPF 1 /* graph_conv                 layers.py:194-206 */
+
+/* One STConvBlock(Kt, Ks, n_vertex, last_block_channel, channels, act_func, graph_conv_type, gso,
+ * bias, droprate) (layers.py:241) applied to a batch. */
+typedef struct stgcn_stblock_desc {
+    int32_t B, T, N;          /* batch, input time steps, vertices                                   */
+    int32_t c_in;             /* last_block_channel                                                  */
+    int32_t c0, c1, c2;       /* channels[0..2]                                                      */
+    int32_t Kt, Ks;           /* temporal / Chebyshev kernel sizes (Ks ignored for STGCN_GC_KIPF)    */
+    int32_t act;              /* STGCN_ACT_*                                                         */
+    int32_t graph_conv;       /* STGCN_GC_*                                                          */
+    int32_t training;         /* 1: dropout active (nn.Module.train()), 0: eval                      */
+    float droprate;           /* p of nn.Dropout                                                     */
+    float ln_eps;             /* 1e-12 in the reference (layers.py:246)                              */
+    int32_t need_dx;          /* backward: also produce the input gradient                           */
+    int32_t reserved;
+} stgcn_stblock_desc;
+
+/* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
+ *   tc1_w  tmp_conv1.causal_conv.weight (2*c0, c_in, Kt, 1)   tc1_b  .bias (2*c0)
+ *   tc1_aw tmp_conv1.align.align_conv.weight (c0, c_in, 1, 1) tc1_ab .bias (c0)   [read iff c_in > c0]
+ *   al_w   graph_conv.align.align_conv.weight (c1, c0, 1, 1)  al_b   .bias (c1)   [read iff c0 > c1]
+ *   gc_w   graph_conv.cheb_graph_conv.weight (Ks, c1, c1) | graph_conv.graph_conv.weight (c1, c1)
+ *   gc_b   ....bias (c1) or NULL (enable_bias False)
+ *   tc2_w  tmp_conv2.causal_conv.weight (2*c2, c1, Kt, 1)     tc2_b  .bias (2*c2)
+ *   tc2_aw tmp_conv2.align.align_conv.weight (c2, c1, 1, 1)   tc2_ab .bias (c2)   [read iff c1 > c2]
+ *   ln_w   tc2_ln.weight (N, c2)                              ln_b   tc2_ln.bias (N, c2)           */
+typedef struct stgcn_stblock_params {
+    const float *tc1_w, *tc1_b, *tc1_aw, *tc1_ab;
+    const float *al_w, *al_b;
+    const float *gc_w, *gc_b;
+    const float *tc2_w, *tc2_b, *tc2_aw, *tc2_ab;
+    const float *ln_w, *ln_b;
+} stgcn_stblock_params;
+
+/* Gradient outputs, same keys/layouts; a NULL entry is skipped.  Entries whose parameter is unused by
+ * the forward (align convs with c_in <= c_out) are never written: the reference leaves .grad None.  */
+typedef struct stgcn_stblock_grads {
+    float *tc1_w, *tc1_b, *tc1_aw, *tc1_ab;
+    float *al_w, *al_b;
+    float *gc_w, *gc_b;
+    float *tc2_w, *tc2_b, *tc2_aw, *tc2_ab;
+    float *ln_w, *ln_b;
+} stgcn_stblock_grads;
+
+/* Buffer sizes and the layout of the `saved` / `ws` buffers (all in floats).  `saved` carries the
+ * activations kept for backward, `ws` holds packed weights (written by forward, re-used by backward of
+ * the same step) and backward temporaries.  Offsets are exposed so tests can check every stage.      */
+typedef struct stgcn_stblock_plan {
+    int64_t T1, T2, rows1, rows2, NP; /* T1 = T-Kt+1, T2 = T1-Kt+1, rowsX = B*TX*N, NP = roundup16(N)  */
+    int64_t y_floats;                 /* B*T2*N*c2                                                     */
+    int64_t saved_floats, ws_floats;
+    /* saved */
+    int64_t sv_U1, sv_S1;             /* [rows1][c0] gate inputs of tmp_conv1 (U = P + R, S = sigmoid Q) */
+    int64_t sv_A;                     /* [rows1][c1] aligned graph-conv input X0                       */
+    int64_t sv_Xk;                    /* [Ks-1][rows1][c1] Chebyshev terms X1..                        */
+    int64_t sv_G;                     /* [rows1][c1] relu(graph conv + residual)                       */
+    int64_t sv_U2, sv_S2;             /* [rows2][c2]                                                   */
+    int64_t sv_mean, sv_rstd;         /* [B*T2]                                                        */
+    /* ws: packed weights */
+    int64_t ws_W1p, ws_W1d, ws_b1, ws_Wap, ws_WaT, ws_ba, ws_W2p, ws_W2d, ws_b2;
+    /* ws: backward temporaries */
+    int64_t ws_c1, ws_c2;             /* [B*T2] LayerNorm backward slab means                          */
+    int64_t ws_dZ2;                   /* [rows2][2*c2]                                                 */
+    int64_t ws_dYg;                   /* [rows1][c1]  d(relu out) masked                               */
+    int64_t ws_dA;                    /* [rows1][c1]                                                   */
+    int64_t ws_dZ1;                   /* [rows1][2*c0]                                                 */
+    int64_t ws_part;                  /* partial-sum arena for the parameter gradients                 */
+    int64_t part_floats;
+} stgcn_stblock_plan;
+
+int stgcn_version(void);
+const char* stgcn_backend(void);    /* "hip-gfx950" for the product library                           */
+const char* stgcn_last_error(void); /* thread-local message of the last failing call                  */
+
+int stgcn_stblock_plan_query(const stgcn_stblock_desc* desc, stgcn_stblock_plan* plan);
+
+/* gso: dense (N, N) row-major.  gso_pad / gso_t_pad: (NP, NP), NP = roundup16(N).                    */
+int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream);
+
+/* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4).     */
+int stgcn_stblock_forward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
+                          const float* gso_pad, float* y, float* saved, float* ws, uint64_t seed, uint64_t offset,
+                          void* stream);
+
+/* dy: (B, T2, N, c2); dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the matching
+ * forward call filled; seed/offset must be the forward's.                                            */
+int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
+                           const float* gso_t_pad, const float* dy, const float* saved, float* ws,
+                           const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset, void* stream);
+
+/* out[e] = 0 or 1/(1-p): the keep-scale the forward applies to element e of y (n multiple of 4).     */
+int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STGCN_HIP_H */

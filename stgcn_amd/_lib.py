@@ -1,0 +1,112 @@
+"""ctypes binding of libstgcn_hip.so (C ABI declared in include/stgcn_hip.h).
+
+The product path has exactly one backend: the HIP library built for gfx950 by
+``__graft_entry__.build()`` / ``stgcn_amd/build.py``.  If it is missing, importing the ops raises --
+there is no CPU or eager-PyTorch fallback.  (``use_library`` exists so the test-suite can point the
+same host code at the CPU-emulated twin built from the same sources, tests/emu/.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libstgcn_hip.so")
+
+STGCN_OK = 0
+ACT = {"glu": 0, "gtu": 1}
+GRAPH_CONV = {"cheb_graph_conv": 0, "graph_conv": 1}
+
+_fp = C.POINTER(C.c_float)
+
+
+class StblockDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32),
+                ("c0", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32), ("Kt", C.c_int32), ("Ks", C.c_int32),
+                ("act", C.c_int32), ("graph_conv", C.c_int32), ("training", C.c_int32),
+                ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32)]
+
+
+PARAM_FIELDS = ["tc1_w", "tc1_b", "tc1_aw", "tc1_ab", "al_w", "al_b", "gc_w", "gc_b",
+                "tc2_w", "tc2_b", "tc2_aw", "tc2_ab", "ln_w", "ln_b"]
+
+
+class StblockParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class StblockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+PLAN_FIELDS = ["T1", "T2", "rows1", "rows2", "NP", "y_floats", "saved_floats", "ws_floats",
+               "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd",
+               "ws_W1p", "ws_W1d", "ws_b1", "ws_Wap", "ws_WaT", "ws_ba", "ws_W2p", "ws_W2d", "ws_b2",
+               "ws_c1", "ws_c2", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats"]
+
+
+class StblockPlan(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in PLAN_FIELDS]
+
+
+class StgcnError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise StgcnError(
+                f"{path} not found: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `python -m stgcn_amd.build`). There is no fallback path.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        d.stgcn_version.restype = C.c_int
+        d.stgcn_backend.restype = C.c_char_p
+        d.stgcn_last_error.restype = C.c_char_p
+        d.stgcn_stblock_plan_query.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockPlan)]
+        d.stgcn_gso_prepare.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
+                                             C.c_uint64, C.c_uint64, C.c_void_p]
+        d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]
+        for f in ("stgcn_stblock_plan_query", "stgcn_gso_prepare", "stgcn_stblock_forward", "stgcn_stblock_backward",
+                  "stgcn_dropout_mask"):
+            getattr(d, f).restype = C.c_int
+        self.backend = d.stgcn_backend().decode()
+        self.is_emulator = self.backend.startswith("emu")
+
+    def check(self, rc: int, what: str):
+        if rc != STGCN_OK:
+            msg = self.dll.stgcn_last_error().decode()
+            if rc == 1:
+                raise NotImplementedError(f"{what}: {msg}")
+            if rc == 2:
+                raise ValueError(f"{what}: {msg}")
+            raise StgcnError(f"{what}: {msg} (code {rc})")
+
+
+_lib: Optional[_Lib] = None
+
+
+def use_library(path: str) -> _Lib:
+    """Bind an explicit shared library (tests use this for the emulated twin)."""
+    global _lib
+    _lib = _Lib(path)
+    return _lib
+
+
+def lib() -> _Lib:
+    """The bound library; binds the product HIP library on first use (raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        _lib = _Lib(os.environ.get("STGCN_AMD_LIB", DEFAULT_LIB))
+    return _lib
+
+
+EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
+                    "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask"]

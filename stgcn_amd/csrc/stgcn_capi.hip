@@ -1,0 +1,265 @@
+// C-ABI of libstgcn_hip.so: argument checking, buffer planning and kernel launches.
+// Declarations and the reference call sites each entry replaces: include/stgcn_hip.h.
+#include "../../include/stgcn_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "stgcn_kernels_bwd.hip.h"
+#include "stgcn_kernels_fwd.hip.h"
+
+using namespace stgcn;
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+#define STGCN_CHECK_LAUNCH(name)                                                                  \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(STGCN_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+int check_desc(const stgcn_stblock_desc* d) {
+    if (!d) return fail(STGCN_ERR_INVALID, "desc is NULL");
+    if (d->B < 1 || d->T < 1 || d->N < 1 || d->c_in < 1) return fail(STGCN_ERR_INVALID, "B/T/N/c_in must be positive");
+    if (d->Kt < 1) return fail(STGCN_ERR_INVALID, "Kt must be >= 1");
+    if (d->graph_conv == STGCN_GC_CHEB && d->Ks < 1)
+        return fail(STGCN_ERR_INVALID, "ERROR: the graph convolution kernel size Ks has to be a positive integer, but received %d.", d->Ks);
+    if (d->act != STGCN_ACT_GLU && d->act != STGCN_ACT_GTU) return fail(STGCN_ERR_INVALID, "act must be glu or gtu");
+    if (d->graph_conv != STGCN_GC_CHEB && d->graph_conv != STGCN_GC_KIPF) return fail(STGCN_ERR_INVALID, "bad graph_conv enum");
+    if (d->T - 2 * (d->Kt - 1) < 1) return fail(STGCN_ERR_INVALID, "T=%d too short for two Kt=%d temporal convs", d->T, d->Kt);
+    if (d->droprate < 0.f || d->droprate >= 1.f) return fail(STGCN_ERR_INVALID, "droprate must be in [0, 1)");
+    if (!(d->c0 == 64 || d->c0 == 128) || !(d->c2 == 64 || d->c2 == 128))
+        return fail(STGCN_ERR_UNSUPPORTED, "temporal-conv output channels must be 64 or 128 (got c0=%d c2=%d)", d->c0, d->c2);
+    if (d->c1 != 16) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv channels c1 must be 16 (got %d)", d->c1);
+    if (d->N > 512) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 512: slab-resident graph conv needs the tiled variant", d->N);
+    if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
+    return STGCN_OK;
+}
+
+inline int terms(const stgcn_stblock_desc* d) { return d->graph_conv == STGCN_GC_KIPF ? 2 : d->Ks; }
+
+struct Derived {
+    int T1, T2, NP, KP1, KP2, NC1, NC2, CP_in, CP1, terms;
+    int64_t rows0, rows1, rows2, slabs1, slabs2;
+};
+Derived derive(const stgcn_stblock_desc* d) {
+    Derived v;
+    v.T1 = d->T - d->Kt + 1;
+    v.T2 = v.T1 - d->Kt + 1;
+    v.NP = (int)rup(d->N, 16);
+    v.KP1 = (int)rup((int64_t)d->Kt * d->c_in, 16);
+    v.KP2 = (int)rup((int64_t)d->Kt * d->c1, 16);
+    v.NC1 = 2 * d->c0;
+    v.NC2 = 2 * d->c2;
+    v.CP_in = (int)rup(d->c_in, 16);
+    v.CP1 = (int)rup(d->c1, 16);
+    v.terms = terms(d);
+    v.rows0 = (int64_t)d->B * d->T * d->N;
+    v.rows1 = (int64_t)d->B * v.T1 * d->N;
+    v.rows2 = (int64_t)d->B * v.T2 * d->N;
+    v.slabs1 = (int64_t)d->B * v.T1;
+    v.slabs2 = (int64_t)d->B * v.T2;
+    return v;
+}
+
+uint32_t drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    if (t < 0.0) t = 0.0;
+    return (uint32_t)t;
+}
+int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const stgcn_stblock_plan& pl, float* ws,
+                       hipStream_t st) {
+    const Derived v = derive(d);
+    PackArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    int nj = 0;
+    auto add = [&](int kind, int n, float* dst, const float* w, const float* b, const float* aw, const float* ab, int Cin, int Cout,
+                   int Kt, int KCH) {
+        PackJob& j = pa.job[nj];
+        j.kind = kind; j.n = n; j.dst = dst; j.w = w; j.b = b; j.aw = aw; j.ab = ab;
+        j.Cin = Cin; j.Cout = Cout; j.Kt = Kt; j.KCH = KCH; j.gated = 1;
+        pa.start[nj + 1] = pa.start[nj] + cdiv(n, kThreads);
+        ++nj;
+    };
+    add(PK_TCONV_FWD, v.NC1 * v.KP1, ws + pl.ws_W1p, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, v.KP1 / 16);
+    if (d->need_dx)
+        add(PK_TCONV_BWD, d->Kt * v.NC1 * v.CP_in, ws + pl.ws_W1d, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt,
+            d->Kt * v.NC1 / 16);
+    add(PK_TCONV_BIAS, v.NC1, ws + pl.ws_b1, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
+    add(PK_ALIGN_FWD, d->c0 * d->c1, ws + pl.ws_Wap, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, d->c0 / 16);
+    add(PK_ALIGN_BWD, v.CP1 * d->c0, ws + pl.ws_WaT, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, v.CP1 / 16);
+    add(PK_ALIGN_BIAS, d->c1, ws + pl.ws_ba, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, 0);
+    add(PK_TCONV_FWD, v.NC2 * v.KP2, ws + pl.ws_W2p, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, v.KP2 / 16);
+    add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
+        d->Kt * v.NC2 / 16);
+    add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
+    pa.njobs = nj;
+    hipLaunchKernelGGL(pack_kernel, dim3(pa.start[nj]), dim3(kThreads), 0, st, pa);
+    STGCN_CHECK_LAUNCH("pack_kernel");
+    return STGCN_OK;
+}
+
+template <int NT>
+void launch_tconv_fwd(const TconvFwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((tconv_fwd_kernel<NT>), dim3(cdiv(a.ts.rows, kTileRows)), dim3(kThreads), kTileLdsFloats * sizeof(float), st, a);
+}
+
+int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
+    const int HT = a.NP / 16, maxq = (HT + 3) / 4;
+    const size_t lds = (size_t)3 * 16 * (a.NP + 4) * sizeof(float);
+    const dim3 grid((unsigned)a.slabs), blk(kThreads);
+    if (maxq <= 1) hipLaunchKernelGGL((gconv_fwd_kernel<1>), grid, blk, lds, st, a);
+    else if (maxq <= 2) hipLaunchKernelGGL((gconv_fwd_kernel<2>), grid, blk, lds, st, a);
+    else if (maxq <= 4) hipLaunchKernelGGL((gconv_fwd_kernel<4>), grid, blk, lds, st, a);
+    else if (maxq <= 6) hipLaunchKernelGGL((gconv_fwd_kernel<6>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((gconv_fwd_kernel<8>), grid, blk, lds, st, a);
+    STGCN_CHECK_LAUNCH("gconv_fwd_kernel");
+    return STGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int stgcn_version(void) { return 1; }
+const char* stgcn_backend(void) { return STGCN_BACKEND_NAME; }
+const char* stgcn_last_error(void) { return g_err; }
+
+int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!p) return fail(STGCN_ERR_INVALID, "plan is NULL");
+    const Derived v = derive(d);
+    memset(p, 0, sizeof(*p));
+    p->T1 = v.T1; p->T2 = v.T2; p->rows1 = v.rows1; p->rows2 = v.rows2; p->NP = v.NP;
+    p->y_floats = v.rows2 * d->c2;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t at = o; o += rup(n, 64); return at; };   // 256-byte aligned carve
+    p->sv_U1 = take(v.rows1 * d->c0);
+    p->sv_S1 = take(v.rows1 * d->c0);
+    p->sv_A = take(v.rows1 * d->c1);
+    p->sv_Xk = take((int64_t)(v.terms - 1) * v.rows1 * d->c1);
+    p->sv_G = take(v.rows1 * d->c1);
+    p->sv_U2 = take(v.rows2 * d->c2);
+    p->sv_S2 = take(v.rows2 * d->c2);
+    p->sv_mean = take(v.slabs2);
+    p->sv_rstd = take(v.slabs2);
+    p->saved_floats = o;
+    o = 0;
+    p->ws_W1p = take((int64_t)v.NC1 * v.KP1);
+    p->ws_W1d = take((int64_t)d->Kt * v.NC1 * v.CP_in);
+    p->ws_b1 = take(v.NC1);
+    p->ws_Wap = take((int64_t)d->c0 * d->c1);
+    p->ws_WaT = take((int64_t)v.CP1 * d->c0);
+    p->ws_ba = take(d->c1);
+    p->ws_W2p = take((int64_t)v.NC2 * v.KP2);
+    p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
+    p->ws_b2 = take(v.NC2);
+    p->ws_c1 = take(v.slabs2);
+    p->ws_c2 = take(v.slabs2);
+    p->ws_dZ2 = take(v.rows2 * v.NC2);
+    p->ws_dYg = take(v.rows1 * d->c1);
+    p->ws_dA = take(v.rows1 * d->c1);
+    p->ws_dZ1 = take(v.rows1 * v.NC1);
+    p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
+    p->ws_part = take(p->part_floats);
+    p->ws_floats = o;
+    return STGCN_OK;
+}
+
+int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream) {
+    if (!gso || !gso_pad || !gso_t_pad || N < 1) return fail(STGCN_ERR_INVALID, "stgcn_gso_prepare: bad arguments");
+    const int NP = (int)rup(N, 16);
+    hipLaunchKernelGGL(gso_pad_kernel, dim3(cdiv((int64_t)NP * NP, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, gso, (int)N, NP,
+                       gso_pad, gso_t_pad);
+    STGCN_CHECK_LAUNCH("gso_pad_kernel");
+    return STGCN_OK;
+}
+
+int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n < 0 || (n & 3)) return fail(STGCN_ERR_INVALID, "stgcn_dropout_mask: n must be a non-negative multiple of 4");
+    if (n == 0) return STGCN_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n / 4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, out, (long)(n / 4), seed,
+                       offset, drop_thresh(droprate), 1.0f / (1.0f - droprate));
+    STGCN_CHECK_LAUNCH("dropout_mask_kernel");
+    return STGCN_OK;
+}
+
+int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* x, const float* gso_pad, float* y,
+                          float* saved, float* ws, uint64_t seed, uint64_t offset, void* stream) {
+    stgcn_stblock_plan pl;
+    int rc = stgcn_stblock_plan_query(d, &pl);
+    if (rc) return rc;
+    if (!P || !x || !gso_pad || !y || !saved || !ws) return fail(STGCN_ERR_INVALID, "stgcn_stblock_forward: NULL buffer");
+    if (!P->tc1_w || !P->tc1_b || !P->gc_w || !P->tc2_w || !P->tc2_b || !P->ln_w || !P->ln_b)
+        return fail(STGCN_ERR_INVALID, "stgcn_stblock_forward: missing parameter pointer");
+    if (d->c_in > d->c0 && !P->tc1_aw) return fail(STGCN_ERR_INVALID, "tc1_aw required when c_in > c0");
+    if (d->c0 > d->c1 && !P->al_w) return fail(STGCN_ERR_INVALID, "al_w required when c0 > c1");
+    if (d->c1 > d->c2 && !P->tc2_aw) return fail(STGCN_ERR_INVALID, "tc2_aw required when c1 > c2");
+    const Derived v = derive(d);
+    hipStream_t st = (hipStream_t)stream;
+
+    rc = launch_pack(d, P, pl, ws, st);
+    if (rc) return rc;
+
+    // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------
+    TconvFwdArgs t1;
+    memset(&t1, 0, sizeof(t1));
+    t1.ts.src = x; t1.ts.C = d->c_in; t1.ts.taps = d->Kt; t1.ts.N = d->N; t1.ts.Tsrc = d->T; t1.ts.Tdst = v.T1; t1.ts.dir = 1;
+    t1.ts.rows = v.rows1;
+    t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
+    t1.U = saved + pl.sv_U1; t1.S = saved + pl.sv_S1; t1.H = nullptr;
+    t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;
+    if (d->c0 == 64) launch_tconv_fwd<2>(t1, st); else launch_tconv_fwd<4>(t1, st);
+    STGCN_CHECK_LAUNCH("tconv_fwd_kernel(tmp_conv1)");
+
+    // ---- graph conv + residual + relu -----------------------------------------------------------
+    GconvFwdArgs gc;
+    memset(&gc, 0, sizeof(gc));
+    gc.A = saved + pl.sv_A; gc.Lp = gso_pad; gc.W = P->gc_w; gc.bias = P->gc_b;
+    gc.Xk = saved + pl.sv_Xk; gc.G = saved + pl.sv_G;
+    gc.N = d->N; gc.NP = v.NP; gc.Ks = v.terms; gc.kipf = d->graph_conv == STGCN_GC_KIPF; gc.slabs = v.slabs1;
+    rc = launch_gconv_fwd(gc, st);
+    if (rc) return rc;
+
+    // ---- tmp_conv2 + GLU ---------------------------------------------------------------------------
+    TconvFwdArgs t2;
+    memset(&t2, 0, sizeof(t2));
+    t2.ts.src = saved + pl.sv_G; t2.ts.C = d->c1; t2.ts.taps = d->Kt; t2.ts.N = d->N; t2.ts.Tsrc = v.T1; t2.ts.Tdst = v.T2; t2.ts.dir = 1;
+    t2.ts.rows = v.rows2;
+    t2.Wp = ws + pl.ws_W2p; t2.bias = ws + pl.ws_b2; t2.KCH = v.KP2 / 16; t2.Cout = d->c2; t2.act = d->act;
+    t2.U = saved + pl.sv_U2; t2.S = saved + pl.sv_S2;
+    if (d->c2 == 64) launch_tconv_fwd<2>(t2, st); else launch_tconv_fwd<4>(t2, st);
+    STGCN_CHECK_LAUNCH("tconv_fwd_kernel(tmp_conv2)");
+
+    // ---- LayerNorm([N, c2]) + dropout ----------------------------------------------------------------
+    LnFwdArgs ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.U = saved + pl.sv_U2; ln.S = saved + pl.sv_S2; ln.gamma = P->ln_w; ln.beta = P->ln_b; ln.y = y;
+    ln.mean = saved + pl.sv_mean; ln.rstd = saved + pl.sv_rstd;
+    ln.n = d->N * d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
+    ln.eps = d->ln_eps; ln.keep_scale = 1.0f / (1.0f - d->droprate); ln.thresh = drop_thresh(d->droprate);
+    ln.seed = seed; ln.offset = offset;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)v.slabs2), dim3(kThreads), 64, st, ln);
+    STGCN_CHECK_LAUNCH("ln_fwd_kernel");
+    return STGCN_OK;
+}
+
+#include "stgcn_capi_bwd.inc"
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Device-side helpers shared by all STGCN kernels (gfx950 / CDNA4, wave64).
+//
+// MFMA conventions used throughout (cdna_hip_programming.md section 3, v_mfma_f32_16x16x4_f32):
+//   A operand: lane l holds A[row = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][col = l & 15]
+//   C/D      : lane l, reg r holds D[row = 4 * (l >> 4) + r][col = l & 15]
+// "16-chunk trick": a lane loads 4 consecutive k values (one 16-byte load) and feeds component s
+// to MFMA step s, so MFMA step s of chunk kc contracts k = kc*16 + 4*(l>>4) + s.  Both operands use
+// the same permutation of k, so the sum is unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace stgcn {
+
+constexpr int kThreads = 256;   // 4 waves per workgroup, one per SIMD
+constexpr int kTileRows = 64;   // rows of a flat row tile (4 MFMA m-tiles)
+constexpr int kSegMax = 128;    // K columns staged in LDS per segment
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- gate math (reference model/layers.py:105 GLU, :109 GTU) --------------------------------
+// forward: h = act(u) * s ; act = identity (glu) or tanh (gtu)
+__device__ __forceinline__ float gate_fwd(float u, float s, int act) { return (act == 0 ? u : tanhf(u)) * s; }
+// backward: returns dU, dQ for upstream dh
+__device__ __forceinline__ void gate_bwd(float dh, float u, float s, int act, float& du, float& dq) {
+    if (act == 0) {
+        du = dh * s;
+        dq = dh * u * s * (1.0f - s);
+    } else {
+        const float th = tanhf(u);
+        du = dh * s * (1.0f - th * th);
+        dq = dh * th * s * (1.0f - s);
+    }
+}
+
+// ---- block-wide sum of two values (256 threads) ----------------------------------------------
+// red must point to >= 8 floats of LDS.  All threads must call.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m);
+        b += __shfl_xor(b, m);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();   // protect red from a previous use
+    if (lane == 0) {
+        red[wave] = a;
+        red[4 + wave] = b;
+    }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+}
+
+// ---- Philox4x32-10 counter-based RNG (dropout mask; regenerated in backward, never stored) ---
+struct Philox4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 r = {c0, c1, c2, c3};
+    return r;
+}
+// keep-scale factors for the 4 consecutive elements [4*idx4, 4*idx4+4): 0 (dropped) or 1/(1-p).
+// thresh = floor(p * 2^32) clamped; an element is kept iff its 32-bit draw >= thresh.
+__device__ __forceinline__ f32x4 dropout_scale4(uint64_t idx4, uint64_t seed, uint64_t offset, uint32_t thresh, float scale) {
+    const Philox4 r = philox4x32_10(idx4, offset, seed);
+    f32x4 k;
+    k[0] = r.x >= thresh ? scale : 0.f;
+    k[1] = r.y >= thresh ? scale : 0.f;
+    k[2] = r.z >= thresh ? scale : 0.f;
+    k[3] = r.w >= thresh ? scale : 0.f;
+    return k;
+}
+
+}  // namespace stgcn

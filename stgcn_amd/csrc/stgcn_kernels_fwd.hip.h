@@ -1,0 +1,474 @@
+// Forward kernels of the fused ST-Conv block (gfx950).  See DESIGN.md section 3 for the data flow.
+//
+// All activations are channels-last (B, T, N, C) fp32.  "rows" are flattened (b, t, n) triples.
+// Reference arithmetic: hazdzz/STGCN model/layers.py:87-120 (TemporalConvLayer), :143-172
+// (ChebGraphConv), :194-206 (GraphConv), :222-231 (GraphConvLayer), :250-258 (STConvBlock).
+#pragma once
+#include "stgcn_device.hip.h"
+
+namespace stgcn {
+
+// ================================================================================================
+// Weight packing: parameters in the reference's native layouts -> MFMA B-operand fragment order.
+// Packed layout of a [K x NC] matrix W (K padded to KP = 16*KCH, NC = 16*NTT):
+//     Wp[((nt*KCH + kc)*64 + lane)*4 + s] = W[kc*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
+// so a wave fetches one (nt, kc) fragment with a single coalesced 1 KiB load (16 B per lane).
+// ================================================================================================
+enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5 };
+
+struct PackJob {
+    int kind;
+    int n;            // number of floats to produce
+    float* dst;
+    const float* w;   // conv weight (2*Cout, Cin, Kt, 1)   | align weight (c1, c0, 1, 1)
+    const float* b;   // conv bias (2*Cout) or null          | align bias (c1) or null
+    const float* aw;  // temporal-layer Align conv weight (Cout, Cin, 1, 1) (used iff Cin > Cout)
+    const float* ab;  // temporal-layer Align conv bias (Cout) or null
+    int Cin, Cout, Kt, KCH, gated;
+};
+constexpr int kMaxPackJobs = 12;
+struct PackArgs {
+    PackJob job[kMaxPackJobs];
+    int start[kMaxPackJobs + 1];   // prefix sums of workgroup counts
+    int njobs;
+};
+
+// W_eff[tap*Cin + i][o]: causal-conv weight with the residual branch Align(x)[:, :, Kt-1:] folded in
+// (layers.py:88-89 and :14-23): the residual only touches tap Kt-1 of the first Cout outputs.
+__device__ __forceinline__ float tconv_weff(const PackJob& j, int tap, int i, int o) {
+    float v = j.w[((size_t)o * j.Cin + i) * j.Kt + tap];
+    if (tap == j.Kt - 1 && o < j.Cout) {
+        if (j.Cin > j.Cout) v += j.aw[(size_t)o * j.Cin + i];
+        else if (i == o) v += 1.0f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
+    const PackJob& j = a.job[jb];
+    const int e = ((int)blockIdx.x - a.start[jb]) * kThreads + (int)threadIdx.x;
+    if (e >= j.n) return;
+    const int NC = j.gated ? 2 * j.Cout : j.Cout;
+    float v = 0.f;
+    if (j.kind == PK_TCONV_BIAS) {
+        v = j.b ? j.b[e] : 0.f;
+        if (j.Cin > j.Cout && e < j.Cout && j.ab) v += j.ab[e];
+    } else if (j.kind == PK_ALIGN_BIAS) {
+        v = (j.Cin > j.Cout && j.b) ? j.b[e] : 0.f;
+    } else {
+        const int s = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+        const int kc = rest % j.KCH, nt = rest / j.KCH;
+        const int kidx = kc * 16 + 4 * (lane >> 4) + s, col = nt * 16 + (lane & 15);
+        if (j.kind == PK_TCONV_FWD) {          // K = Kt*Cin, cols = NC
+            if (kidx < j.Kt * j.Cin) v = tconv_weff(j, kidx / j.Cin, kidx % j.Cin, col);
+        } else if (j.kind == PK_TCONV_BWD) {   // K = Kt*NC, cols = Cin (padded to 16)
+            if (col < j.Cin) v = tconv_weff(j, kidx / NC, col, kidx % NC);
+        } else if (j.kind == PK_ALIGN_FWD) {   // A = H @ Wa : K = c0 (=Cin), cols = c1 (=Cout)
+            if (kidx < j.Cin && col < j.Cout) v = (j.Cin > j.Cout) ? j.w[(size_t)col * j.Cin + kidx] : (kidx == col ? 1.f : 0.f);
+        } else {                                // PK_ALIGN_BWD: dH = dA @ Wa^T : K = c1, cols = c0
+            if (kidx < j.Cout && col < j.Cin) v = (j.Cin > j.Cout) ? j.w[(size_t)kidx * j.Cin + col] : (kidx == col ? 1.f : 0.f);
+        }
+    }
+    j.dst[e] = v;
+}
+
+// Zero-padded copies of the graph shift operator: Lp[h][i] = L[h][i], LTp[h][i] = L[i][h], both
+// [NP][NP] with NP = roundup(N, 16) so that fragment loads are 16-byte aligned and padding rows /
+// columns contribute exact zeros.
+__global__ __launch_bounds__(256) void gso_pad_kernel(const float* L, int N, int NP, float* Lp, float* LTp) {
+    const int e = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    if (e >= NP * NP) return;
+    const int h = e / NP, i = e % NP;
+    const bool in = h < N && i < N;
+    Lp[e] = in ? L[(size_t)h * N + i] : 0.f;
+    LTp[e] = in ? L[(size_t)i * N + h] : 0.f;
+}
+
+// ================================================================================================
+// Row-tile im2col staging (shared by the forward conv GEMM, the backward-data GEMM).
+// A "tap source" is a (B, Tsrc, N, C) tensor viewed as the implicit matrix whose row (b, t, n),
+// t < Tdst, is the concatenation over taps k of src[b, t + dir*k, n, :]  (dir = +1 forward conv,
+// dir = -1 transposed conv; out-of-range taps read as zeros).
+// ================================================================================================
+struct TapSrc {
+    const float* src;
+    int C, taps, N, Tsrc, Tdst, dir;
+    long rows;   // B * Tdst * N
+};
+
+// per-tile row bookkeeping in LDS: rowbase[r] = flat source row of tap 0, rowt[r] = t (or -2^20 if the
+// row is beyond the tensor, which makes every tap invalid)
+__device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, int* rowbase, int* rowt) {
+    const int r = threadIdx.x;
+    if (r < kTileRows) {
+        const long R = tile_row0 + r;
+        int base = 0, t = -(1 << 20);
+        if (R < ts.rows) {
+            const long per_b = (long)ts.Tdst * ts.N;
+            const int b = (int)(R / per_b);
+            const int rem = (int)(R - (long)b * per_b);
+            t = rem / ts.N;
+            base = b * ts.Tsrc * ts.N + rem;   // = (b*Tsrc + t)*N + n
+        }
+        rowbase[r] = base;
+        rowt[r] = t;
+    }
+}
+
+// Stage columns [k0, k0 + kseg) of the implicit matrix for the 64 rows of the tile into At[64][lda].
+__device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
+                                                  float* At, int lda) {
+    const int K = ts.taps * ts.C;
+    if ((ts.C & 3) == 0) {
+        const int q4 = kseg >> 2;
+        for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kThreads) {
+            const int r = idx / q4, q = idx - r * q4;
+            const int kidx = k0 + 4 * q;
+            f32x4 v = zero4();
+            if (kidx < K) {
+                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tt = rowt[r] + ts.dir * tap;
+                if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+            }
+            st4(At + r * lda + 4 * q, v);
+        }
+    } else {   // narrow inputs (C = 1 for the first block): scalar gather
+        for (int idx = threadIdx.x; idx < kTileRows * kseg; idx += kThreads) {
+            const int r = idx / kseg, q = idx - r * kseg;
+            const int kidx = k0 + q;
+            float v = 0.f;
+            if (kidx < K) {
+                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tt = rowt[r] + ts.dir * tap;
+                if (tt >= 0 && tt < ts.Tsrc) v = ts.src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
+            }
+            At[r * lda + q] = v;
+        }
+    }
+}
+
+// acc[i][j] += A_tile(m-tile mt0+i) x Wp(n-tile nt0 + j*nts) over kcs 16-wide chunks of this segment.
+template <int WM, int NT>
+__device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int kcs, const float* Wp,
+                                        int kc0, int KCH, int nt0, int nts) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = At + (mt0 * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
+    for (int kc = 0; kc < kcs; ++kc) {
+        f32x4 b[NT], a[WM];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc0 + kc) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], b[j][s], acc[i][j]);
+    }
+}
+
+// LDS carve for the row-tile GEMM kernels (floats): [rowbase 64 ints][rowt 64 ints][At 64 x (kSegMax+4)]
+constexpr int kLdaMax = kSegMax + 4;
+constexpr int kTileLdsFloats = 128 + kTileRows * kLdaMax;
+
+// ================================================================================================
+// F1: gated temporal convolution  Z = im2col(x) @ W_eff + b_eff ; U = Z[:, :Cout] ; S = sigmoid(Z[:, Cout:])
+//     H = act(U) * S   (layers.py:87-109, residual folded into W_eff)
+//     optional epilogue: A = H @ Wa + ba  (GraphConvLayer's Align, layers.py:223)
+// grid = ceil(rows / 64); each wave owns n-tiles {w + 4j}, so P channel c and Q channel c + Cout
+// meet in the same lane (GLU pairing without data movement).
+// ================================================================================================
+struct TconvFwdArgs {
+    TapSrc ts;            // x viewed through Kt taps, dir = +1
+    const float* Wp;      // packed W_eff, K = Kt*Cin (KCH chunks), NC = 2*Cout
+    const float* bias;    // b_eff[2*Cout]
+    int KCH, Cout, act;
+    float* U;             // [rows][Cout]  (nullable)
+    float* S;             // [rows][Cout]  (nullable)
+    float* H;             // [rows][Cout]  (nullable)
+    const float* Wap;     // packed Wa: K = Cout, cols = c1 (nullable -> no align epilogue)
+    const float* ba;      // [c1]
+    float* A;             // [rows][c1]
+    int c1;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    int* rowbase = reinterpret_cast<int*>(stgcn_smem);
+    int* rowt = rowbase + 64;
+    float* At = stgcn_smem + 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const long row0 = (long)blockIdx.x * kTileRows;
+
+    tile_rowinfo(a.ts, row0, rowbase, rowt);
+    __syncthreads();
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+
+    const int KP = a.KCH * 16;
+    for (int k0 = 0; k0 < KP; k0 += kSegMax) {
+        const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+        if (k0 > 0) __syncthreads();   // previous segment fully consumed
+        tile_load_segment(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        __syncthreads();
+        seg_mma<4, NT>(acc, At, kseg + 4, 0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+    }
+
+    // ---- epilogue: bias, gate, stores -------------------------------------------------------
+    const int Cout = a.Cout;
+    const bool do_align = a.Wap != nullptr;
+    const int ldh = Cout + 4;
+    if (do_align) __syncthreads();   // At is about to be reused as the H tile
+#pragma unroll
+    for (int jj = 0; jj < NT / 2; ++jj) {
+        const int col = (wave + 4 * jj) * 16 + l15;      // P channel; its gate is channel Cout + col
+        const float bp = a.bias[col], bq = a.bias[Cout + col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + 4 * g + r;
+                const long R = row0 + row;
+                const float u = acc[i][jj][r] + bp;
+                const float s = sigmoid_f(acc[i][jj + NT / 2][r] + bq);
+                const float h = gate_fwd(u, s, a.act);
+                if (R < a.ts.rows) {
+                    const size_t o = (size_t)R * Cout + col;
+                    if (a.U) a.U[o] = u;
+                    if (a.S) a.S[o] = s;
+                    if (a.H) a.H[o] = h;
+                }
+                if (do_align) At[row * ldh + col] = h;
+            }
+        }
+    }
+    if (!do_align) return;
+    __syncthreads();
+
+    // ---- align epilogue: A[64 x c1] = H[64 x Cout] @ Wa + ba ; wave w owns rows 16w..16w+15 -------
+    const int KCHa = Cout >> 4;
+    for (int nt = 0; nt < (a.c1 >> 4); ++nt) {
+        f32x4 c0 = zero4(), c1v = zero4();
+        for (int kc = 0; kc < KCHa; ++kc) {
+            const f32x4 b = ld4(a.Wap + ((size_t)(nt * KCHa + kc) * 64 + lane) * 4);
+            const f32x4 av = ld4(At + (wave * 16 + l15) * ldh + kc * 16 + 4 * g);
+            c0 = mfma4(av[0], b[0], c0);
+            c1v = mfma4(av[1], b[1], c1v);
+            c0 = mfma4(av[2], b[2], c0);
+            c1v = mfma4(av[3], b[3], c1v);
+        }
+        const int col = nt * 16 + l15;
+        const float bb = a.ba[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long R = row0 + wave * 16 + 4 * g + r;
+            if (R < a.ts.rows) a.A[(size_t)R * a.c1 + col] = c0[r] + c1v[r] + bb;
+        }
+    }
+}
+
+// ================================================================================================
+// F2: graph convolution on one (b, t) slab  X0 = A[slab] (N x 16)
+//     X1 = L X0 ; Xk = 2 L X_{k-1} - X_{k-2}          (layers.py:147-161, Kipf: X1 = L X0, layers.py:198)
+//     Y  = sum_k Xk Wk + bias                          (layers.py:165-168 / :199-202)
+//     G  = relu(Y + X0)                                (layers.py:229, 253)
+// One workgroup per slab.  X_k live transposed in LDS (XT[c][node]) so that they are the MFMA A operand
+// (rows = 16 channels, k = nodes); L fragments come straight from L2 (padded operator, 16-B loads);
+// D = X_k^T tile[c][h] leaves each lane with 4 consecutive channels of one node, which is at once the
+// store layout and the A operand of the 16x16 weight contraction.
+// Wave w owns node tiles h-tile = w, w+4, ... (MAXQ of them).
+// ================================================================================================
+struct GconvFwdArgs {
+    const float* A;      // [slabs][N][16]
+    const float* Lp;     // [NP][NP] zero padded
+    const float* W;      // cheb: [Ks][16][16] ; kipf: [16][16]
+    const float* bias;   // [16] or null
+    float* Xk;           // [Ks-1][slabs][N][16]   (X1..X_{Ks-1}, saved for backward; nullable)
+    float* G;            // [slabs][N][16]
+    int N, NP, Ks, kipf; // Ks = number of terms (kipf: 2)
+    long slabs;
+};
+
+template <int MAXQ>
+__global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const long slab = blockIdx.x;
+    const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
+    float* const XT0 = stgcn_smem;   // three rotating transposed buffers XT(k) = XT0 + (k % 3) * 16 * LDX
+
+    // stage X0 transposed
+    const float* Asl = a.A + (size_t)slab * N * 16;
+    for (int idx = tid; idx < NP * 4; idx += kThreads) {
+        const int n = idx >> 2, c4 = idx & 3;
+        const f32x4 v = n < N ? ld4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) XT0[(c4 * 4 + i) * LDX + n] = v[i];
+    }
+    __syncthreads();
+
+    f32x4 yacc[MAXQ], res[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        yacc[q] = zero4();
+        const int ht = wave + 4 * q;
+        // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
+        res[q] = ht < HT ? ld4(XT0 + l15 * LDX + ht * 16 + 4 * g) : zero4();
+    }
+
+    for (int k = 0; k < a.Ks; ++k) {
+        // weight fragment B[kk = c][col = j] = W_k[c = 4g + s][j = l15]
+        f32x4 wf = zero4();
+        if (!(a.kipf && k == 0)) {
+            const float* Wk = a.W + (a.kipf ? 0 : (size_t)k * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wf[s] = Wk[(4 * g + s) * 16 + l15];
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int ht = wave + 4 * q;
+                if (ht < HT) {
+                    const int h = ht * 16 + l15;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) yacc[q] = mfma4(XT0[(4 * g + s) * LDX + h], wf[s], yacc[q]);
+                }
+            }
+            continue;
+        }
+        if (k >= 2) __syncthreads();   // X_{k-1} complete in LDS
+        const float* Xprev = XT0 + ((k - 1) % 3) * 16 * LDX;
+        f32x4 acc[MAXQ];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
+        for (int kc = 0; kc < KCH; ++kc) {
+            const f32x4 af = ld4(Xprev + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int ht = wave + 4 * q;
+                if (ht < HT) {
+                    const f32x4 bf = ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + kc * 16 + 4 * g);   // B[node][h = l15]
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[s], acc[q]);
+                }
+            }
+        }
+        float* Xcur = XT0 + (k % 3) * 16 * LDX;
+        const float* Xpp = XT0 + ((k + 1) % 3) * 16 * LDX;   // == (k-2) % 3
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + 4 * q;
+            if (ht < HT) {
+                const int h = ht * 16 + l15;
+                f32x4 x = acc[q];   // X_k[h][c = 4g + r]
+                if (k >= 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = 2.0f * x[r] - Xpp[(4 * g + r) * LDX + h];
+                }
+                if (k + 1 < a.Ks) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xcur[(4 * g + r) * LDX + h] = x[r];
+                }
+                if (a.Xk && h < N) st4(a.Xk + (((size_t)(k - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, x);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) yacc[q] = mfma4(x[s], wf[s], yacc[q]);
+            }
+        }
+    }
+
+    const float bb = a.bias ? a.bias[l15] : 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int ht = wave + 4 * q;
+        if (ht < HT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = ht * 16 + 4 * g + r;
+                if (h < N) a.G[((size_t)slab * N + h) * 16 + l15] = fmaxf(yacc[q][r] + bb + res[q][r], 0.f);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// F4: LayerNorm over the joint [N, C] axes of one (b, t) slab (biased variance, eps 1e-12,
+//     layers.py:246/255) of H = act(U) * S, followed by inverted dropout (layers.py:256).
+//     Exact two-pass statistics; the slab (<= a few hundred KB) is re-read from L2.
+// ================================================================================================
+struct LnFwdArgs {
+    const float* U;      // [slabs][n]   n = N*C
+    const float* S;
+    const float* gamma;  // [n]
+    const float* beta;
+    float* y;            // [slabs][n]
+    float* mean;         // [slabs]
+    float* rstd;
+    int n, act, training;
+    float eps, keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+};
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const long slab = blockIdx.x;
+    const int n4 = a.n >> 2, tid = threadIdx.x;
+    const float* U = a.U + (size_t)slab * a.n;
+    const float* S = a.S + (size_t)slab * a.n;
+    float s1 = 0.f, dummy = 0.f;
+    for (int q = tid; q < n4; q += kThreads) {
+        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1 += gate_fwd(u[i], s[i], a.act);
+    }
+    block_sum2(s1, dummy, stgcn_smem);
+    const float mean = s1 / (float)a.n;
+    float s2 = 0.f;
+    dummy = 0.f;
+    for (int q = tid; q < n4; q += kThreads) {
+        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = gate_fwd(u[i], s[i], a.act) - mean;
+            s2 += d * d;
+        }
+    }
+    block_sum2(s2, dummy, stgcn_smem);
+    const float rstd = 1.0f / sqrtf(s2 / (float)a.n + a.eps);
+    if (tid == 0) {
+        a.mean[slab] = mean;
+        a.rstd[slab] = rstd;
+    }
+    float* y = a.y + (size_t)slab * a.n;
+    for (int q = tid; q < n4; q += kThreads) {
+        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q), ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], s[i], a.act) - mean) * rstd * ga[i] + be[i];
+        if (a.training) {
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] *= k[i];
+        }
+        st4(y + 4 * q, o);
+    }
+}
+
+// keep-scale mask exactly as ln_fwd_kernel draws it (test / debugging aid; also used by the oracle
+// comparison in training mode): out[e] in {0, 1/(1-p)}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* out, long n4, uint64_t seed, uint64_t offset, uint32_t thresh,
+                                                           float keep_scale) {
+    const long q = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (q >= n4) return;
+    st4(out + 4 * q, dropout_scale4((uint64_t)q, seed, offset, thresh, keep_scale));
+}
+
+}  // namespace stgcn

@@ -1,0 +1,201 @@
+"""Host side of the fused ST-Conv-block operator: buffer planning, autograd glue, stream plumbing.
+
+``st_conv_block(x, ...)`` is the custom ``autograd.Function`` the north star asks for: one forward call
+(`stgcn_stblock_forward`) and one backward call (`stgcn_stblock_backward`) into the HIP library replace
+the ~60 ATen launches the reference issues per block per step.
+
+PyTorch is used for device memory (caching allocator), streams and autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PARAM_FIELDS, StblockDesc, StblockGrads, StblockParams, StblockPlan
+
+
+@dataclass(frozen=True)
+class BlockConfig:
+    """Static configuration of one STConvBlock (constructor arguments at model/layers.py:241)."""
+    Kt: int
+    Ks: int
+    n_vertex: int
+    c_in: int
+    channels: Tuple[int, int, int]
+    act_func: str
+    graph_conv_type: str
+    droprate: float
+    ln_eps: float = 1e-12
+
+
+def _stream_of(t: torch.Tensor) -> Optional[int]:
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def _check_device(t: torch.Tensor, what: str):
+    L = _lib.lib()
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: expected float32, got {t.dtype}")
+    if L.is_emulator:
+        if t.is_cuda:
+            raise RuntimeError(f"{what}: the bound library is the CPU emulator but the tensor is on {t.device}")
+    elif not t.is_cuda:
+        raise RuntimeError(f"{what}: stgcn_amd runs on MI355X only (tensor is on {t.device}); there is no CPU fallback")
+
+
+def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool) -> StblockDesc:
+    if cfg.act_func not in _lib.ACT:
+        raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")  # layers.py:117-118
+    if cfg.graph_conv_type not in _lib.GRAPH_CONV:
+        raise ValueError(f"unknown graph_conv_type {cfg.graph_conv_type}")
+    d = StblockDesc()
+    d.B, d.T, d.N, d.c_in = B, T, cfg.n_vertex, cfg.c_in
+    d.c0, d.c1, d.c2 = cfg.channels
+    d.Kt, d.Ks = cfg.Kt, cfg.Ks
+    d.act = _lib.ACT[cfg.act_func]
+    d.graph_conv = _lib.GRAPH_CONV[cfg.graph_conv_type]
+    d.training = 1 if training else 0
+    d.droprate = float(cfg.droprate)
+    d.ln_eps = float(cfg.ln_eps)
+    d.need_dx = 1 if need_dx else 0
+    return d
+
+
+_plan_cache: Dict[tuple, StblockPlan] = {}
+
+
+def query_plan(desc: StblockDesc) -> StblockPlan:
+    key = tuple(getattr(desc, f) for f, _ in StblockDesc._fields_)
+    p = _plan_cache.get(key)
+    if p is None:
+        L = _lib.lib()
+        p = StblockPlan()
+        L.check(L.dll.stgcn_stblock_plan_query(C.byref(desc), C.byref(p)), "stgcn_stblock_plan_query")
+        _plan_cache[key] = p
+    return p
+
+
+def gso_prepare(gso: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pad (and transpose) the dense (N, N) graph shift operator once (main.py:101-103 upload)."""
+    L = _lib.lib()
+    gso = gso.detach().to(torch.float32).contiguous()
+    _check_device(gso, "gso")
+    N = gso.shape[0]
+    assert gso.shape == (N, N)
+    NP = (N + 15) // 16 * 16
+    gp = torch.empty(NP, NP, dtype=torch.float32, device=gso.device)
+    gt = torch.empty(NP, NP, dtype=torch.float32, device=gso.device)
+    L.check(L.dll.stgcn_gso_prepare(gso.data_ptr(), N, gp.data_ptr(), gt.data_ptr(), _stream_of(gso)), "stgcn_gso_prepare")
+    return gp, gt
+
+
+def dropout_mask(n: int, droprate: float, seed: int, offset: int, device) -> torch.Tensor:
+    """Keep-scale (0 or 1/(1-p)) for the first n elements of a block output, as the forward draws it."""
+    L = _lib.lib()
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.dll.stgcn_dropout_mask(out.data_ptr(), n, float(droprate), seed, offset, _stream_of(out)), "stgcn_dropout_mask")
+    return out
+
+
+class WorkspaceCache:
+    """Per-module scratch (`ws` of the C ABI): packed weights written by forward and re-read by the
+    backward of the same step, plus backward temporaries.  Re-allocated only when the plan grows."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, n_floats: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < n_floats or self.buf.device != device:
+            self.buf = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
+        return self.buf
+
+
+def _param_struct(cls, tensors):
+    s = cls()
+    for name, t in zip(PARAM_FIELDS, tensors):
+        setattr(s, name, None if t is None else t.data_ptr())
+    return s
+
+
+class _STBlockFn(torch.autograd.Function):
+    """x_cl: (B, T, N, c_in) contiguous -> y_cl: (B, T2, N, c2) contiguous."""
+
+    @staticmethod
+    def forward(ctx, x_cl, gso_pad, gso_t_pad, cfg: BlockConfig, training: bool, seed: int, offset: int, wsc: WorkspaceCache,
+                *params):
+        L = _lib.lib()
+        B, T, N, c_in = x_cl.shape
+        need_dx = bool(x_cl.requires_grad)
+        desc = make_desc(cfg, B, T, training, need_dx)
+        plan = query_plan(desc)
+        dev = x_cl.device
+        ps = [None if p is None else p.detach() for p in params]
+        for p in ps:
+            if p is not None:
+                assert p.is_contiguous() and p.dtype == torch.float32 and p.device == dev
+        y = torch.empty(B, plan.T2, N, cfg.channels[2], dtype=torch.float32, device=dev)
+        saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=dev)
+        ws = wsc.get(plan.ws_floats, dev)
+        pst = _param_struct(StblockParams, ps)
+        L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_pad.data_ptr(), y.data_ptr(),
+                                            saved.data_ptr(), ws.data_ptr(), seed, offset, _stream_of(x_cl)),
+                "stgcn_stblock_forward")
+        ctx.save_for_backward(x_cl, saved, gso_t_pad, *[p for p in params if p is not None])
+        ctx.param_present = [p is not None for p in params]
+        ctx.cfg, ctx.training, ctx.seed, ctx.offset, ctx.wsc, ctx.ws = cfg, training, seed, offset, wsc, ws
+        ctx.need_dx = need_dx
+        ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x_cl, saved, gso_t_pad, *present = ctx.saved_tensors
+        it = iter(present)
+        params = [next(it) if pr else None for pr in ctx.param_present]
+        cfg = ctx.cfg
+        B, T, N, c_in = x_cl.shape
+        desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx)
+        plan = query_plan(desc)
+        dy = dy.contiguous()
+        dev = x_cl.device
+        c0, c1, c2 = cfg.channels
+        # which parameters the forward actually used (reference leaves .grad None for the others)
+        used = {"tc1_aw": c_in > c0, "tc1_ab": c_in > c0, "al_w": c0 > c1, "al_b": c0 > c1, "tc2_aw": c1 > c2, "tc2_ab": c1 > c2}
+        grads = []
+        for name, p, need in zip(PARAM_FIELDS, params, ctx.param_needs_grad):
+            if p is None or not need or not used.get(name, True):
+                grads.append(None)
+            else:
+                grads.append(torch.empty_like(p))
+        dx = torch.empty_like(x_cl) if ctx.need_dx else None
+        ws = ctx.ws
+        pst = _param_struct(StblockParams, [None if p is None else p.detach() for p in params])
+        gst = _param_struct(StblockGrads, grads)
+        L.check(L.dll.stgcn_stblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(),
+                                             saved.data_ptr(), ws.data_ptr(), C.byref(gst),
+                                             None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _stream_of(x_cl)),
+                "stgcn_stblock_backward")
+        return (dx, None, None, None, None, None, None, None, *grads)
+
+
+def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tensor, cfg: BlockConfig, params, training: bool,
+                  seed: int, offset: int, wsc: WorkspaceCache) -> torch.Tensor:
+    """Fused STConvBlock.forward (model/layers.py:250-258).
+
+    ``x`` is logical (B, c_in, T, N) with ARBITRARY strides (NCHW for the first block, channels-last
+    for later ones -- SURVEY.md section 3.3); the result is logical (B, c2, T-2(Kt-1), N) with channels-last
+    strides, exactly what the reference's own forward returns.  ``params`` follows PARAM_FIELDS order.
+    """
+    _check_device(x, "x")
+    if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
+        raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
+    x_cl = x.permute(0, 2, 3, 1).contiguous()       # no copy when x is already channels-last (or c_in == 1)
+    y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, wsc, *params)
+    return y_cl.permute(0, 3, 1, 2)

@@ -1,0 +1,162 @@
+// CPU emulation shim for <hip/hip_runtime.h>  --  TEST INFRASTRUCTURE ONLY.
+//
+// tests/emu/build_emu.py compiles the *unmodified* product sources in stgcn_amd/csrc/ with the host
+// clang++ and `-I tests/emu` so that this header is found instead of the ROCm one.  Every
+// workgroup is executed as 256 cooperative fibers (ucontext) on one host thread; __syncthreads(),
+// wave shuffles and the f32 MFMA are emulated as rendezvous points, the MFMA with the documented
+// gfx950 lane->element maps (cdna_hip_programming.md section 3) and an fmaf chain in k order, so index
+// math, fragment layouts, masking and barrier placement of the kernels are exercised on the CPU
+// before any GPU minute is spent.  It is not a performance model and it never ships.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+namespace emu {
+constexpr int kWave = 64;
+constexpr size_t kLdsBytes = 160 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    bool done = false;
+    unsigned tid = 0;
+};
+struct WaveState {
+    float a[kWave], b[kWave];
+    uint32_t u[kWave];
+    int arrived = 0;
+    unsigned gen = 0;
+};
+struct State {
+    dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+    ucontext_t main_ctx;
+    std::vector<Fiber> fibers;
+    Fiber* cur = nullptr;
+    std::function<void()> body;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    int nthreads = 0;
+    std::vector<WaveState> waves;
+    long n_mfma = 0;
+};
+extern State g;
+void yield();
+void block_barrier();
+void wave_barrier();
+void run_block();
+}  // namespace emu
+
+// The one dynamic-LDS array every kernel (all live in namespace stgcn) declares as
+// `extern __shared__ float stgcn_smem[]`; defined in emu_runtime.cpp.
+namespace stgcn { extern float stgcn_smem[]; }
+
+#define threadIdx (emu::g.threadIdx_)
+#define blockIdx (emu::g.blockIdx_)
+#define blockDim (emu::g.blockDim_)
+#define gridDim (emu::g.gridDim_)
+
+static inline void __syncthreads() { emu::block_barrier(); }
+
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: A[i][k] held by lane i + 16k, B[k][j] by lane j + 16k,
+// D[i][j] for i = 4*(lane>>4) + r (r = 0..3), j = lane & 15.
+static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
+    const unsigned t = emu::g.threadIdx_.x;
+    emu::WaveState& w = emu::g.waves[t / emu::kWave];
+    const int lane = t % emu::kWave;
+    w.a[lane] = a;
+    w.b[lane] = b;
+    emu::wave_barrier();
+    emu_f32x4 d = c;
+    const int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.a[i + 16 * k], w.b[j + 16 * k], acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    if (lane == 0) emu::g.n_mfma++;
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+template <typename T>
+static inline T emu_shfl_from(T v, int src_lane) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    const unsigned t = emu::g.threadIdx_.x;
+    emu::WaveState& w = emu::g.waves[t / emu::kWave];
+    const int lane = t % emu::kWave;
+    uint32_t bits;
+    memcpy(&bits, &v, 4);
+    w.u[lane] = bits;
+    emu::wave_barrier();
+    uint32_t r = w.u[src_lane & 63];
+    emu::wave_barrier();
+    T out;
+    memcpy(&out, &r, 4);
+    return out;
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emu_shfl_from(v, (int)(emu::g.threadIdx_.x % 64) ^ mask); }
+template <typename T> static inline T __shfl_down(T v, int d, int width = 64) { (void)width; int l = emu::g.threadIdx_.x % 64; return emu_shfl_from(v, l + d < 64 ? l + d : l); }
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return emu_shfl_from(v, src); }
+
+#define __expf(x) expf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+
+template <typename... KArgs, typename... Args>
+static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+    if (shmem > emu::kLdsBytes) { fprintf(stderr, "emu: LDS request %zu > 160 KiB\n", shmem); abort(); }
+    if (block.x % 64 != 0 || block.y != 1 || block.z != 1) { fprintf(stderr, "emu: block must be 1-D multiple of 64\n"); abort(); }
+    emu::g.gridDim_ = grid;
+    emu::g.blockDim_ = block;
+    emu::g.nthreads = (int)block.x;
+    emu::g.body = [=]() { kernel(static_cast<KArgs>(args)...); };
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                emu::g.blockIdx_ = dim3(bx, by, bz);
+                emu::run_block();
+            }
+}

@@ -1,0 +1,79 @@
+"""Forward kernels of the HIP library, executed on the CPU emulator (tests/emu), checked stage by stage
+against the numpy stage oracle.  Not a GPU test: it validates index math / fragment layouts / barriers of
+the *same sources* that hipcc compiles for gfx950."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stblock_stages as st
+from stgcn_amd import _lib, ops
+from tests.emu_util import bind_emulator, block_case, nonsym_gso, params_in_field_order
+
+CASES = [
+    # c_in, channels, Kt, Ks, gct, act, N, B, T
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 21, 2, 7),
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 1, 6),
+    (64, (64, 16, 64), 3, 3, "graph_conv", "gtu", 35, 1, 5),
+    (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5),
+    (1, (64, 16, 64), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5),
+]
+
+
+@pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T", CASES)
+def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
+    L = bind_emulator()
+    cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    gso = nonsym_gso(N, 5)
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((B, T, N, c_in)).astype(np.float32)      # channels-last
+
+    bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=tuple(channels), act_func=act,
+                           graph_conv_type=gct, droprate=0.5)
+    desc = ops.make_desc(bcfg, B, T, training=True, need_dx=c_in > 1)
+    plan = ops.query_plan(desc)
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso))
+    NP = plan.NP
+    assert np.array_equal(gp.numpy()[:N, :N], gso) and np.array_equal(gt.numpy()[:N, :N], gso.T)
+    assert gp.numpy()[N:].sum() == 0 and gp.numpy()[:, N:].sum() == 0
+
+    params = params_in_field_order(p, "st_blocks.0.", gct)
+    pst = ops._param_struct(_lib.StblockParams, params)
+    xt = torch.from_numpy(x)
+    y = torch.full((B, plan.T2, N, channels[2]), float("nan"))
+    saved = torch.full((plan.saved_floats,), float("nan"))
+    ws = torch.full((plan.ws_floats,), float("nan"))
+    seed, offset = 1234, 7
+    L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), xt.data_ptr(), gp.data_ptr(), y.data_ptr(),
+                                        saved.data_ptr(), ws.data_ptr(), seed, offset, None), "fwd")
+
+    # oracle with the library's own dropout mask
+    keep_scale = ops.dropout_mask(y.numel(), 0.5, seed, offset, "cpu").numpy().reshape(y.shape)
+    assert set(np.unique(keep_scale)) <= {0.0, 2.0}
+    assert 0.35 < (keep_scale > 0).mean() < 0.65
+    bp = st.block_params_np(p, "st_blocks.0.", gct, np.float64)
+    y_ref, sv = st.stblock_fwd(x.astype(np.float64), gso.astype(np.float64), bp, Kt, c_in, channels, gct, act,
+                               keep=(keep_scale > 0).astype(np.float64), p_drop=0.5)
+
+    def seg(off, shape):
+        n = int(np.prod(shape))
+        return saved.numpy()[off:off + n].reshape(shape)
+
+    T1, T2 = plan.T1, plan.T2
+    c0, c1, c2 = channels
+    tol = 2e-5
+    assert np.abs(seg(plan.sv_U1, (B, T1, N, c0)) - sv["U1"]).max() < tol
+    assert np.abs(seg(plan.sv_S1, (B, T1, N, c0)) - sv["S1"]).max() < tol
+    assert np.abs(seg(plan.sv_A, (B, T1, N, c1)) - sv["A"]).max() < tol
+    terms = 2 if gct == "graph_conv" else Ks
+    for k in range(1, terms):
+        got = seg(plan.sv_Xk + (k - 1) * B * T1 * N * c1, (B, T1, N, c1))
+        assert np.abs(got - sv["Xs"][k]).max() < tol, f"X{k}"
+    assert np.abs(seg(plan.sv_G, (B, T1, N, c1)) - sv["G"]).max() < tol
+    assert np.abs(seg(plan.sv_U2, (B, T2, N, c2)) - sv["U2"]).max() < tol
+    assert np.abs(seg(plan.sv_S2, (B, T2, N, c2)) - sv["S2"]).max() < tol
+    assert np.abs(seg(plan.sv_mean, (B, T2)) - sv["mean"]).max() < tol
+    assert np.abs(seg(plan.sv_rstd, (B, T2)) / sv["rstd"] - 1).max() < 1e-4
+    assert np.isfinite(y.numpy()).all()
+    assert np.abs(y.numpy() - y_ref).max() < 5e-5
