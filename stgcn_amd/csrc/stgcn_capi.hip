@@ -47,6 +47,8 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (d->c1 != 16) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv channels c1 must be 16 (got %d)", d->c1);
     if (d->N > 512) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 512: slab-resident graph conv needs the tiled variant", d->N);
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
+    if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
+        return fail(STGCN_ERR_UNSUPPORTED, "c_in=%d: input channels must be a multiple of 4 unless Kt*c_in <= 16", d->c_in);
     return STGCN_OK;
 }
 
@@ -132,6 +134,52 @@ int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
     return STGCN_OK;
 }
 
+
+int launch_bwd_data(const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
+    const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
+    const size_t lds = kTileLdsFloats * sizeof(float);
+    if (ntt == 1) hipLaunchKernelGGL((tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, st, a);
+    else if (ntt == 2) hipLaunchKernelGGL((tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, st, a);
+    else if (ntt == 4) hipLaunchKernelGGL((tconv_bwd_data_kernel<4, 1, 0>), grid, blk, lds, st, a);
+    else if (ntt == 8) hipLaunchKernelGGL((tconv_bwd_data_kernel<4, 2, 0>), grid, blk, lds, st, a);
+    else return fail(STGCN_ERR_UNSUPPORTED, "backward-data with %d input channel tiles (supported: 1, 2, 4, 8)", ntt);
+    STGCN_CHECK_LAUNCH("tconv_bwd_data_kernel");
+    return STGCN_OK;
+}
+
+int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
+    const int HT = a.NP / 16, maxq = (HT + 3) / 4;
+    const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
+    if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
+    const dim3 grid((unsigned)a.slabs), blk(kThreads);
+    if (maxq <= 1) hipLaunchKernelGGL((gconv_bwd_kernel<1>), grid, blk, lds, st, a);
+    else if (maxq <= 2) hipLaunchKernelGGL((gconv_bwd_kernel<2>), grid, blk, lds, st, a);
+    else if (maxq <= 4) hipLaunchKernelGGL((gconv_bwd_kernel<4>), grid, blk, lds, st, a);
+    else if (maxq <= 6) hipLaunchKernelGGL((gconv_bwd_kernel<6>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((gconv_bwd_kernel<8>), grid, blk, lds, st, a);
+    STGCN_CHECK_LAUNCH("gconv_bwd_kernel");
+    return STGCN_OK;
+}
+
+template <int MTW>
+void launch_bwd_weight_n(const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
+    const dim3 grid(w.chunks, w.mchunks), blk(kThreads);
+    size_t lds = (size_t)16 * ((MTW * 16 + 4) + (a.NC + 4)) * sizeof(float);
+    if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
+    if (a.NC == 128) hipLaunchKernelGGL((tconv_bwd_weight_kernel<MTW, 2>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((tconv_bwd_weight_kernel<MTW, 4>), grid, blk, lds, st, a);
+}
+int launch_bwd_weight(const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
+    if (a.NC != 128 && a.NC != 256) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient with %d output channels", a.NC);
+    switch (w.MTW) {
+        case 1: launch_bwd_weight_n<1>(a, w, st); break;
+        case 2: launch_bwd_weight_n<2>(a, w, st); break;
+        case 3: launch_bwd_weight_n<3>(a, w, st); break;
+        default: launch_bwd_weight_n<4>(a, w, st); break;
+    }
+    STGCN_CHECK_LAUNCH("tconv_bwd_weight_kernel");
+    return STGCN_OK;
+}
 }  // namespace
 
 extern "C" {

@@ -1,5 +1,652 @@
+// Backward kernels of the fused ST-Conv block (gfx950).  Math: SURVEY.md section 8a rows a2/a4/a6
+// (checked against autograd in oracle/stblock_stages.py).  Data flow: DESIGN.md section 3.
+//
+//   dy --[ln_bwd_stats]--> c1,c2 --[ln_gate_bwd]--> dZ2, partial dgamma/dbeta
+//   dZ2 --[tconv_bwd_data (relu mask)]--> dYg --[gconv_bwd]--> dA, partial dW_gc/db_gc
+//   dA --[align_gate_bwd]--> dZ1, partial dWa/dba --[tconv_bwd_data]--> dx
+//   (G, dZ2), (x, dZ1) --[tconv_bwd_weight]--> partial dW_eff/db_eff
+//   partials --[reduce_kernel]--> parameter gradients in the reference's layouts
 #pragma once
 #include "stgcn_device.hip.h"
+#include "stgcn_kernels_fwd.hip.h"
+
 namespace stgcn {
-inline int64_t bwd_partial_floats(int, int, int, int, int, int, int, int, int) { return 0; }
+
+// ================================================================================================
+// Geometry of the backward launches and of the partial-sum arena (host + plan use the same numbers)
+// ================================================================================================
+struct WgradGeom {
+    int M, Mtiles, MTW, mchunks, Mpad, NC, rows_per_chunk, chunks;
+    long off;   // arena offset: [chunks][Mpad*NC] then [chunks][NC] bias partials
+    long floats;
+};
+struct BwdGeom {
+    int ln_spg, ln_sg;       // slabs per group / groups for the LayerNorm parameter partials
+    int al_wgs;              // workgroups of align_gate_bwd (grid-stride over 64-row tiles)
+    WgradGeom w1, w2;
+    long off_ln_g, off_ln_b, off_gc, off_al, total;
+    int gc_stride;           // floats per slab in the graph-conv partials: (terms + 1) * 256
+    int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1
+};
+
+inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
+    WgradGeom g;
+    g.M = K;
+    g.Mtiles = (K + 15) / 16;
+    g.MTW = g.Mtiles <= 3 ? g.Mtiles : 4;   // m-tiles per workgroup (1, 2, 3 or 4)
+    g.mchunks = (g.Mtiles + g.MTW - 1) / g.MTW;
+    g.Mpad = g.mchunks * g.MTW * 16;
+    g.NC = NC;
+    // aim at ~512 workgroups in total, at least 64 rows per chunk
+    long target = 512 / g.mchunks;
+    if (target < 1) target = 1;
+    long rpc = (rows + target - 1) / target;
+    rpc = (rpc + 15) / 16 * 16;
+    if (rpc < 64) rpc = 64;
+    g.rows_per_chunk = (int)rpc;
+    g.chunks = (int)((rows + rpc - 1) / rpc);
+    g.off = off;
+    g.floats = (long)g.chunks * ((long)g.Mpad * NC + NC);
+    return g;
 }
+
+inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms) {
+    BwdGeom g;
+    const int T1 = T - Kt + 1, T2 = T1 - Kt + 1;
+    const long rows1 = (long)B * T1 * N, rows2 = (long)B * T2 * N, slabs1 = (long)B * T1, slabs2 = (long)B * T2;
+    const long n = (long)N * c2, n4 = n / 4;
+    const int colgroups = (int)((n4 + kThreads - 1) / kThreads);
+    int sg = (768 + colgroups - 1) / colgroups;   // ~768 workgroups
+    if (sg > slabs2) sg = (int)slabs2;
+    if (sg < 1) sg = 1;
+    g.ln_spg = (int)((slabs2 + sg - 1) / sg);
+    g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
+    const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
+    g.al_wgs = (int)(tiles1 < 512 ? tiles1 : 512);
+    long o = 0;
+    auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };
+    g.off_ln_g = take((long)g.ln_sg * n);
+    g.off_ln_b = take((long)g.ln_sg * n);
+    g.gc_stride = (terms + 1) * 256;
+    g.off_gc = take(slabs1 * g.gc_stride);
+    g.al_stride = c0 * c1 + c1;
+    g.off_al = take((long)g.al_wgs * g.al_stride);
+    g.w1 = wgrad_geom(rows1, Kt * c_in, 2 * c0, 0);
+    g.w1.off = take(g.w1.floats);
+    g.w2 = wgrad_geom(rows2, Kt * c1, 2 * c2, 0);
+    g.w2.off = take(g.w2.floats);
+    g.total = o;
+    return g;
+}
+inline int64_t bwd_partial_floats(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms) {
+    return bwd_geom(B, T, N, c_in, c0, c1, c2, Kt, terms).total;
+}
+
+// ================================================================================================
+// B1a: per-slab means of g = dy_m * gamma and g * xhat (LayerNorm backward)
+// ================================================================================================
+struct LnBwdArgs {
+    const float* dy;     // [slabs][n]
+    const float* U;
+    const float* S;
+    const float* gamma;
+    const float* mean;
+    const float* rstd;
+    float* c1;           // [slabs]
+    float* c2;
+    float* dZ;           // [slabs*N][2*C]
+    float* dgam_part;    // [sg][n]
+    float* dbet_part;
+    int n, C, act, training, spg;
+    long slabs;
+    float keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(LnBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const long slab = blockIdx.x;
+    const int n4 = a.n >> 2, tid = threadIdx.x;
+    const size_t base = (size_t)slab * a.n;
+    const float mean = a.mean[slab], rstd = a.rstd[slab];
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = tid; q < n4; q += kThreads) {
+        f32x4 dy = ld4(a.dy + base + 4 * q);
+        const f32x4 u = ld4(a.U + base + 4 * q), s = ld4(a.S + base + 4 * q), ga = ld4(a.gamma + 4 * q);
+        if (a.training) {
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (gate_fwd(u[i], s[i], a.act) - mean) * rstd;
+            const float gg = dy[i] * ga[i];
+            s1 += gg;
+            s2 += gg * xh;
+        }
+    }
+    block_sum2(s1, s2, stgcn_smem);
+    if (tid == 0) {
+        a.c1[slab] = s1 / (float)a.n;
+        a.c2[slab] = s2 / (float)a.n;
+    }
+}
+
+// ================================================================================================
+// B1b: dH = rstd * (g - c1 - xhat * c2), gate backward -> dZ = [dU | dQ]; partial dgamma / dbeta.
+// A thread owns one float4 column of the [N*C] slab and walks `spg` consecutive slabs.
+// grid = (ceil(n/4 / 256), sg)
+// ================================================================================================
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
+    const int n4 = a.n >> 2;
+    const int q = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    if (q >= n4) return;
+    const int sg = blockIdx.y;
+    const int c4n = a.C >> 2;
+    const int node = q / c4n, c4 = q - node * c4n;
+    const f32x4 ga = ld4(a.gamma + 4 * q);
+    f32x4 dg = zero4(), db = zero4();
+    long s0 = (long)sg * a.spg, s1 = s0 + a.spg;
+    if (s1 > a.slabs) s1 = a.slabs;
+    const int N = a.n / a.C;
+    for (long slab = s0; slab < s1; ++slab) {
+        const size_t base = (size_t)slab * a.n + 4 * (size_t)q;
+        f32x4 dy = ld4(a.dy + base);
+        const f32x4 u = ld4(a.U + base), s = ld4(a.S + base);
+        const float mean = a.mean[slab], rstd = a.rstd[slab], c1 = a.c1[slab], c2 = a.c2[slab];
+        if (a.training) {
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+        }
+        f32x4 du, dq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (gate_fwd(u[i], s[i], a.act) - mean) * rstd;
+            const float gg = dy[i] * ga[i];
+            const float dh = rstd * (gg - c1 - xh * c2);
+            dg[i] += dy[i] * xh;
+            db[i] += dy[i];
+            float du_, dq_;
+            gate_bwd(dh, u[i], s[i], a.act, du_, dq_);
+            du[i] = du_;
+            dq[i] = dq_;
+        }
+        float* z = a.dZ + ((size_t)slab * N + node) * (2 * a.C) + 4 * c4;
+        st4(z, du);
+        st4(z + a.C, dq);
+    }
+    st4(a.dgam_part + (size_t)sg * a.n + 4 * (size_t)q, dg);
+    st4(a.dbet_part + (size_t)sg * a.n + 4 * (size_t)q, db);
+}
+
+// ================================================================================================
+// B2/B5: transposed temporal convolution  dX[b,t,n,i] = sum_k sum_o dZ[b,t-k,n,o] W_eff[k*Cin+i][o]
+// as a row-tile GEMM over the implicit matrix [rows = (b,t,n)] x [K = Kt*NC], weights packed by
+// PK_TCONV_BWD.  Optional relu mask (dX *= (G > 0)) for the gradient entering the graph conv.
+// LAYOUT 0: >= 4 n-tiles  (wave w: all 4 m-tiles, n-tiles w + 4j)
+// LAYOUT 1: 1 n-tile      (wave w: m-tile w)
+// LAYOUT 2: 2 n-tiles     (wave w: m-tiles 2*(w>>1) + {0,1}, n-tile w & 1)
+// ================================================================================================
+struct TconvBwdDataArgs {
+    TapSrc ts;            // dZ viewed through Kt taps, dir = -1
+    const float* Wp;      // packed, K = Kt*NC (KCH chunks), cols = roundup16(Cin)
+    int KCH, Cin;
+    const float* Gmask;   // [rows][Cin] or null
+    float* dX;            // [rows][Cin]
+};
+
+template <int WM, int NT, int LAYOUT>
+__global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a) {
+    extern __shared__ float stgcn_smem[];
+    int* rowbase = reinterpret_cast<int*>(stgcn_smem);
+    int* rowt = rowbase + 64;
+    float* At = stgcn_smem + 128;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const long row0 = (long)blockIdx.x * kTileRows;
+    const int mt0 = LAYOUT == 0 ? 0 : (LAYOUT == 1 ? wave : 2 * (wave >> 1));
+    const int nt0 = LAYOUT == 0 ? wave : (LAYOUT == 1 ? 0 : (wave & 1));
+
+    tile_rowinfo(a.ts, row0, rowbase, rowt);
+    __syncthreads();
+
+    f32x4 acc[WM][NT], acc2[WM][NT];   // two accumulator sets (even / odd chunks) for MFMA ILP
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[i][j] = zero4();
+            acc2[i][j] = zero4();
+        }
+    const int KP = a.KCH * 16;
+    for (int k0 = 0; k0 < KP; k0 += kSegMax) {
+        const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+        if (k0 > 0) __syncthreads();
+        tile_load_segment(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        __syncthreads();
+        const int half = (kseg >> 4) >> 1, rest = (kseg >> 4) - half;
+        seg_mma<WM, NT>(acc, At, kseg + 4, mt0, rest, a.Wp, k0 >> 4, a.KCH, nt0, 4);
+        if (half > 0) seg_mma<WM, NT>(acc2, At + rest * 16, kseg + 4, mt0, half, a.Wp, (k0 >> 4) + rest, a.KCH, nt0, 4);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (nt0 + 4 * j) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long R = row0 + (mt0 + i) * 16 + 4 * g + r;
+                if (R < a.ts.rows && col < a.Cin) {
+                    float v = acc[i][j][r] + acc2[i][j][r];
+                    const size_t o = (size_t)R * a.Cin + col;
+                    if (a.Gmask && !(a.Gmask[o] > 0.f)) v = 0.f;
+                    a.dX[o] = v;
+                }
+            }
+        }
+}
+
+// ================================================================================================
+// B3: graph-conv backward on one (b, t) slab, dY = masked upstream gradient:
+//     dW_k = X_k^T dY, db = 1^T dY                       (partials per slab)
+//     G_k = dY W_k^T ; for k = Ks-1..2: G_{k-1} += 2 L^T G_k ; G_{k-2} -= G_k
+//     dA = G_0 + L^T G_1 + dY                            (the + dY is the residual of layers.py:229)
+// Same fragment scheme as gconv_fwd_kernel with the transposed operator LTp.
+// ================================================================================================
+struct GconvBwdArgs {
+    const float* dY;     // [slabs][N][16]
+    const float* X0;     // [slabs][N][16]   (A)
+    const float* Xk;     // [terms-1][slabs][N][16]
+    const float* LTp;    // [NP][NP]
+    const float* W;
+    float* dA;           // [slabs][N][16]
+    float* part;         // [slabs][(terms+1)*256]
+    int N, NP, Ks, kipf;
+    long slabs;
+};
+
+template <int MAXQ>
+__global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const long slab = blockIdx.x;
+    const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, LDY = 20, Ks = a.Ks;
+    float* const GT0 = stgcn_smem;                 // GT(k) = GT0 + k*16*LDX, transposed [c][node]
+    float* const dYs = stgcn_smem + Ks * 16 * LDX; // [NP][LDY] row major
+
+    // ---- stage dY (row major) and all X_k (transposed) -----------------------------------------
+    const float* dYsl = a.dY + (size_t)slab * N * 16;
+    for (int idx = tid; idx < NP * 4; idx += kThreads) {
+        const int n = idx >> 2, c4 = idx & 3;
+        st4(dYs + n * LDY + c4 * 4, n < N ? ld4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
+        for (int k = 0; k < Ks; ++k) {
+            const float* Xsl = (k == 0 ? a.X0 : a.Xk + (size_t)(k - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
+            const f32x4 v = n < N ? ld4(Xsl + (size_t)n * 16 + c4 * 4) : zero4();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) GT0[(k * 16 + c4 * 4 + i) * LDX + n] = v[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- parameter-gradient partials: job kk < Ks -> dW_kk = X_kk^T dY ; kk == Ks -> db via A = 1 ----
+    float* part = a.part + (size_t)slab * (Ks + 1) * 256;
+    for (int kk = wave; kk <= Ks; kk += 4) {
+        f32x4 c0 = zero4(), c1 = zero4();
+        for (int kc = 0; kc < KCH; ++kc) {
+            f32x4 af;
+            if (kk < Ks) af = ld4(GT0 + (kk * 16 + l15) * LDX + kc * 16 + 4 * g);
+            else { af[0] = 1.f; af[1] = 1.f; af[2] = 1.f; af[3] = 1.f; }
+            const float* yb = dYs + (kc * 16 + 4 * g) * LDY + l15;
+            c0 = mfma4(af[0], yb[0], c0);
+            c1 = mfma4(af[1], yb[LDY], c1);
+            c0 = mfma4(af[2], yb[2 * LDY], c0);
+            c1 = mfma4(af[3], yb[3 * LDY], c1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[kk * 256 + (4 * g + r) * 16 + l15] = c0[r] + c1[r];
+    }
+    __syncthreads();   // X_k no longer needed: GT buffers become G_k
+
+    // ---- G_k = dY W_k^T on the owned node tiles -----------------------------------------------------
+    for (int k = 0; k < Ks; ++k) {
+        f32x4 wf = zero4();   // B[kk = j][col = i] = W_k[i = l15][j = 4g + s]
+        if (!(a.kipf && k == 0)) wf = ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g);
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + 4 * q;
+            if (ht < HT) {
+                const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
+                f32x4 d = zero4();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) d = mfma4(af[s], wf[s], d);
+                st4(GT0 + (k * 16 + l15) * LDX + ht * 16 + 4 * g, d);      // D[h = 4g + r][i = l15]
+            }
+        }
+    }
+
+    // ---- reverse Chebyshev recursion --------------------------------------------------------------------
+    for (int k = Ks - 1; k >= 1; --k) {
+        __syncthreads();   // G_k complete
+        const float* Gk = GT0 + k * 16 * LDX;
+        f32x4 acc[MAXQ];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
+        for (int kc = 0; kc < KCH; ++kc) {
+            const f32x4 af = ld4(Gk + l15 * LDX + kc * 16 + 4 * g);
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int ht = wave + 4 * q;
+                if (ht < HT) {
+                    const f32x4 bf = ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + kc * 16 + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[s], acc[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + 4 * q;
+            if (ht < HT) {
+                const int h = ht * 16 + l15;
+                if (k >= 2) {
+                    float* Gm1 = GT0 + (k - 1) * 16 * LDX;
+                    float* Gm2 = GT0 + (k - 2) * 16 * LDX;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Gm1[(4 * g + r) * LDX + h] += 2.0f * acc[q][r];
+                        Gm2[(4 * g + r) * LDX + h] -= Gk[(4 * g + r) * LDX + h];
+                    }
+                } else {   // k == 1: dA = G_0 + L^T G_1 + dY
+                    if (h < N) {
+                        const f32x4 y = ld4(dYs + h * LDY + 4 * g);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + acc[q][r] + y[r];
+                        st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
+                    }
+                }
+            }
+        }
+    }
+    if (Ks == 1) {   // no operator term: dA = G_0 + dY
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + 4 * q;
+            const int h = ht * 16 + l15;
+            if (ht < HT && h < N) {
+                const f32x4 y = ld4(dYs + h * LDY + 4 * g);
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + y[r];
+                st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// B4: backward of the Align(c0 -> c1) 1x1 map and of the first gate:
+//     dH = dA Wa^T ; dZ1 = gate_bwd(dH, U1, S1) ; partial dWa[i][j] = sum H[.,i] dA[.,j], dba = sum dA
+// grid-stride over 64-row tiles; wave w owns column tiles w + 4j of H (NTA = c0 / 64).
+// ================================================================================================
+struct AlignBwdArgs {
+    const float* dA;     // [rows][c1]
+    const float* U;      // [rows][c0]
+    const float* S;
+    const float* WaT;    // packed: K = c1 (KCH chunks), cols = c0
+    float* dZ;           // [rows][2*c0]
+    float* part;         // [wgs][c0*c1 + c1]
+    long rows;
+    int c0, c1, KCH, act;
+};
+
+template <int NTA>
+__global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int c0 = a.c0, c1 = a.c1, LDA = c1 + 4;
+    float* dAt = stgcn_smem;                 // [64][LDA]
+    float* red = stgcn_smem + 64 * LDA;      // [16][c1] for the dba reduction
+    const long tiles = (a.rows + kTileRows - 1) / kTileRows;
+    f32x4 wacc[NTA];                         // partial dWa tile (rows i = coltile*16 + 4g + r, col j = l15); c1 == 16
+#pragma unroll
+    for (int j = 0; j < NTA; ++j) wacc[j] = zero4();
+    float bsum = 0.f;                        // thread (rg = tid >> 4, jj = tid & 15): column jj, rows rg, rg+16, ..
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long row0 = t * kTileRows;
+        __syncthreads();   // previous tile fully consumed
+        for (int idx = tid; idx < kTileRows * (c1 >> 2); idx += kThreads) {
+            const int r = idx / (c1 >> 2), q = idx - r * (c1 >> 2);
+            st4(dAt + r * LDA + 4 * q, row0 + r < a.rows ? ld4(a.dA + (size_t)(row0 + r) * c1 + 4 * q) : zero4());
+        }
+        __syncthreads();
+        {
+            const int rg = tid >> 4, jj = tid & 15;
+            if (jj < c1) bsum += dAt[rg * LDA + jj] + dAt[(rg + 16) * LDA + jj] + dAt[(rg + 32) * LDA + jj] + dAt[(rg + 48) * LDA + jj];
+        }
+        f32x4 acc[4][NTA];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NTA; ++j) acc[i][j] = zero4();
+        seg_mma<4, NTA>(acc, dAt, LDA, 0, a.KCH, a.WaT, 0, a.KCH, wave, 4);
+#pragma unroll
+        for (int j = 0; j < NTA; ++j) {
+            const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long R = row0 + i * 16 + 4 * g + r;
+                    float h = 0.f;
+                    if (R < a.rows) {
+                        const float u = a.U[(size_t)R * c0 + col], s = a.S[(size_t)R * c0 + col];
+                        float du, dq;
+                        gate_bwd(acc[i][j][r], u, s, a.act, du, dq);
+                        a.dZ[(size_t)R * 2 * c0 + col] = du;
+                        a.dZ[(size_t)R * 2 * c0 + c0 + col] = dq;
+                        h = gate_fwd(u, s, a.act);
+                    }
+                    hv[r] = h;
+                }
+                // dWa[i = col][j] += sum_rows H[row][col] dA[row][j] : A[row_op = col (l15)][kk = row 4g+s] = hv[s]
+                const float* bb = dAt + (i * 16 + 4 * g) * LDA + l15;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wacc[j] = mfma4(hv[s], bb[s * LDA], wacc[j]);
+            }
+        }
+    }
+    float* part = a.part + (size_t)blockIdx.x * (c0 * c1 + c1);
+#pragma unroll
+    for (int j = 0; j < NTA; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[((wave + 4 * j) * 16 + 4 * g + r) * c1 + l15] = wacc[j][r];
+    __syncthreads();
+    red[(tid >> 4) * c1 + (tid & 15)] = bsum;
+    __syncthreads();
+    if (tid < c1) {
+        float s = 0.f;
+        for (int rg = 0; rg < 16; ++rg) s += red[rg * c1 + tid];
+        part[c0 * c1 + tid] = s;
+    }
+}
+
+// ================================================================================================
+// B6: weight gradient of a temporal convolution
+//     dW_eff[k*Cin + i][o] = sum_rows x[row + k*N][i] dZ[row][o]      db_eff[o] = sum_rows dZ[row][o]
+// grid = (row chunks, m chunks); the reduction over rows runs in 16-row steps through LDS with the next
+// step's global loads in flight (register prefetch).  Output: per-chunk partials.
+// wave w owns n-tiles w*NTW .. w*NTW+NTW-1 (NTW = NC/64) of all MTW m-tiles of this m-chunk.
+// ================================================================================================
+struct TconvBwdWeightArgs {
+    TapSrc ts;           // x viewed through Kt taps (dir = +1): implicit [rows][K = Kt*Cin]
+    const float* dZ;     // [rows][NC]
+    float* part;         // [chunks][Mpad*NC] ++ [chunks][NC]
+    int NC, Mpad, rows_per_chunk, chunks;
+};
+
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    constexpr int MC = MTW * 16, LDC = MC + 4;
+    const int NC = a.NC, LDZ = NC + 4;
+    float* ct = stgcn_smem;              // [16][LDC]
+    float* zt = stgcn_smem + 16 * LDC;   // [16][LDZ]
+    const int chunk = blockIdx.x, mchunk = blockIdx.y, m0 = mchunk * MC;
+    const long crow0 = (long)chunk * a.rows_per_chunk;
+    long crow1 = crow0 + a.rows_per_chunk;
+    if (crow1 > a.ts.rows) crow1 = a.ts.rows;
+    const int nsteps = (int)((crow1 - crow0 + 15) / 16);
+    const int K = a.ts.taps * a.ts.C;
+    const bool vec = (a.ts.C & 3) == 0;
+    const long per_b = (long)a.ts.Tdst * a.ts.N;
+
+    // staging registers: one float4 (or scalar) of the im2col tile, NZ float4 of the dZ tile per thread
+    constexpr int NZ = NTW;              // 16 * NC / 4 / 256 = NC / 64
+    f32x4 creg = zero4(), zreg[NZ];
+    auto load_regs = [&](int step) {
+        const long r0 = crow0 + (long)step * 16;
+        // im2col element of this thread
+        creg = zero4();
+        if (vec) {
+            const int r = tid / (MC / 4), q = tid - r * (MC / 4);
+            if (r < 16) {
+                const long R = r0 + r;
+                const int kidx = m0 + 4 * q;
+                if (R < crow1 && kidx < K) {
+                    const int b = (int)(R / per_b);
+                    const long rem = R - (long)b * per_b;
+                    const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                    creg = ld4(a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+                }
+            }
+        } else {
+            const int r = tid / MC, q = tid - r * MC;
+            if (r < 16) {
+                const long R = r0 + r;
+                const int kidx = m0 + q;
+                if (R < crow1 && kidx < K) {
+                    const int b = (int)(R / per_b);
+                    const long rem = R - (long)b * per_b;
+                    const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                    creg[0] = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+                }
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            const int idx = tid + z * kThreads;
+            const int r = idx / (NC / 4), q = idx - r * (NC / 4);
+            const long R = r0 + r;
+            zreg[z] = R < crow1 ? ld4(a.dZ + (size_t)R * NC + 4 * q) : zero4();
+        }
+    };
+    auto store_regs = [&]() {
+        if (vec) {
+            const int r = tid / (MC / 4), q = tid - r * (MC / 4);
+            if (r < 16) st4(ct + r * LDC + 4 * q, creg);
+        } else {
+            const int r = tid / MC, q = tid - r * MC;
+            if (r < 16) ct[r * LDC + q] = creg[0];
+        }
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            const int idx = tid + z * kThreads;
+            const int r = idx / (NC / 4), q = idx - r * (NC / 4);
+            st4(zt + r * LDZ + 4 * q, zreg[z]);
+        }
+    };
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = zero4();
+    // bias partial: NC columns, tpc = 256 / NC threads per column (NC = 128 -> 2, NC = 256 -> 1)
+    const int tpc = kThreads / NC, bcol = tid % NC, bpart = tid / NC, rpt = 16 / tpc;
+    float bsum = 0.f;
+
+    if (nsteps > 0) load_regs(0);
+    for (int step = 0; step < nsteps; ++step) {
+        if (step > 0) __syncthreads();   // previous step's tiles consumed
+        store_regs();
+        __syncthreads();
+        if (step + 1 < nsteps) load_regs(step + 1);
+        if (mchunk == 0) {
+            for (int r = 0; r < rpt; ++r) bsum += zt[(bpart * rpt + r) * LDZ + bcol];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float av[MTW], bv[NTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) av[i] = ct[(4 * g + s) * LDC + i * 16 + l15];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bv[j] = zt[(4 * g + s) * LDZ + (wave * NTW + j) * 16 + l15];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+        }
+    }
+    float* part = a.part + (size_t)chunk * a.Mpad * NC;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)(m0 + i * 16 + 4 * g + r) * NC + (wave * NTW + j) * 16 + l15] = acc[i][j][r];
+    if (mchunk == 0) {
+        float* bp = a.part + (size_t)a.chunks * a.Mpad * NC + (size_t)chunk * NC;
+        if (tpc == 1) bp[bcol] = bsum;
+        else {
+            __syncthreads();
+            stgcn_smem[tid] = bsum;
+            __syncthreads();
+            if (tid < NC) {
+                float s = 0.f;
+                for (int p = 0; p < tpc; ++p) s += stgcn_smem[p * NC + tid];
+                bp[tid] = s;
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// Final deterministic reduction of the partials into gradients laid out like the reference's parameters.
+// Each job: dst[d0][d1][d2] = sum_p src[p*pstride + d0*s0 + d1*s1 + d2*s2]
+// ================================================================================================
+struct ReduceJob {
+    const float* src;
+    float* dst;
+    int P;
+    long pstride;
+    int n0, n1, n2;
+    long s0, s1, s2;
+};
+constexpr int kMaxReduceJobs = 16;
+struct ReduceArgs {
+    ReduceJob job[kMaxReduceJobs];
+    int start[kMaxReduceJobs + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
+    int jb = 0;
+    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
+    const ReduceJob& j = a.job[jb];
+    const long e = ((long)blockIdx.x - a.start[jb]) * kThreads + threadIdx.x;
+    const long n = (long)j.n0 * j.n1 * j.n2;
+    if (e >= n) return;
+    const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
+    const float* s = j.src + d0 * j.s0 + d1 * j.s1 + d2 * j.s2;
+    float acc = 0.f;
+    for (int p = 0; p < j.P; ++p) acc += s[(size_t)p * j.pstride];
+    j.dst[e] = acc;
+}
+
+}  // namespace stgcn
