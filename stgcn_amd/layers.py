@@ -1,0 +1,251 @@
+"""Drop-in operator modules: same class names, constructor signatures, parameter names/shapes
+(``state_dict`` keys) and initialisation order as the reference's ``model/layers.py``, so that the
+reference's ``main.py`` / checkpoints work unchanged -- but ``STConvBlock.forward`` is ONE fused HIP
+operator (fwd) + ONE (bwd) on MI355X instead of ~60 ATen launches.
+
+Reference map (hazdzz/STGCN, model/layers.py):
+    Align :7-23 | CausalConv2d :40-57 | TemporalConvLayer :59-120 | ChebGraphConv :122-172 |
+    GraphConv :174-206 | GraphConvLayer :208-231 | STConvBlock :233-258 | OutputBlock :260-284
+
+The sub-layer modules own the parameters (that is what fixes the checkpoint keys).  Their own
+``forward`` methods are plain tensor expressions kept for API completeness and for the output head
+(``OutputBlock`` -- SURVEY.md section 8f "next #1": it still runs as stock PyTorch-ROCm ops); the ST blocks never
+call them -- ``STConvBlock.forward`` hands the parameter pointers to ``stgcn_stblock_forward``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.init as init
+
+from . import ops
+
+
+class DropoutStream:
+    """Seed / running offset of the counter-based dropout RNG (Philox4x32-10 inside the kernels).
+    Every training forward of every block consumes one offset, so masks never repeat; the trainer
+    gives each data-parallel rank its own seed."""
+    seed: int = 0x5EED5EED
+    _offset: int = 0
+
+    @classmethod
+    def manual_seed(cls, seed: int):
+        cls.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cls._offset = 0
+
+    @classmethod
+    def next_offset(cls) -> int:
+        cls._offset += 1
+        return cls._offset
+
+
+class Align(nn.Module):
+    """Channel matcher of the residual branches (layers.py:7-23).  The 1x1 conv is always
+    allocated, exactly like the reference, even when the pad / identity branch is taken."""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.c_in = c_in
+        self.c_out = c_out
+        self.align_conv = nn.Conv2d(in_channels=c_in, out_channels=c_out, kernel_size=(1, 1))
+
+    def forward(self, x):
+        if self.c_in > self.c_out:
+            return self.align_conv(x)
+        if self.c_in < self.c_out:
+            return F.pad(x, (0, 0, 0, 0, 0, self.c_out - self.c_in))
+        return x
+
+
+class CausalConv2d(nn.Conv2d):
+    """layers.py:40-57.  In this model it is always built with enable_padding=False, i.e. a valid
+    (Kt x 1) convolution along time."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, enable_padding=False, dilation=1, groups=1, bias=True):
+        kernel_size = nn.modules.utils._pair(kernel_size)
+        stride = nn.modules.utils._pair(stride)
+        dilation = nn.modules.utils._pair(dilation)
+        if enable_padding:
+            self._left = [int((kernel_size[i] - 1) * dilation[i]) for i in range(len(kernel_size))]
+        else:
+            self._left = None
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=0, dilation=dilation, groups=groups, bias=bias)
+
+    def forward(self, input):
+        if self._left is not None:
+            input = F.pad(input, (self._left[1], 0, self._left[0], 0))
+        return super().forward(input)
+
+
+class TemporalConvLayer(nn.Module):
+    """Gated causal temporal convolution (layers.py:59-120)."""
+
+    def __init__(self, Kt, c_in, c_out, n_vertex, act_func):
+        super().__init__()
+        self.Kt = Kt
+        self.c_in = c_in
+        self.c_out = c_out
+        self.n_vertex = n_vertex
+        self.align = Align(c_in, c_out)
+        gated = act_func in ("glu", "gtu")
+        self.causal_conv = CausalConv2d(in_channels=c_in, out_channels=2 * c_out if gated else c_out, kernel_size=(Kt, 1),
+                                        enable_padding=False, dilation=1)
+        self.act_func = act_func
+
+    def forward(self, x):
+        x_in = self.align(x)[:, :, self.Kt - 1:, :]
+        z = self.causal_conv(x)
+        if self.act_func in ("glu", "gtu"):
+            p, q = z[:, :self.c_out], z[:, -self.c_out:]
+            if self.act_func == "glu":
+                return (p + x_in) * torch.sigmoid(q)
+            return torch.tanh(p + x_in) * torch.sigmoid(q)
+        if self.act_func == "relu":
+            return torch.relu(z + x_in)
+        if self.act_func == "silu":
+            return F.silu(z + x_in)
+        raise NotImplementedError(f"ERROR: The activation function {self.act_func} is not implemented.")
+
+
+def _init_graph_weight(weight, bias):
+    """layers.py:136-141 / :187-192."""
+    init.kaiming_uniform_(weight, a=math.sqrt(5))
+    if bias is not None:
+        fan_in, _ = init._calculate_fan_in_and_fan_out(weight)
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        init.uniform_(bias, -bound, bound)
+
+
+class ChebGraphConv(nn.Module):
+    """layers.py:122-172.  Parameters are created on the CPU like the reference's FloatTensor."""
+
+    def __init__(self, c_in, c_out, Ks, gso, bias):
+        super().__init__()
+        self.c_in, self.c_out, self.Ks, self.gso = c_in, c_out, Ks, gso
+        self.weight = nn.Parameter(torch.empty(Ks, c_in, c_out, dtype=torch.float32, device="cpu"))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(c_out, dtype=torch.float32, device="cpu"))
+        else:
+            self.register_parameter("bias", None)
+        _init_graph_weight(self.weight, self.bias)
+
+    def forward(self, x):
+        x = x.permute(0, 2, 3, 1)
+        if self.Ks - 1 < 0:
+            raise ValueError(f"ERROR: the graph convolution kernel size Ks has to be a positive integer, but received {self.Ks}.")
+        terms = [x]
+        if self.Ks >= 2:
+            terms.append(torch.einsum("hi,btij->bthj", self.gso, x))
+        for k in range(2, self.Ks):
+            terms.append(2 * torch.einsum("hi,btij->bthj", self.gso, terms[k - 1]) - terms[k - 2])
+        out = torch.einsum("btkhi,kij->bthj", torch.stack(terms, dim=2), self.weight)
+        return out + self.bias if self.bias is not None else out
+
+
+class GraphConv(nn.Module):
+    """layers.py:174-206."""
+
+    def __init__(self, c_in, c_out, gso, bias):
+        super().__init__()
+        self.c_in, self.c_out, self.gso = c_in, c_out, gso
+        self.weight = nn.Parameter(torch.empty(c_in, c_out, dtype=torch.float32, device="cpu"))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(c_out, dtype=torch.float32, device="cpu"))
+        else:
+            self.register_parameter("bias", None)
+        _init_graph_weight(self.weight, self.bias)
+
+    def forward(self, x):
+        x = x.permute(0, 2, 3, 1)
+        out = torch.einsum("bthi,ij->bthj", torch.einsum("hi,btij->bthj", self.gso, x), self.weight)
+        return out + self.bias if self.bias is not None else out
+
+
+class GraphConvLayer(nn.Module):
+    """layers.py:208-231."""
+
+    def __init__(self, graph_conv_type, c_in, c_out, Ks, gso, bias):
+        super().__init__()
+        self.graph_conv_type = graph_conv_type
+        self.c_in, self.c_out = c_in, c_out
+        self.align = Align(c_in, c_out)
+        self.Ks = Ks
+        self.gso = gso
+        if graph_conv_type == "cheb_graph_conv":
+            self.cheb_graph_conv = ChebGraphConv(c_out, c_out, Ks, gso, bias)
+        elif graph_conv_type == "graph_conv":
+            self.graph_conv = GraphConv(c_out, c_out, gso, bias)
+
+    def forward(self, x):
+        x_in = self.align(x)
+        conv = self.cheb_graph_conv if self.graph_conv_type == "cheb_graph_conv" else self.graph_conv
+        return conv(x_in).permute(0, 3, 1, 2) + x_in
+
+
+class STConvBlock(nn.Module):
+    """'TGTND' block (layers.py:233-258) as one fused HIP operator.
+
+    Constructor signature and parameter tree are the reference's; ``forward`` accepts the logical
+    (B, C, T, N) tensor with any strides and returns logical (B, channels[2], T - 2(Kt-1), N).
+    """
+
+    def __init__(self, Kt, Ks, n_vertex, last_block_channel, channels, act_func, graph_conv_type, gso, bias, droprate):
+        super().__init__()
+        self.tmp_conv1 = TemporalConvLayer(Kt, last_block_channel, channels[0], n_vertex, act_func)
+        self.graph_conv = GraphConvLayer(graph_conv_type, channels[0], channels[1], Ks, gso, bias)
+        self.tmp_conv2 = TemporalConvLayer(Kt, channels[1], channels[2], n_vertex, act_func)
+        self.tc2_ln = nn.LayerNorm([n_vertex, channels[2]], eps=1e-12)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(p=droprate)
+        self.cfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=n_vertex, c_in=last_block_channel, channels=tuple(channels),
+                                   act_func=act_func, graph_conv_type=graph_conv_type, droprate=float(droprate),
+                                   ln_eps=self.tc2_ln.eps)
+        self.gso = gso                      # plain attribute like the reference: not in state_dict, not moved by .to()
+        self._gso_cache = None              # (key, padded, padded transposed)
+        self._ws = ops.WorkspaceCache()
+
+    def _operators(self, device):
+        gso = self.gso
+        key = (gso.data_ptr(), gso._version, str(device))
+        if self._gso_cache is None or self._gso_cache[0] != key:
+            gp, gt = ops.gso_prepare(gso.to(device))
+            self._gso_cache = (key, gp, gt)
+        return self._gso_cache[1], self._gso_cache[2]
+
+    def _params(self):
+        gc = self.graph_conv.cheb_graph_conv if self.cfg.graph_conv_type == "cheb_graph_conv" else self.graph_conv.graph_conv
+        t1, t2, al = self.tmp_conv1, self.tmp_conv2, self.graph_conv.align.align_conv
+        return [t1.causal_conv.weight, t1.causal_conv.bias, t1.align.align_conv.weight, t1.align.align_conv.bias,
+                al.weight, al.bias, gc.weight, gc.bias,
+                t2.causal_conv.weight, t2.causal_conv.bias, t2.align.align_conv.weight, t2.align.align_conv.bias,
+                self.tc2_ln.weight, self.tc2_ln.bias]
+
+    def forward(self, x):
+        gp, gt = self._operators(x.device)
+        training = self.training and self.cfg.droprate > 0.0
+        offset = DropoutStream.next_offset() if training else 0
+        return ops.st_conv_block(x, gp, gt, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws)
+
+
+class OutputBlock(nn.Module):
+    """'TNFF' head (layers.py:260-284).  Still stock PyTorch-ROCm ops."""
+
+    def __init__(self, Ko, last_block_channel, channels, end_channel, n_vertex, act_func, bias, droprate):
+        super().__init__()
+        self.tmp_conv1 = TemporalConvLayer(Ko, last_block_channel, channels[0], n_vertex, act_func)
+        self.fc1 = nn.Linear(in_features=channels[0], out_features=channels[1], bias=bias)
+        self.fc2 = nn.Linear(in_features=channels[1], out_features=end_channel, bias=bias)
+        self.tc1_ln = nn.LayerNorm([n_vertex, channels[0]], eps=1e-12)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(p=droprate)
+
+    def forward(self, x):
+        x = self.tmp_conv1(x)
+        x = self.tc1_ln(x.permute(0, 2, 3, 1))
+        x = self.fc1(x)
+        x = self.relu(x)
+        x = self.dropout(x)
+        return self.fc2(x).permute(0, 3, 1, 2)

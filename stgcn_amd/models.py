@@ -1,0 +1,58 @@
+"""Drop-in model classes: ``STGCNChebGraphConv(args, blocks, n_vertex)`` and
+``STGCNGraphConv(args, blocks, n_vertex)`` with the reference's signatures, attribute names and
+``state_dict`` keys (hazdzz/STGCN model/models.py:28-53 and :78-103), assembled from the fused
+``layers.STConvBlock``.  Input (B, 1, n_his, N) -> output (B, 1, 1, N) as at main.py:166.
+
+``args`` needs exactly the attributes the reference reads (models.py:32-42): Kt, Ks, act_func,
+graph_conv_type, gso, enable_bias, droprate, n_his.
+"""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from . import layers
+
+
+class _STGCNBase(nn.Module):
+    def __init__(self, args, blocks, n_vertex):
+        super().__init__()
+        n_st = len(blocks) - 3
+        self.st_blocks = nn.Sequential(*[
+            layers.STConvBlock(args.Kt, args.Ks, n_vertex, blocks[l][-1], blocks[l + 1], args.act_func,
+                               args.graph_conv_type, args.gso, args.enable_bias, args.droprate)
+            for l in range(n_st)])
+        self.Ko = args.n_his - n_st * 2 * (args.Kt - 1)
+        if self.Ko > 1:
+            self.output = layers.OutputBlock(self.Ko, blocks[-3][-1], blocks[-2], blocks[-1][0], n_vertex,
+                                             args.act_func, args.enable_bias, args.droprate)
+        elif self.Ko == 0:
+            self.fc1 = nn.Linear(in_features=blocks[-3][-1], out_features=blocks[-2][0], bias=args.enable_bias)
+            self.fc2 = nn.Linear(in_features=blocks[-2][0], out_features=blocks[-1][0], bias=args.enable_bias)
+            self.relu = nn.ReLU()
+            self._make_dropout(args.droprate)
+        # Ko == 1: like the reference, no head at all (models.py:46-51)
+
+    def _make_dropout(self, p):
+        self.dropout = nn.Dropout(p=p)
+
+    def forward(self, x):
+        x = self.st_blocks(x)
+        if self.Ko > 1:
+            x = self.output(x)
+        elif self.Ko == 0:
+            x = self.fc1(x.permute(0, 2, 3, 1))
+            x = self.relu(x)
+            x = self.fc2(x).permute(0, 3, 1, 2)
+        return x
+
+
+class STGCNChebGraphConv(_STGCNBase):
+    """'TGTND TGTND TNFF' with Chebyshev graph convolution (models.py:6-53)."""
+
+
+class STGCNGraphConv(_STGCNBase):
+    """Same structure with the first-order (Kipf) graph convolution (models.py:55-103); the reference
+    names the unused Ko == 0 dropout ``do`` in this class (models.py:92)."""
+
+    def _make_dropout(self, p):
+        self.do = nn.Dropout(p=p)

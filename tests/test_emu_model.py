@@ -1,0 +1,62 @@
+"""Whole drop-in model on the CPU emulator vs golden fixtures produced by the reference itself:
+state_dict contract (load_state_dict strict), eval forward, loss + every gradient."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from stgcn_amd import models
+from tests.emu_util import bind_emulator
+from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture, maxabs
+
+
+def _build(name):
+    bind_emulator()
+    fx = load_fixture(name)
+    cfg = cfg_from_fixture(fx)
+    gso = torch.from_numpy(fixture_gso(name, fx))
+    args = types.SimpleNamespace(Kt=cfg.Kt, Ks=cfg.Ks, act_func=cfg.act_func, graph_conv_type=cfg.graph_conv_type, gso=gso,
+                                 enable_bias=True, droprate=cfg.droprate, n_his=cfg.n_his)
+    cls = models.STGCNChebGraphConv if cfg.graph_conv_type == "cheb_graph_conv" else models.STGCNGraphConv
+    model = cls(args, cfg.blocks, int(fx["n_vertex"]))
+    model.load_state_dict(fixture_params(fx, cfg, torch.float32), strict=True)
+    rs = np.random.RandomState(int(fx["seed"]) + 1)
+    B, N = int(fx["B"]), int(fx["n_vertex"])
+    x = torch.from_numpy(rs.standard_normal((B, 1, cfg.n_his, N))).float()
+    y = torch.from_numpy(rs.standard_normal((B, N))).float()
+    return fx, model, x, y
+
+
+@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32"])
+def test_model_matches_reference_golden(name):
+    fx, model, x, y = _build(name)
+    model.eval()
+    blocks = []
+    hooks = [b.register_forward_hook(lambda m, i, o: blocks.append(o.detach())) for b in model.st_blocks]
+    with torch.no_grad():
+        out = model(x)
+    for h in hooks:
+        h.remove()
+    assert out.shape == fx["eval.out"].shape
+    for l, b in enumerate(blocks):
+        assert maxabs(b.numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"      # north-star bar: 1e-4 abs
+    assert maxabs(out.numpy(), fx["eval.out"]) <= 1e-4
+
+    model.train()          # fixtures were generated with droprate 0 -> deterministic
+    model.zero_grad()
+    loss = torch.nn.MSELoss()(model(x).view(len(x), -1), y)
+    loss.backward()
+    assert abs(loss.item() - float(fx["train.loss"])) <= 1e-4 * abs(float(fx["train.loss"]))
+    nograd = set(str(s) for s in fx["nograd"])
+    for k, prm in model.named_parameters():
+        if k in nograd:
+            assert prm.grad is None, f"{k}: the reference leaves .grad None"
+            continue
+        assert prm.grad is not None, k
+        ref = fx["gradsum." + k]
+        ga = float(prm.grad.double().abs().sum())
+        assert abs(ga - ref[1]) <= 1e-3 * ref[1] + 1e-9, k          # north-star bar for gradients: rtol 1e-3
+        if ("grad." + k) in fx:
+            r = fx["grad." + k]
+            assert maxabs(prm.grad.numpy(), r) <= 1e-3 * max(1e-30, float(np.abs(r).max())) + 1e-7, k
