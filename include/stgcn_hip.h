@@ -130,6 +130,12 @@ int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_p
 /* out[e] = 0 or 1/(1-p): the keep-scale the forward applies to element e of y (n multiple of 4).     */
 int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream);
 
+/* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
+ * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the
+ * recorded events, writes {"<kernel label>": {"calls": n, "total_ms": t}, ...} as JSON and resets.      */
+int stgcn_profile_enable(int on);
+int stgcn_profile_collect(char* json_buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,10 @@ class _Lib:
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
                                              C.c_uint64, C.c_uint64, C.c_void_p]
         d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]
+        d.stgcn_profile_enable.argtypes = [C.c_int]
+        d.stgcn_profile_enable.restype = C.c_int
+        d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]
+        d.stgcn_profile_collect.restype = C.c_int
         for f in ("stgcn_stblock_plan_query", "stgcn_gso_prepare", "stgcn_stblock_forward", "stgcn_stblock_backward",
                   "stgcn_dropout_mask"):
             getattr(d, f).restype = C.c_int
@@ -109,4 +113,5 @@ def lib() -> _Lib:
 
 
 EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
-                    "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask"]
+                    "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
+                    "stgcn_profile_collect"]

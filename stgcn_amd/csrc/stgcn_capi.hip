@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "stgcn_kernels_bwd.hip.h"
@@ -25,6 +26,43 @@ int fail(int code, const char* fmt, ...) {
 
 inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-kernel timing: hipEvent pairs around every launch (off by default) ---------------
+struct ProfSlot { const char* name; hipEvent_t e0, e1; };
+constexpr int kProfMax = 8192;
+ProfSlot* g_prof = nullptr;
+int g_prof_n = 0, g_prof_on = 0, g_prof_cap = 0;
+
+inline int prof_begin(const char* name, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    if (g_prof_n >= g_prof_cap) {
+        if (g_prof_cap >= kProfMax) return -1;
+        if (!g_prof) g_prof = (ProfSlot*)calloc(kProfMax, sizeof(ProfSlot));
+        const int grow = g_prof_cap + 256 > kProfMax ? kProfMax : g_prof_cap + 256;
+        for (int i = g_prof_cap; i < grow; ++i) {
+            hipEventCreate(&g_prof[i].e0);
+            hipEventCreate(&g_prof[i].e1);
+        }
+        g_prof_cap = grow;
+    }
+    const int i = g_prof_n++;
+    g_prof[i].name = name;
+    hipEventRecord(g_prof[i].e0, st);
+    return i;
+}
+inline void prof_end(int i, hipStream_t st) {
+    if (i >= 0) hipEventRecord(g_prof[i].e1, st);
+}
+
+// every kernel launch of the library goes through this macro
+#define STGCN_LAUNCH(label, st, kernel, grid, block, lds, ...)                                    \
+    do {                                                                                          \
+        const int pi_ = prof_begin(label, st);                                                    \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                            \
+        prof_end(pi_, st);                                                                        \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) return fail(STGCN_ERR_LAUNCH, "%s: %s", label, hipGetErrorString(e_)); \
+    } while (0)
 
 #define STGCN_CHECK_LAUNCH(name)                                                                  \
     do {                                                                                          \
@@ -111,39 +149,39 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
         d->Kt * v.NC2 / 16);
     add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
     pa.njobs = nj;
-    hipLaunchKernelGGL(pack_kernel, dim3(pa.start[nj]), dim3(kThreads), 0, st, pa);
-    STGCN_CHECK_LAUNCH("pack_kernel");
+    STGCN_LAUNCH("pack", st, pack_kernel, dim3(pa.start[nj]), dim3(kThreads), 0, pa);
     return STGCN_OK;
 }
 
-template <int NT>
-void launch_tconv_fwd(const TconvFwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((tconv_fwd_kernel<NT>), dim3(cdiv(a.ts.rows, kTileRows)), dim3(kThreads), kTileLdsFloats * sizeof(float), st, a);
+int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
+    const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
+    const size_t lds = kTileLdsFloats * sizeof(float);
+    if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2>), grid, blk, lds, a);
+    else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4>), grid, blk, lds, a);
+    return STGCN_OK;
 }
 
 int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
     const int HT = a.NP / 16, maxq = (HT + 3) / 4;
     const size_t lds = (size_t)3 * 16 * (a.NP + 4) * sizeof(float);
     const dim3 grid((unsigned)a.slabs), blk(kThreads);
-    if (maxq <= 1) hipLaunchKernelGGL((gconv_fwd_kernel<1>), grid, blk, lds, st, a);
-    else if (maxq <= 2) hipLaunchKernelGGL((gconv_fwd_kernel<2>), grid, blk, lds, st, a);
-    else if (maxq <= 4) hipLaunchKernelGGL((gconv_fwd_kernel<4>), grid, blk, lds, st, a);
-    else if (maxq <= 6) hipLaunchKernelGGL((gconv_fwd_kernel<6>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((gconv_fwd_kernel<8>), grid, blk, lds, st, a);
-    STGCN_CHECK_LAUNCH("gconv_fwd_kernel");
+    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2>), grid, blk, lds, a);
+    else if (maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4>), grid, blk, lds, a);
+    else if (maxq <= 6) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<6>), grid, blk, lds, a);
+    else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<8>), grid, blk, lds, a);
     return STGCN_OK;
 }
 
 
-int launch_bwd_data(const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
+int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
     const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
     const size_t lds = kTileLdsFloats * sizeof(float);
-    if (ntt == 1) hipLaunchKernelGGL((tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, st, a);
-    else if (ntt == 2) hipLaunchKernelGGL((tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, st, a);
-    else if (ntt == 4) hipLaunchKernelGGL((tconv_bwd_data_kernel<4, 1, 0>), grid, blk, lds, st, a);
-    else if (ntt == 8) hipLaunchKernelGGL((tconv_bwd_data_kernel<4, 2, 0>), grid, blk, lds, st, a);
+    if (ntt == 1) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, a);
+    else if (ntt == 2) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, a);
+    else if (ntt == 4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<4, 1, 0>), grid, blk, lds, a);
+    else if (ntt == 8) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<4, 2, 0>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "backward-data with %d input channel tiles (supported: 1, 2, 4, 8)", ntt);
-    STGCN_CHECK_LAUNCH("tconv_bwd_data_kernel");
     return STGCN_OK;
 }
 
@@ -152,33 +190,31 @@ int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
     const dim3 grid((unsigned)a.slabs), blk(kThreads);
-    if (maxq <= 1) hipLaunchKernelGGL((gconv_bwd_kernel<1>), grid, blk, lds, st, a);
-    else if (maxq <= 2) hipLaunchKernelGGL((gconv_bwd_kernel<2>), grid, blk, lds, st, a);
-    else if (maxq <= 4) hipLaunchKernelGGL((gconv_bwd_kernel<4>), grid, blk, lds, st, a);
-    else if (maxq <= 6) hipLaunchKernelGGL((gconv_bwd_kernel<6>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((gconv_bwd_kernel<8>), grid, blk, lds, st, a);
-    STGCN_CHECK_LAUNCH("gconv_bwd_kernel");
+    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2>), grid, blk, lds, a);
+    else if (maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4>), grid, blk, lds, a);
+    else if (maxq <= 6) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<6>), grid, blk, lds, a);
+    else STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<8>), grid, blk, lds, a);
     return STGCN_OK;
 }
 
 template <int MTW>
-void launch_bwd_weight_n(const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
+int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     const dim3 grid(w.chunks, w.mchunks), blk(kThreads);
     size_t lds = (size_t)16 * ((MTW * 16 + 4) + (a.NC + 4)) * sizeof(float);
     if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
-    if (a.NC == 128) hipLaunchKernelGGL((tconv_bwd_weight_kernel<MTW, 2>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((tconv_bwd_weight_kernel<MTW, 4>), grid, blk, lds, st, a);
+    if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2>), grid, blk, lds, a);
+    else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4>), grid, blk, lds, a);
+    return STGCN_OK;
 }
-int launch_bwd_weight(const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
+int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     if (a.NC != 128 && a.NC != 256) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient with %d output channels", a.NC);
     switch (w.MTW) {
-        case 1: launch_bwd_weight_n<1>(a, w, st); break;
-        case 2: launch_bwd_weight_n<2>(a, w, st); break;
-        case 3: launch_bwd_weight_n<3>(a, w, st); break;
-        default: launch_bwd_weight_n<4>(a, w, st); break;
+        case 1: return launch_bwd_weight_n<1>(label, a, w, st);
+        case 2: return launch_bwd_weight_n<2>(label, a, w, st);
+        case 3: return launch_bwd_weight_n<3>(label, a, w, st);
+        default: return launch_bwd_weight_n<4>(label, a, w, st);
     }
-    STGCN_CHECK_LAUNCH("tconv_bwd_weight_kernel");
-    return STGCN_OK;
 }
 }  // namespace
 
@@ -187,6 +223,41 @@ extern "C" {
 int stgcn_version(void) { return 1; }
 const char* stgcn_backend(void) { return STGCN_BACKEND_NAME; }
 const char* stgcn_last_error(void) { return g_err; }
+
+int stgcn_profile_enable(int on) {
+    g_prof_on = on ? 1 : 0;
+    if (on) g_prof_n = 0;
+    return STGCN_OK;
+}
+
+int stgcn_profile_collect(char* buf, size_t cap) {
+    if (!buf || cap < 64) return fail(STGCN_ERR_INVALID, "stgcn_profile_collect: buffer too small");
+    struct Agg { const char* name; int calls; double ms; };
+    Agg agg[64];
+    int na = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        hipEventSynchronize(g_prof[i].e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
+        int k = 0;
+        for (; k < na; ++k)
+            if (strcmp(agg[k].name, g_prof[i].name) == 0) break;
+        if (k == na) {
+            if (na == 64) continue;
+            agg[na].name = g_prof[i].name; agg[na].calls = 0; agg[na].ms = 0.0;
+            ++na;
+        }
+        agg[k].calls++;
+        agg[k].ms += ms;
+    }
+    size_t o = 0;
+    o += snprintf(buf + o, cap - o, "{");
+    for (int k = 0; k < na && o + 96 < cap; ++k)
+        o += snprintf(buf + o, cap - o, "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", k ? ", " : "", agg[k].name, agg[k].calls, agg[k].ms);
+    snprintf(buf + o, cap - o, "}");
+    g_prof_n = 0;
+    return STGCN_OK;
+}
 
 int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p) {
     int rc = check_desc(d);
@@ -233,18 +304,16 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
 int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream) {
     if (!gso || !gso_pad || !gso_t_pad || N < 1) return fail(STGCN_ERR_INVALID, "stgcn_gso_prepare: bad arguments");
     const int NP = (int)rup(N, 16);
-    hipLaunchKernelGGL(gso_pad_kernel, dim3(cdiv((int64_t)NP * NP, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, gso, (int)N, NP,
-                       gso_pad, gso_t_pad);
-    STGCN_CHECK_LAUNCH("gso_pad_kernel");
+    STGCN_LAUNCH("gso_pad", (hipStream_t)stream, gso_pad_kernel, dim3(cdiv((int64_t)NP * NP, kThreads)), dim3(kThreads), 0, gso, (int)N,
+                 NP, gso_pad, gso_t_pad);
     return STGCN_OK;
 }
 
 int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream) {
     if (!out || n < 0 || (n & 3)) return fail(STGCN_ERR_INVALID, "stgcn_dropout_mask: n must be a non-negative multiple of 4");
     if (n == 0) return STGCN_OK;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n / 4, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, out, (long)(n / 4), seed,
-                       offset, drop_thresh(droprate), 1.0f / (1.0f - droprate));
-    STGCN_CHECK_LAUNCH("dropout_mask_kernel");
+    STGCN_LAUNCH("dropout_mask", (hipStream_t)stream, dropout_mask_kernel, dim3(cdiv(n / 4, kThreads)), dim3(kThreads), 0, out,
+                 (long)(n / 4), seed, offset, drop_thresh(droprate), 1.0f / (1.0f - droprate));
     return STGCN_OK;
 }
 
@@ -273,8 +342,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
     t1.U = saved + pl.sv_U1; t1.S = saved + pl.sv_S1; t1.H = nullptr;
     t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;
-    if (d->c0 == 64) launch_tconv_fwd<2>(t1, st); else launch_tconv_fwd<4>(t1, st);
-    STGCN_CHECK_LAUNCH("tconv_fwd_kernel(tmp_conv1)");
+    rc = launch_tconv_fwd("tconv_fwd.tc1", t1, st);
+    if (rc) return rc;
 
     // ---- graph conv + residual + relu -----------------------------------------------------------
     GconvFwdArgs gc;
@@ -292,8 +361,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     t2.ts.rows = v.rows2;
     t2.Wp = ws + pl.ws_W2p; t2.bias = ws + pl.ws_b2; t2.KCH = v.KP2 / 16; t2.Cout = d->c2; t2.act = d->act;
     t2.U = saved + pl.sv_U2; t2.S = saved + pl.sv_S2;
-    if (d->c2 == 64) launch_tconv_fwd<2>(t2, st); else launch_tconv_fwd<4>(t2, st);
-    STGCN_CHECK_LAUNCH("tconv_fwd_kernel(tmp_conv2)");
+    rc = launch_tconv_fwd("tconv_fwd.tc2", t2, st);
+    if (rc) return rc;
 
     // ---- LayerNorm([N, c2]) + dropout ----------------------------------------------------------------
     LnFwdArgs ln;
@@ -303,8 +372,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     ln.n = d->N * d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
     ln.eps = d->ln_eps; ln.keep_scale = 1.0f / (1.0f - d->droprate); ln.thresh = drop_thresh(d->droprate);
     ln.seed = seed; ln.offset = offset;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)v.slabs2), dim3(kThreads), 64, st, ln);
-    STGCN_CHECK_LAUNCH("ln_fwd_kernel");
+    STGCN_LAUNCH("ln_fwd", st, ln_fwd_kernel, dim3((unsigned)v.slabs2), dim3(kThreads), 64, ln);
     return STGCN_OK;
 }
 

@@ -1,0 +1,67 @@
+"""-m gpu: the fused ST-Conv block on a real MI355X, every stage against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import real_gso
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 21, 2, 7, True),
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 6, True),
+    (64, (64, 16, 64), 3, 3, "graph_conv", "gtu", 35, 1, 5, False),
+    (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5, True),
+    (32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False),
+    (128, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 10, 1, 5, True),
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 1, 1, 5, True),        # single vertex
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 300, 1, 5, False),      # 19 node tiles (MAXQ 6 path), ragged rows
+]
+
+
+@pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T,training", SMALL)
+def test_small_cases(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
+    from tests.gpu_util import assert_errors, run_block_case
+    assert_errors(run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training))
+
+
+@pytest.mark.parametrize("blk", [0, 1])
+@pytest.mark.parametrize("training", [False, True])
+def test_c2_full_size(blk, training):
+    """BASELINE.json configs[1] at full size: METR-LA 207 nodes (real GSO), bs 32, both ST blocks."""
+    from tests.gpu_util import assert_errors, run_block_case
+    gso = real_gso("metr_la.cheb_sym_norm_lap")
+    c_in, T = ((1, 12), (64, 8))[blk]
+    assert_errors(run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, training, gso=gso))
+
+
+def test_c1_shapes_kipf():
+    """BASELINE.json configs[0] shapes (PeMSD7(M) 228 nodes, graph_conv, bs 8) on the GPU path."""
+    from tests.gpu_util import assert_errors, run_block_case
+    gso = real_gso("pemsd7_m.sym_renorm_adj")
+    assert_errors(run_block_case(64, (64, 16, 64), 3, 3, "graph_conv", "glu", 228, 8, 8, True, gso=gso))
+
+
+def test_c3_shapes_fp32():
+    """BASELINE.json configs[2] shapes (PEMS-BAY 325 nodes, bs 64) -- fp32 path (bf16 storage is a later round)."""
+    from tests.gpu_util import assert_errors, run_block_case
+    gso = real_gso("pems_bay.cheb_sym_norm_lap")
+    assert_errors(run_block_case(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 325, 64, 8, True, gso=gso))
+
+
+def test_errors_are_loud():
+    from stgcn_amd import ops
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    cfg = ops.BlockConfig(Kt=3, Ks=3, n_vertex=20, c_in=64, channels=(64, 16, 64), act_func="glu", graph_conv_type="cheb_graph_conv",
+                          droprate=0.5)
+    x_cpu = torch.zeros(1, 64, 8, 20)
+    with pytest.raises(RuntimeError):          # CPU tensor into the HIP library: no fallback
+        ops.st_conv_block(x_cpu, None, None, cfg, [None] * 14, False, 0, 0, ops.WorkspaceCache())
+    bad = ops.BlockConfig(Kt=3, Ks=0, n_vertex=20, c_in=64, channels=(64, 16, 64), act_func="glu", graph_conv_type="cheb_graph_conv",
+                          droprate=0.5)
+    with pytest.raises(ValueError):            # layers.py:147-148
+        ops.query_plan(ops.make_desc(bad, 1, 8, False, True))
+    with pytest.raises(NotImplementedError):   # layers.py:117-118
+        ops.make_desc(ops.BlockConfig(Kt=3, Ks=3, n_vertex=20, c_in=64, channels=(64, 16, 64), act_func="relu6",
+                                      graph_conv_type="cheb_graph_conv", droprate=0.5), 1, 8, False, True)

@@ -1,0 +1,135 @@
+"""-m gpu: whole drop-in model on MI355X against golden fixtures produced by the reference, plus
+size-independent properties at the full C2 size and a short training trajectory against the oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture, maxabs, real_gso
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model_from_fixture(name, droprate=None):
+    from stgcn_amd import models
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    fx = load_fixture(name)
+    cfg = cfg_from_fixture(fx)
+    gso = torch.from_numpy(fixture_gso(name, fx)).to(DEV)
+    args = types.SimpleNamespace(Kt=cfg.Kt, Ks=cfg.Ks, act_func=cfg.act_func, graph_conv_type=cfg.graph_conv_type, gso=gso,
+                                 enable_bias=True, droprate=cfg.droprate if droprate is None else droprate, n_his=cfg.n_his)
+    cls = models.STGCNChebGraphConv if cfg.graph_conv_type == "cheb_graph_conv" else models.STGCNGraphConv
+    model = cls(args, cfg.blocks, int(fx["n_vertex"]))
+    model.load_state_dict(fixture_params(fx, cfg, torch.float32), strict=True)
+    model = model.to(DEV)
+    rs = np.random.RandomState(int(fx["seed"]) + 1)
+    B, N = int(fx["B"]), int(fx["n_vertex"])
+    x = torch.from_numpy(rs.standard_normal((B, 1, cfg.n_his, N))).float().to(DEV)
+    y = torch.from_numpy(rs.standard_normal((B, N))).float().to(DEV)
+    return fx, cfg, model, x, y
+
+
+@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32", "metrla_c2_f32", "pemsd7m_c1_f32"])
+def test_model_matches_reference_golden(name):
+    fx, cfg, model, x, y = _model_from_fixture(name)
+    model.eval()
+    blocks = []
+    hooks = [b.register_forward_hook(lambda m, i, o: blocks.append(o.detach())) for b in model.st_blocks]
+    with torch.no_grad():
+        out = model(x)
+    for h in hooks:
+        h.remove()
+    for l, b in enumerate(blocks):
+        assert b.shape == fx[f"act.st_blocks.{l}"].shape
+        assert maxabs(b.cpu().numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"
+    assert maxabs(out.cpu().numpy(), fx["eval.out"]) <= 1e-4
+    model.train()
+    model.zero_grad()
+    loss = torch.nn.MSELoss()(model(x).view(len(x), -1), y)
+    loss.backward()
+    assert abs(loss.item() - float(fx["train.loss"])) <= 1e-4 * abs(float(fx["train.loss"]))
+    nograd = set(str(s) for s in fx["nograd"])
+    for k, prm in model.named_parameters():
+        if k in nograd:
+            assert prm.grad is None, k
+            continue
+        ref = fx["gradsum." + k]
+        assert abs(float(prm.grad.double().abs().sum()) - ref[1]) <= 1e-3 * ref[1] + 1e-9, k
+        if ("grad." + k) in fx:
+            r = fx["grad." + k]
+            assert maxabs(prm.grad.cpu().numpy(), r) <= 1e-3 * max(1e-30, float(np.abs(r).max())) + 1e-7, k
+
+
+def test_state_dict_roundtrip_and_keys():
+    fx, cfg, model, x, y = _model_from_fixture("tiny_cheb_f32")
+    from oracle import stgcn_oracle as orc
+    assert list(model.state_dict().keys()) == list(orc.param_shapes(cfg, int(fx["n_vertex"])).keys())
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    out1 = model.eval()(x)
+    model.load_state_dict(sd, strict=True)
+    assert torch.equal(out1, model(x))
+
+
+def test_full_size_properties_c2():
+    """Size-independent properties at BASELINE.json configs[1] full size (bs 32, 207 nodes)."""
+    from stgcn_amd import DropoutStream, models
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    gso = torch.from_numpy(real_gso("metr_la.cheb_sym_norm_lap")).to(DEV)
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True,
+                                 droprate=0.5, n_his=12)
+    torch.manual_seed(0)
+    model = models.STGCNChebGraphConv(args, [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]], 207).to(DEV)
+    x = torch.randn(32, 1, 12, 207, device=DEV)
+    blk = model.st_blocks[0]
+    # (1) eval: LayerNorm statistics of every (b, t) slab: (y - beta) / gamma has mean 0, var 1 over [N, C]
+    model.eval()
+    with torch.no_grad():
+        y = blk(x)                                   # logical (B, C, T, N)
+        z = (y.permute(0, 2, 3, 1) - blk.tc2_ln.bias) / blk.tc2_ln.weight
+        assert z.mean(dim=(2, 3)).abs().max() < 1e-4
+        assert (z.var(dim=(2, 3), unbiased=False) - 1).abs().max() < 1e-3
+        # (2) determinism: bitwise identical on repeat
+        assert torch.equal(y, blk(x))
+    # (3) train: dropout keeps ~half, kept values are exactly 2x the eval values, pattern differs between calls
+    model.train()
+    DropoutStream.manual_seed(5)
+    with torch.no_grad():
+        yt1, yt2 = blk(x), blk(x)
+    kept = yt1 != 0
+    assert abs(kept.float().mean().item() - 0.5) < 5e-3
+    assert torch.allclose(yt1[kept], 2 * y[kept], rtol=0, atol=1e-5)
+    assert (kept != (yt2 != 0)).float().mean().item() > 0.4
+    # (4) backward is linear in dy (same dropout mask: same seed/offset via manual_seed)
+    xg = torch.randn(32, 64, 8, 207, device=DEV).permute(0, 1, 2, 3).requires_grad_(True)
+    b1 = model.st_blocks[1]
+    dy1, dy2 = torch.randn(32, 64, 4, 207, device=DEV), torch.randn(32, 64, 4, 207, device=DEV)
+
+    def grads(dy):
+        DropoutStream.manual_seed(9)
+        b1.zero_grad()
+        xg.grad = None
+        b1(xg).backward(dy)
+        return [xg.grad.clone()] + [p.grad.clone() for p in b1.parameters() if p.grad is not None]
+
+    g1, g2, g12 = grads(dy1), grads(dy2), grads(dy1 + 2 * dy2)
+    for a, b, c in zip(g1, g2, g12):
+        assert (a + 2 * b - c).abs().max() <= 2e-4 * c.abs().max() + 1e-6
+
+
+def test_training_trajectory_matches_oracle():
+    """3 AdamW steps (dropout off) on the GPU path vs the reference's own trajectory (golden)."""
+    from stgcn_amd.train import make_optimizer, train_step
+    fx, cfg, model, x, y = _model_from_fixture("tiny_cheb_f32")
+    model.train()
+    opt = make_optimizer(model)
+    losses = [float(train_step(model, opt, x, y).item()) for _ in range(len(fx["steps.losses"]))]
+    assert np.allclose(losses, fx["steps.losses"], rtol=1e-4)
+    for k, v in model.state_dict().items():
+        ref = fx["steps.paramsum." + k]
+        assert abs(float(v.double().abs().sum()) - ref[1]) <= 1e-4 * ref[1] + 1e-9, k
+        if ("steps.param." + k) in fx:
+            assert maxabs(v.cpu().numpy(), fx["steps.param." + k]) <= 1e-4, k
