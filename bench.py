@@ -74,8 +74,9 @@ def stblock_flops_by_label(B, N):
 def cpu_baseline(gso_np, budget_s=20.0):
     """The reference's loop body restated by the oracle (torch CPU, all host cores), bounded sample."""
     from oracle import stgcn_oracle as orc
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch CPU intra-op threading collapses on very wide hosts (256 threads: 36 s/step measured in round 1),
+    # so the baseline uses the best of a few thread counts; `cores` reports the count actually used.
+    ncpu = os.cpu_count() or 1
     cfg = orc.OracleConfig(Kt=KT, Ks=KS, n_his=N_HIS, droprate=0.5, blocks=BLOCKS)
     N = gso_np.shape[0]
     p = orc.random_params(cfg, N, seed=0)
@@ -88,18 +89,33 @@ def cpu_baseline(gso_np, budget_s=20.0):
         return [(torch.rand(B_LOCAL, 64, 8, N, generator=g) >= 0.5), (torch.rand(B_LOCAL, 64, 4, N, generator=g) >= 0.5),
                 (torch.rand(B_LOCAL, 1, N, 128, generator=g) >= 0.5)]
 
-    state = {}
-    for _ in range(2):
+    def one_step(state):
+        t = time.perf_counter()
         orc.train_step(x, y, gso, p, cfg, state, keep_masks=masks())
+        return time.perf_counter() - t
+
+    best, cores = None, 1
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        st = {}
+        one_step(st)                       # warm-up at this thread count
+        dt = min(one_step(st), one_step(st))
+        if best is None or dt < best:
+            best, cores = dt, th
+        if dt > 3.0:                       # hopeless configuration, stop probing wider
+            break
+    torch.set_num_threads(cores)
+    state = {}
+    one_step(state)
     n, t0 = 0, time.perf_counter()
     while True:
-        orc.train_step(x, y, gso, p, cfg, state, keep_masks=masks())
+        one_step(state)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
+        if el > budget_s or n >= 100:
             break
     return {"value": round(B_LOCAL * n / el, 2), "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of bs {B_LOCAL} (C2 shapes, dropout on, AdamW) in {el:.1f} s, torch CPU oracle"}
+            "sample": f"{n} steps of bs {B_LOCAL} (C2 shapes, dropout on, AdamW) in {el:.1f} s, torch CPU oracle, {cores} of {ncpu} host threads"}
 
 
 def main():

@@ -260,17 +260,19 @@ def param_shapes(cfg: OracleConfig, n_vertex: int) -> Dict[str, tuple]:
     if Ko > 1:
         tconv("output.tmp_conv1.", Ko, blocks[-3][-1], blocks[-2][0])
         shapes["output.fc1.weight"] = (blocks[-2][1], blocks[-2][0])
-        shapes["output.fc2.weight"] = (blocks[-1][0], blocks[-2][1])
         if cfg.enable_bias:
             shapes["output.fc1.bias"] = (blocks[-2][1],)
+        shapes["output.fc2.weight"] = (blocks[-1][0], blocks[-2][1])
+        if cfg.enable_bias:
             shapes["output.fc2.bias"] = (blocks[-1][0],)
         shapes["output.tc1_ln.weight"] = (n_vertex, blocks[-2][0])
         shapes["output.tc1_ln.bias"] = (n_vertex, blocks[-2][0])
     elif Ko == 0:
         shapes["fc1.weight"] = (blocks[-2][0], blocks[-3][-1])
-        shapes["fc2.weight"] = (blocks[-1][0], blocks[-2][0])
         if cfg.enable_bias:
             shapes["fc1.bias"] = (blocks[-2][0],)
+        shapes["fc2.weight"] = (blocks[-1][0], blocks[-2][0])
+        if cfg.enable_bias:
             shapes["fc2.bias"] = (blocks[-1][0],)
     return shapes
 

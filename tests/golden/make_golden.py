@@ -79,6 +79,7 @@ def run_case(models, name, cfg, gso, B, seed, train_steps=0, double=False, store
     cls = models.STGCNChebGraphConv if cfg["gct"] == "cheb_graph_conv" else models.STGCNGraphConv
     model = cls(make_args(cfg, gso_t), cfg["blocks"], n_vertex).to(dt)
     model.load_state_dict(params, strict=True)       # pins key names + shapes against the reference
+    assert list(model.state_dict().keys()) == list(params.keys()), "state_dict key ORDER differs from the reference"
     xn, yn = synth_xy(B, cfg["n_his"], n_vertex, seed + 1)
     x, y = torch.from_numpy(xn).to(dt), torch.from_numpy(yn).to(dt)
 
