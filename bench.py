@@ -125,10 +125,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
     from stgcn_amd import DropoutStream, _lib, models
-    from stgcn_amd.train import FlatGradAllReduce, init_distributed, make_optimizer, train_step
+    from stgcn_amd.train import FlatGradAllReduce, GraphedTrainStep, init_distributed, make_optimizer, train_step
 
     rank, local_rank, world = init_distributed()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -143,7 +144,8 @@ def main():
     torch.manual_seed(42)                       # identical replicas on every rank
     model = models.STGCNChebGraphConv(make_args(torch.from_numpy(gso_np).to(dev)), BLOCKS, N).to(dev)
     DropoutStream.manual_seed(1234 + rank)      # independent dropout streams per rank
-    opt = make_optimizer(model, lr=1e-3, weight_decay=1e-3)
+    use_graph = not args.no_graph
+    opt = make_optimizer(model, lr=1e-3, weight_decay=1e-3, capturable=use_graph)
     allreduce = FlatGradAllReduce(list(model.parameters()), world) if world > 1 else None
 
     # synthetic windows, resident in HBM: (num, 1, n_his, N) / (num, N) like script/dataloader.py:32-47
@@ -158,8 +160,22 @@ def main():
 
     model.train()
     step_i = 0
+    graph_err = None
+    if use_graph:
+        try:
+            graphed = GraphedTrainStep(model, opt, *batch(0), world=world)
+
+            def run_step(xb, yb):
+                return graphed(xb, yb)
+        except Exception as e:  # noqa: BLE001  -- same HIP path, just launched eagerly
+            graph_err = repr(e)
+            use_graph = False
+            DropoutStream.disable_device_counter()
+    if not use_graph:
+        def run_step(xb, yb):
+            return train_step(model, opt, xb, yb, allreduce)
     for _ in range(args.warmup):
-        train_step(model, opt, *batch(step_i), allreduce)
+        run_step(*batch(step_i))
         step_i += 1
 
     def sync():
@@ -170,7 +186,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, opt, *batch(step_i), allreduce)
+        loss = run_step(*batch(step_i))
         step_i += 1
     sync()
     el = time.perf_counter() - t0
@@ -188,10 +204,13 @@ def main():
            "config": {"workload": "C2: METR-LA 207 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=32 per GPU, fp32, "
                                   "dropout 0.5, AdamW lr 1e-3 wd 1e-3; full step zero_grad+fwd+MSE+bwd+opt",
                       "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
-                      "output_block": "stock PyTorch-ROCm ops (not yet fused)", "final_loss": round(loss_val, 5)}}
+                      "output_block": "stock PyTorch-ROCm ops (not yet fused)", "final_loss": round(loss_val, 5),
+                      "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err}}
 
     if rank == 0 and not args.no_profile:
         # per-kernel durations with hipEvents on the launch stream, over the same K steps (second pass)
+        # (eager launches: hipEvents cannot be recorded inside a graph replay; the kernels and shapes are the same)
+        DropoutStream.disable_device_counter()
         L.dll.stgcn_profile_enable(1)
         ksteps = min(args.steps, 50)
         for _ in range(ksteps):

@@ -116,19 +116,24 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* desc, stgcn_stblock_plan*
 /* gso: dense (N, N) row-major.  gso_pad / gso_t_pad: (NP, NP), NP = roundup16(N).                    */
 int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream);
 
-/* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4).     */
+/* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
+ * offset is the high 64 counter bits).  offset_dev (nullable) points to a DEVICE uint64 added to `offset` when
+ * the kernel runs: a step counter the caller bumps on the stream, so that a captured hipGraph draws a fresh
+ * mask on every replay.                                                                                  */
 int stgcn_stblock_forward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
                           const float* gso_pad, float* y, float* saved, float* ws, uint64_t seed, uint64_t offset,
-                          void* stream);
+                          const uint64_t* offset_dev, void* stream);
 
 /* dy: (B, T2, N, c2); dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the matching
  * forward call filled; seed/offset must be the forward's.                                            */
 int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
                            const float* gso_t_pad, const float* dy, const float* saved, float* ws,
-                           const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset, void* stream);
+                           const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
+                           const uint64_t* offset_dev, void* stream);
 
 /* out[e] = 0 or 1/(1-p): the keep-scale the forward applies to element e of y (n multiple of 4).     */
-int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream);
+int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                       void* stream);
 
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the

@@ -69,11 +69,11 @@ class _Lib:
         d.stgcn_stblock_plan_query.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockPlan)]
         d.stgcn_gso_prepare.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
-                                             C.c_uint64, C.c_uint64, C.c_void_p]
-        d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]
+                                             C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int
         d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]

@@ -153,26 +153,35 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
     return STGCN_OK;
 }
 
+int launch_ln_fwd(const LnFwdArgs& ln, int64_t slabs, hipStream_t st) {
+    const dim3 grid((unsigned)slabs), blk(kThreads);
+    const int n4 = ln.n / 4;
+    if (n4 <= 16 * kThreads) STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<16>), grid, blk, 64, ln);
+    else if (n4 <= 32 * kThreads) STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<32>), grid, blk, 64, ln);
+    else STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<0>), grid, blk, 64, ln);
+    return STGCN_OK;
+}
+
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
     const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
-    const size_t lds = kTileLdsFloats * sizeof(float);
+    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout) * sizeof(float);
     if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2>), grid, blk, lds, a);
     else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4>), grid, blk, lds, a);
     return STGCN_OK;
 }
 
+constexpr int kGcWaves = 8;   // graph-conv workgroups: 8 waves (2 per SIMD)
+
 int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, maxq = (HT + 3) / 4;
+    const int HT = a.NP / 16, maxq = (HT + kGcWaves - 1) / kGcWaves;
     const size_t lds = (size_t)3 * 16 * (a.NP + 4) * sizeof(float);
-    const dim3 grid((unsigned)a.slabs), blk(kThreads);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2>), grid, blk, lds, a);
-    else if (maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4>), grid, blk, lds, a);
-    else if (maxq <= 6) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<6>), grid, blk, lds, a);
-    else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<8>), grid, blk, lds, a);
+    const dim3 grid((unsigned)a.slabs), blk(kGcWaves * 64);
+    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, kGcWaves>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, kGcWaves>), grid, blk, lds, a);
+    else if (maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, kGcWaves>), grid, blk, lds, a);
+    else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, kGcWaves>), grid, blk, lds, a);
     return STGCN_OK;
 }
-
 
 int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
     const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
@@ -186,15 +195,14 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
 }
 
 int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, maxq = (HT + 3) / 4;
+    const int HT = a.NP / 16, maxq = (HT + kGcWaves - 1) / kGcWaves;
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
-    const dim3 grid((unsigned)a.slabs), blk(kThreads);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2>), grid, blk, lds, a);
-    else if (maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4>), grid, blk, lds, a);
-    else if (maxq <= 6) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<6>), grid, blk, lds, a);
-    else STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<8>), grid, blk, lds, a);
+    const dim3 grid((unsigned)a.slabs), blk(kGcWaves * 64);
+    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, kGcWaves>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, kGcWaves>), grid, blk, lds, a);
+    else if (maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, kGcWaves>), grid, blk, lds, a);
+    else STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, kGcWaves>), grid, blk, lds, a);
     return STGCN_OK;
 }
 
@@ -309,16 +317,16 @@ int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_
     return STGCN_OK;
 }
 
-int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, void* stream) {
+int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
     if (!out || n < 0 || (n & 3)) return fail(STGCN_ERR_INVALID, "stgcn_dropout_mask: n must be a non-negative multiple of 4");
     if (n == 0) return STGCN_OK;
     STGCN_LAUNCH("dropout_mask", (hipStream_t)stream, dropout_mask_kernel, dim3(cdiv(n / 4, kThreads)), dim3(kThreads), 0, out,
-                 (long)(n / 4), seed, offset, drop_thresh(droprate), 1.0f / (1.0f - droprate));
+                 (long)(n / 4), seed, offset, offset_dev, drop_thresh(droprate), 1.0f / (1.0f - droprate));
     return STGCN_OK;
 }
 
 int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* x, const float* gso_pad, float* y,
-                          float* saved, float* ws, uint64_t seed, uint64_t offset, void* stream) {
+                          float* saved, float* ws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
     stgcn_stblock_plan pl;
     int rc = stgcn_stblock_plan_query(d, &pl);
     if (rc) return rc;
@@ -371,8 +379,9 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     ln.mean = saved + pl.sv_mean; ln.rstd = saved + pl.sv_rstd;
     ln.n = d->N * d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
     ln.eps = d->ln_eps; ln.keep_scale = 1.0f / (1.0f - d->droprate); ln.thresh = drop_thresh(d->droprate);
-    ln.seed = seed; ln.offset = offset;
-    STGCN_LAUNCH("ln_fwd", st, ln_fwd_kernel, dim3((unsigned)v.slabs2), dim3(kThreads), 64, ln);
+    ln.seed = seed; ln.offset = offset; ln.offset_dev = offset_dev;
+    rc = launch_ln_fwd(ln, v.slabs2, st);
+    if (rc) return rc;
     return STGCN_OK;
 }
 

@@ -37,8 +37,8 @@ inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
     g.mchunks = (g.Mtiles + g.MTW - 1) / g.MTW;
     g.Mpad = g.mchunks * g.MTW * 16;
     g.NC = NC;
-    // aim at ~512 workgroups in total, at least 64 rows per chunk
-    long target = 512 / g.mchunks;
+    // aim at ~256 workgroups in total (one per CU; fewer partials to write and re-read), >= 64 rows per chunk
+    long target = 256 / g.mchunks;
     if (target < 1) target = 1;
     long rpc = (rows + target - 1) / target;
     rpc = (rpc + 15) / 16 * 16;
@@ -56,13 +56,13 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     const long rows1 = (long)B * T1 * N, rows2 = (long)B * T2 * N, slabs1 = (long)B * T1, slabs2 = (long)B * T2;
     const long n = (long)N * c2, n4 = n / 4;
     const int colgroups = (int)((n4 + kThreads - 1) / kThreads);
-    int sg = (768 + colgroups - 1) / colgroups;   // ~768 workgroups
+    int sg = (512 + colgroups - 1) / colgroups;   // ~512 workgroups
     if (sg > slabs2) sg = (int)slabs2;
     if (sg < 1) sg = 1;
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
-    g.al_wgs = (int)(tiles1 < 512 ? tiles1 : 512);
+    g.al_wgs = (int)(tiles1 < 256 ? tiles1 : 256);
     long o = 0;
     auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };
     g.off_ln_g = take((long)g.ln_sg * n);
@@ -102,6 +102,7 @@ struct LnBwdArgs {
     float keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
+    const uint64_t* offset_dev;
 };
 
 __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(LnBwdArgs a) {
@@ -110,12 +111,14 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(LnBwdArgs a) {
     const int n4 = a.n >> 2, tid = threadIdx.x;
     const size_t base = (size_t)slab * a.n;
     const float mean = a.mean[slab], rstd = a.rstd[slab];
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
     for (int q = tid; q < n4; q += kThreads) {
         f32x4 dy = ld4(a.dy + base + 4 * q);
         const f32x4 u = ld4(a.U + base + 4 * q), s = ld4(a.S + base + 4 * q), ga = ld4(a.gamma + 4 * q);
         if (a.training) {
-            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dy[i] *= k[i];
         }
@@ -147,17 +150,27 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
     const int c4n = a.C >> 2;
     const int node = q / c4n, c4 = q - node * c4n;
     const f32x4 ga = ld4(a.gamma + 4 * q);
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     f32x4 dg = zero4(), db = zero4();
     long s0 = (long)sg * a.spg, s1 = s0 + a.spg;
     if (s1 > a.slabs) s1 = a.slabs;
     const int N = a.n / a.C;
+    // one-slab software prefetch: the loads of slab+1 are issued before the stores of slab
+    f32x4 dy_n = zero4(), u_n = zero4(), s_n = zero4();
+    if (s0 < s1) {
+        const size_t base = (size_t)s0 * a.n + 4 * (size_t)q;
+        dy_n = ld4(a.dy + base); u_n = ld4(a.U + base); s_n = ld4(a.S + base);
+    }
     for (long slab = s0; slab < s1; ++slab) {
-        const size_t base = (size_t)slab * a.n + 4 * (size_t)q;
-        f32x4 dy = ld4(a.dy + base);
-        const f32x4 u = ld4(a.U + base), s = ld4(a.S + base);
+        f32x4 dy = dy_n;
+        const f32x4 u = u_n, s = s_n;
+        if (slab + 1 < s1) {
+            const size_t nb = (size_t)(slab + 1) * a.n + 4 * (size_t)q;
+            dy_n = ld4(a.dy + nb); u_n = ld4(a.U + nb); s_n = ld4(a.S + nb);
+        }
         const float mean = a.mean[slab], rstd = a.rstd[slab], c1 = a.c1[slab], c2 = a.c2[slab];
         if (a.training) {
-            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dy[i] *= k[i];
         }
@@ -267,8 +280,9 @@ struct GconvBwdArgs {
     long slabs;
 };
 
-template <int MAXQ>
-__global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
+template <int MAXQ, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
+    constexpr int THREADS = WAVES * 64;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const long slab = blockIdx.x;
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
 
     // ---- stage dY (row major) and all X_k (transposed) -----------------------------------------
     const float* dYsl = a.dY + (size_t)slab * N * 16;
-    for (int idx = tid; idx < NP * 4; idx += kThreads) {
+    for (int idx = tid; idx < NP * 4; idx += THREADS) {
         const int n = idx >> 2, c4 = idx & 3;
         st4(dYs + n * LDY + c4 * 4, n < N ? ld4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
         for (int k = 0; k < Ks; ++k) {
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
 
     // ---- parameter-gradient partials: job kk < Ks -> dW_kk = X_kk^T dY ; kk == Ks -> db via A = 1 ----
     float* part = a.part + (size_t)slab * (Ks + 1) * 256;
-    for (int kk = wave; kk <= Ks; kk += 4) {
+    for (int kk = wave; kk <= Ks; kk += WAVES) {
         f32x4 c0 = zero4(), c1 = zero4();
         for (int kc = 0; kc < KCH; ++kc) {
             f32x4 af;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
         if (!(a.kipf && k == 0)) wf = ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g);
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + 4 * q;
+            const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
                 f32x4 d = zero4();
@@ -333,21 +347,33 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
         f32x4 acc[MAXQ];
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
+        f32x4 bnext[MAXQ];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            bnext[q] = ht < HT ? ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + 4 * g) : zero4();
+        }
         for (int kc = 0; kc < KCH; ++kc) {
             const f32x4 af = ld4(Gk + l15 * LDX + kc * 16 + 4 * g);
+            f32x4 bf[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + 4 * q;
-                if (ht < HT) {
-                    const f32x4 bf = ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + kc * 16 + 4 * g);
+                bf[q] = bnext[q];
+                const int ht = wave + WAVES * q;
+                if (kc + 1 < KCH && ht < HT) bnext[q] = ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + (kc + 1) * 16 + 4 * g);
+            }
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[s], acc[q]);
+            for (int q = 0; q < MAXQ; ++q) {
+                const int ht = wave + WAVES * q;
+                if (ht < HT) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[q][s], acc[q]);
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + 4 * q;
+            const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const int h = ht * 16 + l15;
                 if (k >= 2) {
@@ -374,7 +400,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(GconvBwdArgs a) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + 4 * q;
+            const int ht = wave + WAVES * q;
             const int h = ht * 16 + l15;
             if (ht < HT && h < N) {
                 const f32x4 y = ld4(dYs + h * LDY + 4 * g);
@@ -407,14 +433,16 @@ template <int NTA>
 __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const int c0 = a.c0, c1 = a.c1, LDA = c1 + 4;
-    float* dAt = stgcn_smem;                 // [64][LDA]
-    float* red = stgcn_smem + 64 * LDA;      // [16][c1] for the dba reduction
+    const int c0 = a.c0, c1 = a.c1, LDA = c1 + 4, LDH = c0 + 4;
+    float* dAt = stgcn_smem;                     // [64][LDA]
+    float* Ht = stgcn_smem + 64 * LDA;           // [64][LDH]  dH, then H in place
+    float* red = Ht + 64 * LDH;                  // [16][c1] for the dba reduction
     const long tiles = (a.rows + kTileRows - 1) / kTileRows;
-    f32x4 wacc[NTA];                         // partial dWa tile (rows i = coltile*16 + 4g + r, col j = l15); c1 == 16
+    f32x4 wacc[NTA];                             // partial dWa tile (rows i = coltile*16 + 4g + r, col j = l15); c1 == 16
 #pragma unroll
     for (int j = 0; j < NTA; ++j) wacc[j] = zero4();
-    float bsum = 0.f;                        // thread (rg = tid >> 4, jj = tid & 15): column jj, rows rg, rg+16, ..
+    float bsum = 0.f;                            // thread (rg = tid >> 4, jj = tid & 15): column jj, rows rg, rg+16, ..
+    const int c4n = c0 >> 2;
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * kTileRows;
         __syncthreads();   // previous tile fully consumed
@@ -427,6 +455,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
             const int rg = tid >> 4, jj = tid & 15;
             if (jj < c1) bsum += dAt[rg * LDA + jj] + dAt[(rg + 16) * LDA + jj] + dAt[(rg + 32) * LDA + jj] + dAt[(rg + 48) * LDA + jj];
         }
+        // dH = dA @ Wa^T  (wave w: column tiles w + 4j), D layout -> LDS
         f32x4 acc[4][NTA];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -437,26 +466,44 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
         for (int j = 0; j < NTA; ++j) {
             const int col = (wave + 4 * j) * 16 + l15;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 hv;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long R = row0 + i * 16 + 4 * g + r;
-                    float h = 0.f;
-                    if (R < a.rows) {
-                        const float u = a.U[(size_t)R * c0 + col], s = a.S[(size_t)R * c0 + col];
-                        float du, dq;
-                        gate_bwd(acc[i][j][r], u, s, a.act, du, dq);
-                        a.dZ[(size_t)R * 2 * c0 + col] = du;
-                        a.dZ[(size_t)R * 2 * c0 + c0 + col] = dq;
-                        h = gate_fwd(u, s, a.act);
-                    }
-                    hv[r] = h;
+                for (int r = 0; r < 4; ++r) Ht[(i * 16 + 4 * g + r) * LDH + col] = acc[i][j][r];
+        }
+        __syncthreads();
+        // row-major pass with 16-byte global accesses: gate backward -> dZ, H back into the tile
+        for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            const long R = row0 + row;
+            f32x4 h = zero4();
+            if (R < a.rows) {
+                const f32x4 dh = ld4(Ht + row * LDH + 4 * c4);
+                const f32x4 u = ld4(a.U + (size_t)R * c0 + 4 * c4), s = ld4(a.S + (size_t)R * c0 + 4 * c4);
+                f32x4 du, dq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float du_, dq_;
+                    gate_bwd(dh[i], u[i], s[i], a.act, du_, dq_);
+                    du[i] = du_;
+                    dq[i] = dq_;
+                    h[i] = gate_fwd(u[i], s[i], a.act);
                 }
-                // dWa[i = col][j] += sum_rows H[row][col] dA[row][j] : A[row_op = col (l15)][kk = row 4g+s] = hv[s]
+                st4(a.dZ + (size_t)R * 2 * c0 + 4 * c4, du);
+                st4(a.dZ + (size_t)R * 2 * c0 + c0 + 4 * c4, dq);
+            }
+            st4(Ht + row * LDH + 4 * c4, h);
+        }
+        __syncthreads();
+        // dWa[i][j] += sum_rows H[row][i] dA[row][j] : A[row_op = i (l15)][kk = row 4g+s], B[kk = row][col = j (l15)]
+#pragma unroll
+        for (int j = 0; j < NTA; ++j) {
+            const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* hh = Ht + (i * 16 + 4 * g) * LDH + col;
                 const float* bb = dAt + (i * 16 + 4 * g) * LDA + l15;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) wacc[j] = mfma4(hv[s], bb[s * LDA], wacc[j]);
+                for (int s = 0; s < 4; ++s) wacc[j] = mfma4(hh[s * LDH], bb[s * LDA], wacc[j]);
             }
         }
     }
@@ -618,7 +665,10 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
 
 // ================================================================================================
 // Final deterministic reduction of the partials into gradients laid out like the reference's parameters.
-// Each job: dst[d0][d1][d2] = sum_p src[p*pstride + d0*s0 + d1*s1 + d2*s2]
+// A job enumerates a 3-D index (d0, d1, d2), d2 fastest and contiguous in the SOURCE (coalesced reads):
+//     dst[d0*t0 + d1*t1 + d2*t2] = sum_p src[p*pstride + d0*s0 + d1*s1 + d2*s2]
+// A workgroup owns 32 consecutive elements; its 8 slices (tid >> 5) walk the partials p = slice, slice+8, ..
+// and are combined through LDS in a fixed order (bitwise reproducible).
 // ================================================================================================
 struct ReduceJob {
     const float* src;
@@ -627,8 +677,10 @@ struct ReduceJob {
     long pstride;
     int n0, n1, n2;
     long s0, s1, s2;
+    long t0, t1, t2;
 };
 constexpr int kMaxReduceJobs = 16;
+constexpr int kReduceElems = 32, kReduceSlices = kThreads / kReduceElems;
 struct ReduceArgs {
     ReduceJob job[kMaxReduceJobs];
     int start[kMaxReduceJobs + 1];
@@ -636,17 +688,38 @@ struct ReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
+    extern __shared__ float stgcn_smem[];
     int jb = 0;
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
     const ReduceJob& j = a.job[jb];
-    const long e = ((long)blockIdx.x - a.start[jb]) * kThreads + threadIdx.x;
+    const int el = threadIdx.x & (kReduceElems - 1), sl = threadIdx.x >> 5;
+    const long e = ((long)blockIdx.x - a.start[jb]) * kReduceElems + el;
     const long n = (long)j.n0 * j.n1 * j.n2;
-    if (e >= n) return;
-    const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
-    const float* s = j.src + d0 * j.s0 + d1 * j.s1 + d2 * j.s2;
     float acc = 0.f;
-    for (int p = 0; p < j.P; ++p) acc += s[(size_t)p * j.pstride];
-    j.dst[e] = acc;
+    long doff = 0;
+    if (e < n) {
+        const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
+        const float* s = j.src + d0 * j.s0 + d1 * j.s1 + d2 * j.s2;
+        doff = d0 * j.t0 + d1 * j.t1 + d2 * j.t2;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // 4 loads in flight per thread
+        int p = sl;
+        for (; p + 3 * kReduceSlices < j.P; p += 4 * kReduceSlices) {
+            a0 += s[(size_t)p * j.pstride];
+            a1 += s[(size_t)(p + kReduceSlices) * j.pstride];
+            a2 += s[(size_t)(p + 2 * kReduceSlices) * j.pstride];
+            a3 += s[(size_t)(p + 3 * kReduceSlices) * j.pstride];
+        }
+        for (; p < j.P; p += kReduceSlices) a0 += s[(size_t)p * j.pstride];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    stgcn_smem[sl * kReduceElems + el] = acc;
+    __syncthreads();
+    if (sl == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kReduceSlices; ++k) t += stgcn_smem[k * kReduceElems + el];
+        j.dst[doff] = t;
+    }
 }
 
 }  // namespace stgcn

@@ -171,8 +171,10 @@ __device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, i
 }
 
 // LDS carve for the row-tile GEMM kernels (floats): [rowbase 64 ints][rowt 64 ints][At 64 x (kSegMax+4)]
+// (tconv_fwd re-uses At as its [64][NC + 4] epilogue tile: tile_lds_floats(NC))
 constexpr int kLdaMax = kSegMax + 4;
 constexpr int kTileLdsFloats = 128 + kTileRows * kLdaMax;
+inline int tile_lds_floats(int nc) { return 128 + kTileRows * ((nc > kSegMax ? nc : kSegMax) + 4); }
 
 // ================================================================================================
 // F1: gated temporal convolution  Z = im2col(x) @ W_eff + b_eff ; U = Z[:, :Cout] ; S = sigmoid(Z[:, Cout:])
@@ -222,36 +224,44 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
         seg_mma<4, NT>(acc, At, kseg + 4, 0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
     }
 
-    // ---- epilogue: bias, gate, stores -------------------------------------------------------
-    const int Cout = a.Cout;
+    // ---- epilogue: accumulators -> LDS tile Zt[64][NC + 4] -> row-major float4 pass (coalesced U/S/H stores) ----
+    const int Cout = a.Cout, NC = 2 * Cout, ldz = NC + 4;
     const bool do_align = a.Wap != nullptr;
-    const int ldh = Cout + 4;
-    if (do_align) __syncthreads();   // At is about to be reused as the H tile
+    float* Zt = At;
+    __syncthreads();   // every wave is done reading At
 #pragma unroll
-    for (int jj = 0; jj < NT / 2; ++jj) {
-        const int col = (wave + 4 * jj) * 16 + l15;      // P channel; its gate is channel Cout + col
-        const float bp = a.bias[col], bq = a.bias[Cout + col];
+    for (int j = 0; j < NT; ++j) {
+        const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int c4n = Cout >> 2;
+    for (int idx = threadIdx.x; idx < kTileRows * c4n; idx += kThreads) {
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        const long R = row0 + row;
+        const f32x4 p = ld4(Zt + row * ldz + 4 * c4), q = ld4(Zt + row * ldz + Cout + 4 * c4);
+        const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + Cout + 4 * c4);
+        f32x4 u, sg, h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i * 16 + 4 * g + r;
-                const long R = row0 + row;
-                const float u = acc[i][jj][r] + bp;
-                const float s = sigmoid_f(acc[i][jj + NT / 2][r] + bq);
-                const float h = gate_fwd(u, s, a.act);
-                if (R < a.ts.rows) {
-                    const size_t o = (size_t)R * Cout + col;
-                    if (a.U) a.U[o] = u;
-                    if (a.S) a.S[o] = s;
-                    if (a.H) a.H[o] = h;
-                }
-                if (do_align) At[row * ldh + col] = h;
-            }
+            u[i] = p[i] + bp[i];
+            sg[i] = sigmoid_f(q[i] + bq[i]);
+            h[i] = gate_fwd(u[i], sg[i], a.act);
         }
+        if (R < a.ts.rows) {
+            const size_t o = (size_t)R * Cout + 4 * c4;
+            if (a.U) st4(a.U + o, u);
+            if (a.S) st4(a.S + o, sg);
+            if (a.H) st4(a.H + o, h);
+        }
+        if (do_align) st4(Zt + row * ldz + 4 * c4, h);   // H tile in place of the P half
     }
     if (!do_align) return;
     __syncthreads();
+    const int ldh = ldz;
 
     // ---- align epilogue: A[64 x c1] = H[64 x Cout] @ Wa + ba ; wave w owns rows 16w..16w+15 -------
     const int KCHa = Cout >> 4;
@@ -284,7 +294,9 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
 // (rows = 16 channels, k = nodes); L fragments come straight from L2 (padded operator, 16-B loads);
 // D = X_k^T tile[c][h] leaves each lane with 4 consecutive channels of one node, which is at once the
 // store layout and the A operand of the 16x16 weight contraction.
-// Wave w owns node tiles h-tile = w, w+4, ... (MAXQ of them).
+// Wave w of WAVES owns node tiles h-tile = w, w+WAVES, ... (MAXQ of them).  8 waves = 2 per SIMD, so one
+// wave's operator-fragment loads (L2 latency) hide behind the other's MFMAs; the fragments of chunk kc+1
+// are also requested before the MFMAs of chunk kc.
 // ================================================================================================
 struct GconvFwdArgs {
     const float* A;      // [slabs][N][16]
@@ -297,8 +309,9 @@ struct GconvFwdArgs {
     long slabs;
 };
 
-template <int MAXQ>
-__global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
+template <int MAXQ, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
+    constexpr int THREADS = WAVES * 64;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const long slab = blockIdx.x;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
 
     // stage X0 transposed
     const float* Asl = a.A + (size_t)slab * N * 16;
-    for (int idx = tid; idx < NP * 4; idx += kThreads) {
+    for (int idx = tid; idx < NP * 4; idx += THREADS) {
         const int n = idx >> 2, c4 = idx & 3;
         const f32x4 v = n < N ? ld4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
 #pragma unroll
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
         yacc[q] = zero4();
-        const int ht = wave + 4 * q;
+        const int ht = wave + WAVES * q;
         // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
         res[q] = ht < HT ? ld4(XT0 + l15 * LDX + ht * 16 + 4 * g) : zero4();
     }
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
         if (k == 0) {
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + 4 * q;
+                const int ht = wave + WAVES * q;
                 if (ht < HT) {
                     const int h = ht * 16 + l15;
 #pragma unroll
@@ -349,15 +362,27 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
         f32x4 acc[MAXQ];
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
+        f32x4 bnext[MAXQ];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            bnext[q] = ht < HT ? ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + 4 * g) : zero4();
+        }
         for (int kc = 0; kc < KCH; ++kc) {
             const f32x4 af = ld4(Xprev + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
+            f32x4 bf[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + 4 * q;
-                if (ht < HT) {
-                    const f32x4 bf = ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + kc * 16 + 4 * g);   // B[node][h = l15]
+                bf[q] = bnext[q];                                           // B[node][h = l15]
+                const int ht = wave + WAVES * q;
+                if (kc + 1 < KCH && ht < HT) bnext[q] = ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + (kc + 1) * 16 + 4 * g);
+            }
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[s], acc[q]);
+            for (int q = 0; q < MAXQ; ++q) {
+                const int ht = wave + WAVES * q;
+                if (ht < HT) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[q][s], acc[q]);
                 }
             }
         }
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
         const float* Xpp = XT0 + ((k + 1) % 3) * 16 * LDX;   // == (k-2) % 3
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + 4 * q;
+            const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const int h = ht * 16 + l15;
                 f32x4 x = acc[q];   // X_k[h][c = 4g + r]
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvFwdArgs a) {
     const float bb = a.bias ? a.bias[l15] : 0.f;
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-        const int ht = wave + 4 * q;
+        const int ht = wave + WAVES * q;
         if (ht < HT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -415,30 +440,68 @@ struct LnFwdArgs {
     float eps, keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
+    const uint64_t* offset_dev;   // optional device-side step counter added to `offset` (graph replay safe)
 };
 
+// MAXV > 0: the slab's n/4 float4 columns fit in MAXV registers per thread -> one read of U and S with every
+// load in flight at once (the kernel is latency-bound otherwise: one workgroup streams the whole slab).
+// MAXV == 0: generic three-pass variant for large slabs (re-reads come from L2).
+template <int MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     extern __shared__ float stgcn_smem[];
     const long slab = blockIdx.x;
     const int n4 = a.n >> 2, tid = threadIdx.x;
     const float* U = a.U + (size_t)slab * a.n;
     const float* S = a.S + (size_t)slab * a.n;
-    float s1 = 0.f, dummy = 0.f;
-    for (int q = tid; q < n4; q += kThreads) {
-        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+    float* y = a.y + (size_t)slab * a.n;
+    float s1 = 0.f, s2 = 0.f, dummy = 0.f;
+    constexpr int NV = MAXV > 0 ? MAXV : 1;
+    f32x4 h[NV];
+    if (MAXV > 0) {
+        f32x4 u[NV], s[NV];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s1 += gate_fwd(u[i], s[i], a.act);
+        for (int v = 0; v < NV; ++v) {
+            const int q = tid + v * kThreads;
+            u[v] = q < n4 ? ld4(U + 4 * q) : zero4();
+            s[v] = q < n4 ? ld4(S + 4 * q) : zero4();
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[v][i] = gate_fwd(u[v][i], s[v][i], a.act);   // 0 for the padding columns (u = s = 0)
+                s1 += h[v][i];
+            }
+        }
+    } else {
+        for (int q = tid; q < n4; q += kThreads) {
+            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s1 += gate_fwd(u[i], s[i], a.act);
+        }
     }
     block_sum2(s1, dummy, stgcn_smem);
     const float mean = s1 / (float)a.n;
-    float s2 = 0.f;
     dummy = 0.f;
-    for (int q = tid; q < n4; q += kThreads) {
-        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+    if (MAXV > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = gate_fwd(u[i], s[i], a.act) - mean;
-            s2 += d * d;
+        for (int v = 0; v < NV; ++v) {
+            if (tid + v * kThreads < n4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = h[v][i] - mean;
+                    s2 += d * d;
+                }
+            }
+        }
+    } else {
+        for (int q = tid; q < n4; q += kThreads) {
+            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = gate_fwd(u[i], s[i], a.act) - mean;
+                s2 += d * d;
+            }
         }
     }
     block_sum2(s2, dummy, stgcn_smem);
@@ -447,28 +510,43 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
         a.mean[slab] = mean;
         a.rstd[slab] = rstd;
     }
-    float* y = a.y + (size_t)slab * a.n;
-    for (int q = tid; q < n4; q += kThreads) {
-        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q), ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+    auto emit = [&](int q, const f32x4& hv) {
+        const f32x4 ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
         f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], s[i], a.act) - mean) * rstd * ga[i] + be[i];
+        for (int i = 0; i < 4; ++i) o[i] = (hv[i] - mean) * rstd * ga[i] + be[i];
         if (a.training) {
-            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, a.offset, a.thresh, a.keep_scale);
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] *= k[i];
         }
         st4(y + 4 * q, o);
+    };
+    if (MAXV > 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int q = tid + v * kThreads;
+            if (q < n4) emit(q, h[v]);
+        }
+    } else {
+        for (int q = tid; q < n4; q += kThreads) {
+            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
+            f32x4 hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = gate_fwd(u[i], s[i], a.act);
+            emit(q, hv);
+        }
     }
 }
 
 // keep-scale mask exactly as ln_fwd_kernel draws it (test / debugging aid; also used by the oracle
 // comparison in training mode): out[e] in {0, 1/(1-p)}
-__global__ __launch_bounds__(256) void dropout_mask_kernel(float* out, long n4, uint64_t seed, uint64_t offset, uint32_t thresh,
-                                                           float keep_scale) {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* out, long n4, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                                           uint32_t thresh, float keep_scale) {
     const long q = (long)blockIdx.x * kThreads + threadIdx.x;
     if (q >= n4) return;
-    st4(out + 4 * q, dropout_scale4((uint64_t)q, seed, offset, thresh, keep_scale));
+    st4(out + 4 * q, dropout_scale4((uint64_t)q, seed, offset + (offset_dev ? *offset_dev : 0), thresh, keep_scale));
 }
 
 }  // namespace stgcn

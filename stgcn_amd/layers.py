@@ -26,20 +26,47 @@ from . import ops
 
 class DropoutStream:
     """Seed / running offset of the counter-based dropout RNG (Philox4x32-10 inside the kernels).
-    Every training forward of every block consumes one offset, so masks never repeat; the trainer
-    gives each data-parallel rank its own seed."""
+
+    Eager mode: every training forward of every block consumes one host-side offset, so masks never
+    repeat.  Graph mode (``use_device_counter``): kernel arguments are frozen inside a captured hipGraph, so
+    the running part of the offset lives in a device int64 that the captured step bumps (``advance``);
+    each block adds its own static site id.  The trainer gives each data-parallel rank its own seed."""
     seed: int = 0x5EED5EED
     _offset: int = 0
+    _sites: int = 0
+    counter = None            # device int64[1] in graph mode
+    SITE_STRIDE = 1 << 20     # room for a million dropout sites per step
 
     @classmethod
     def manual_seed(cls, seed: int):
         cls.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cls._offset = 0
+        if cls.counter is not None:
+            cls.counter.zero_()
 
     @classmethod
     def next_offset(cls) -> int:
         cls._offset += 1
         return cls._offset
+
+    @classmethod
+    def new_site(cls) -> int:
+        cls._sites += 1
+        return cls._sites
+
+    @classmethod
+    def use_device_counter(cls, device):
+        cls.counter = torch.zeros(1, dtype=torch.int64, device=device)
+
+    @classmethod
+    def disable_device_counter(cls):
+        cls.counter = None
+
+    @classmethod
+    def advance(cls):
+        """Call once per training step (inside the captured region in graph mode)."""
+        if cls.counter is not None:
+            cls.counter.add_(cls.SITE_STRIDE)
 
 
 class Align(nn.Module):
@@ -206,6 +233,7 @@ class STConvBlock(nn.Module):
         self.gso = gso                      # plain attribute like the reference: not in state_dict, not moved by .to()
         self._gso_cache = None              # (key, padded, padded transposed)
         self._ws = ops.WorkspaceCache()
+        self._site = DropoutStream.new_site()
 
     def _operators(self, device):
         gso = self.gso
@@ -226,8 +254,12 @@ class STConvBlock(nn.Module):
     def forward(self, x):
         gp, gt = self._operators(x.device)
         training = self.training and self.cfg.droprate > 0.0
-        offset = DropoutStream.next_offset() if training else 0
-        return ops.st_conv_block(x, gp, gt, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws)
+        counter = DropoutStream.counter if training else None
+        if counter is not None:
+            offset = self._site                       # static per block; the device counter supplies the step
+        else:
+            offset = DropoutStream.next_offset() if training else 0
+        return ops.st_conv_block(x, gp, gt, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)
 
 
 class OutputBlock(nn.Module):

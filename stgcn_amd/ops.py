@@ -95,11 +95,16 @@ def gso_prepare(gso: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return gp, gt
 
 
-def dropout_mask(n: int, droprate: float, seed: int, offset: int, device) -> torch.Tensor:
+def _optr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def dropout_mask(n: int, droprate: float, seed: int, offset: int, device, offset_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Keep-scale (0 or 1/(1-p)) for the first n elements of a block output, as the forward draws it."""
     L = _lib.lib()
     out = torch.empty(n, dtype=torch.float32, device=device)
-    L.check(L.dll.stgcn_dropout_mask(out.data_ptr(), n, float(droprate), seed, offset, _stream_of(out)), "stgcn_dropout_mask")
+    L.check(L.dll.stgcn_dropout_mask(out.data_ptr(), n, float(droprate), seed, offset, _optr(offset_dev), _stream_of(out)),
+            "stgcn_dropout_mask")
     return out
 
 
@@ -127,8 +132,8 @@ class _STBlockFn(torch.autograd.Function):
     """x_cl: (B, T, N, c_in) contiguous -> y_cl: (B, T2, N, c2) contiguous."""
 
     @staticmethod
-    def forward(ctx, x_cl, gso_pad, gso_t_pad, cfg: BlockConfig, training: bool, seed: int, offset: int, wsc: WorkspaceCache,
-                *params):
+    def forward(ctx, x_cl, gso_pad, gso_t_pad, cfg: BlockConfig, training: bool, seed: int, offset: int, offset_dev,
+                wsc: WorkspaceCache, *params):
         L = _lib.lib()
         B, T, N, c_in = x_cl.shape
         need_dx = bool(x_cl.requires_grad)
@@ -144,11 +149,12 @@ class _STBlockFn(torch.autograd.Function):
         ws = wsc.get(plan.ws_floats, dev)
         pst = _param_struct(StblockParams, ps)
         L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_pad.data_ptr(), y.data_ptr(),
-                                            saved.data_ptr(), ws.data_ptr(), seed, offset, _stream_of(x_cl)),
+                                            saved.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev), _stream_of(x_cl)),
                 "stgcn_stblock_forward")
         ctx.save_for_backward(x_cl, saved, gso_t_pad, *[p for p in params if p is not None])
         ctx.param_present = [p is not None for p in params]
         ctx.cfg, ctx.training, ctx.seed, ctx.offset, ctx.wsc, ctx.ws = cfg, training, seed, offset, wsc, ws
+        ctx.offset_dev = offset_dev
         ctx.need_dx = need_dx
         ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
         return y
@@ -180,22 +186,24 @@ class _STBlockFn(torch.autograd.Function):
         gst = _param_struct(StblockGrads, grads)
         L.check(L.dll.stgcn_stblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(),
                                              saved.data_ptr(), ws.data_ptr(), C.byref(gst),
-                                             None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _stream_of(x_cl)),
+                                             None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _optr(ctx.offset_dev),
+                                             _stream_of(x_cl)),
                 "stgcn_stblock_backward")
-        return (dx, None, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, None, *grads)
 
 
 def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tensor, cfg: BlockConfig, params, training: bool,
-                  seed: int, offset: int, wsc: WorkspaceCache) -> torch.Tensor:
+                  seed: int, offset: int, wsc: WorkspaceCache, offset_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused STConvBlock.forward (model/layers.py:250-258).
 
     ``x`` is logical (B, c_in, T, N) with ARBITRARY strides (NCHW for the first block, channels-last
     for later ones -- SURVEY.md section 3.3); the result is logical (B, c2, T-2(Kt-1), N) with channels-last
     strides, exactly what the reference's own forward returns.  ``params`` follows PARAM_FIELDS order.
+    ``offset_dev``: optional 1-element int64 device tensor added to ``offset`` on the device (hipGraph replay).
     """
     _check_device(x, "x")
     if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
         raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
     x_cl = x.permute(0, 2, 3, 1).contiguous()       # no copy when x is already channels-last (or c_in == 1)
-    y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, wsc, *params)
+    y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, offset_dev, wsc, *params)
     return y_cl.permute(0, 3, 1, 2)

@@ -61,12 +61,16 @@ class FlatGradAllReduce:
         torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(self.flat.split([p.numel() for p in live])))
 
 
-def make_optimizer(model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-3, name: str = "adamw"):
-    """main.py:147-154 (adamw is the default; nadamw is NAdam with decoupled decay)."""
+def make_optimizer(model: torch.nn.Module, lr: float = 1e-3, weight_decay: float = 1e-3, name: str = "adamw",
+                   capturable: bool = False):
+    """main.py:147-154 (adamw is the default; nadamw is NAdam with decoupled decay).
+    ``capturable``: keep the step counters on the device so that ``step()`` can live inside a hipGraph."""
     params = list(model.parameters())
     on_gpu = len(params) > 0 and params[0].is_cuda
     if name == "adamw":
-        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True if on_gpu else None)
+        if on_gpu:
+            return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True, capturable=capturable)
+        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
     if name == "nadamw":
         return torch.optim.NAdam(params, lr=lr, weight_decay=weight_decay, decoupled_weight_decay=True)
     raise ValueError(f"ERROR: The {name} optimizer is undefined.")   # main.py:154
@@ -83,3 +87,84 @@ def train_step(model, optimizer, x, y, allreduce: Optional[FlatGradAllReduce] = 
         allreduce()
     optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """The loop body of main.py:165-169 captured once into hipGraph(s) and replayed.
+
+    The eager step is host-bound on MI355X (the GPU needs ~1 ms of kernels, Python + ~100 launches need
+    more), so the whole step -- forward, MSE, backward, AdamW, dropout-counter bump -- is recorded with
+    ``torch.cuda.graph`` and replayed with one host call.  Kernel arguments are frozen by capture, hence:
+      * inputs are copied into static buffers before each replay;
+      * the dropout offset comes from a device counter (``DropoutStream.use_device_counter``);
+      * the optimizer is built ``capturable`` (device-side step counts).
+    With world > 1 the step is split into two graphs around ONE eager RCCL all-reduce of the flat gradient
+    buffer (fwd+bwd+flatten | all-reduce | unflatten+AdamW).
+    """
+
+    def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3):
+        from .layers import DropoutStream
+        assert x_example.is_cuda, "hipGraph capture needs the MI355X path"
+        self.model, self.opt, self.world = model, optimizer, world
+        dev = x_example.device
+        self.x = torch.empty_like(x_example)
+        self.y = torch.empty_like(y_example)
+        self.x.copy_(x_example)
+        self.y.copy_(y_example)
+        if DropoutStream.counter is None or DropoutStream.counter.device != dev:
+            DropoutStream.use_device_counter(dev)
+        self.loss = None
+        self.flat = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_once()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.opt.zero_grad(set_to_none=True)
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self.loss = self._fwd_bwd()
+            if world > 1:
+                self.live = [p for p in model.parameters() if p.grad is not None]
+                self.flat = torch.cat([p.grad.reshape(-1) for p in self.live])
+            else:
+                self.opt.step()
+                DropoutStream.advance()
+        self.g2 = None
+        if world > 1:
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+                self.flat.mul_(1.0 / world)
+                torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
+                self.opt.step()
+                DropoutStream.advance()
+
+    def _fwd_bwd(self):
+        y_pred = self.model(self.x).reshape(len(self.x), -1)
+        loss = torch.nn.functional.mse_loss(y_pred, self.y)
+        loss.backward()
+        return loss.detach()
+
+    def _eager_once(self):
+        from .layers import DropoutStream
+        self.opt.zero_grad(set_to_none=True)
+        self._fwd_bwd()
+        if self.world > 1:
+            live = [p for p in self.model.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in live])
+            dist.all_reduce(flat)
+            flat.mul_(1.0 / self.world)
+            torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(flat.split([p.numel() for p in live])))
+        self.opt.step()
+        DropoutStream.advance()
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.g1.replay()
+        if self.g2 is not None:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.g2.replay()
+        return self.loss

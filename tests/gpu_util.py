@@ -56,7 +56,7 @@ def run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None
     x_cl = x.detach().permute(0, 2, 3, 1).contiguous()
     ws2 = torch.empty(plan.ws_floats, device=dev)
     L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gp.data_ptr(), y2.data_ptr(), saved.data_ptr(),
-                                        ws2.data_ptr(), seed, offset, torch.cuda.current_stream().cuda_stream), "fwd")
+                                        ws2.data_ptr(), seed, offset, None, torch.cuda.current_stream().cuda_stream), "fwd")
     torch.cuda.synchronize()
     svn = saved.cpu().numpy()
     T1 = plan.T1

@@ -46,7 +46,7 @@ def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
     ws = torch.full((plan.ws_floats,), float("nan"))
     seed, offset = 1234, 7
     L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), xt.data_ptr(), gp.data_ptr(), y.data_ptr(),
-                                        saved.data_ptr(), ws.data_ptr(), seed, offset, None), "fwd")
+                                        saved.data_ptr(), ws.data_ptr(), seed, offset, None, None), "fwd")
 
     # oracle with the library's own dropout mask
     keep_scale = ops.dropout_mask(y.numel(), 0.5, seed, offset, "cpu").numpy().reshape(y.shape)

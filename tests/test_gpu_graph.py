@@ -1,0 +1,96 @@
+"""-m gpu: the hipGraph-captured training step replays to exactly what eager launches of the same kernels give,
+draws a fresh dropout mask on every replay (device-side counter) and actually trains."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import real_gso
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
+
+
+def _make(droprate):
+    from stgcn_amd import models
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    gso = torch.from_numpy(real_gso("metr_la.cheb_sym_norm_lap")).to(DEV)
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True,
+                                 droprate=droprate, n_his=12)
+    torch.manual_seed(1)
+    return models.STGCNChebGraphConv(args, BLOCKS, 207).to(DEV)
+
+
+def test_graph_replay_equals_eager_and_masks_change():
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer, train_step
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(6, 8, 1, 12, 207, generator=g).to(DEV)
+    ys = torch.randn(6, 8, 207, generator=g).to(DEV)
+
+    # graph path (output-block nn.Dropout uses torch's own graph-safe Philox; compare ST-block behaviour with p_out = 0:
+    # a model-wide droprate applies to both, so use eval-free comparison on droprate 0 for exactness, 0.5 for mask checks)
+    DropoutStream.use_device_counter(torch.device(DEV))
+    DropoutStream.manual_seed(3)
+    m1 = _make(0.0)
+    init = {k: v.clone() for k, v in m1.state_dict().items()}
+    o1 = make_optimizer(m1, capturable=True)
+    gs = GraphedTrainStep(m1, o1, xs[0], ys[0], warmup=2)
+    # GraphedTrainStep's warm-up already trained 2 steps on xs[0]; replicate that eagerly on the twin
+    DropoutStream.disable_device_counter()
+    m2 = _make(0.0)
+    o2 = make_optimizer(m2, capturable=True)
+    for _ in range(2):
+        train_step(m2, o2, xs[0], ys[0])
+    l1 = [float(gs(xs[i], ys[i]).item()) for i in range(1, 6)]
+    l2 = [float(train_step(m2, o2, xs[i], ys[i]).item()) for i in range(1, 6)]
+    assert np.allclose(l1, l2, rtol=1e-6, atol=0), (l1, l2)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    unused = [k for k, p in m1.named_parameters() if p.grad is None]
+    assert len(unused) == 10
+    report = {k: (float((sd1[k] - sd2[k]).abs().max()), float((sd1[k] - init[k]).abs().max()), float((sd2[k] - init[k]).abs().max()))
+              for k in sd1}
+    for k in unused:      # never touched by either path (the reference skips grad-None parameters)
+        assert report[k][1] == 0.0 and report[k][2] == 0.0, (k, report[k])
+    bad = {k: v for k, v in report.items() if v[0] > 1e-6}
+    assert not bad, bad
+    exact = sum(1 for v in report.values() if v[0] == 0.0)
+    print(f"graph vs eager: {exact}/{len(report)} tensors bitwise equal; max diff {max(v[0] for v in report.values()):.3e}")
+
+    # dropout masks change from replay to replay
+    DropoutStream.use_device_counter(torch.device(DEV))
+    DropoutStream.manual_seed(4)
+    m3 = _make(0.5)
+    o3 = make_optimizer(m3, lr=0.0, weight_decay=0.0, capturable=True)     # frozen weights: only the mask varies
+    outs = []
+    h = m3.st_blocks[0].register_forward_hook(lambda mod, i, o: outs.append(o))
+    gs3 = GraphedTrainStep(m3, o3, xs[0], ys[0], warmup=1)
+    h.remove()
+    static_out = outs[-1]                 # the block output tensor captured in the graph
+    pats = []
+    for _ in range(3):
+        gs3(xs[0], ys[0])
+        torch.cuda.synchronize()
+        pats.append((static_out != 0).clone())
+    assert abs(pats[0].float().mean().item() - 0.5) < 0.01
+    assert (pats[0] != pats[1]).float().mean().item() > 0.4 and (pats[1] != pats[2]).float().mean().item() > 0.4
+    DropoutStream.disable_device_counter()
+
+
+def test_graphed_training_reduces_loss():
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 1, 12, 207, generator=g).to(DEV)
+    y = (x[:, 0, -1, :] * 0.5).contiguous()        # learnable target: half of the last observation
+    m = _make(0.5)
+    o = make_optimizer(m, capturable=True)
+    gs = GraphedTrainStep(m, o, x, y, warmup=1)
+    first = float(gs(x, y).item())
+    for _ in range(150):
+        last = gs(x, y)
+    DropoutStream.disable_device_counter()
+    assert float(last.item()) < 0.6 * first
