@@ -135,6 +135,52 @@ int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_p
 int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                        void* stream);
 
+/* ---- Output head: OutputBlock(Ko, last_block_channel, channels, end_channel, n_vertex, act_func, bias, droprate)
+ *      (layers.py:260-284): tmp_conv1 (Ko taps, c_in -> c0, gated) -> LayerNorm([N, c0]) -> fc1 (c0 -> c1) -> ReLU
+ *      -> Dropout -> fc2 (c1 -> end_channel).  stgcn_outblock_forward replaces OutputBlock.forward (layers.py:276-284),
+ *      stgcn_outblock_backward what autograd derives from it.  Supported: c0 in {64,128}, c1 = 128, end_channel = 1. */
+typedef struct stgcn_outblock_desc {
+    int32_t B, T, N;          /* input (B, c_in, T, N) logical; T >= Ko (T == Ko in the reference models)        */
+    int32_t c_in, c0, c1, c_end;
+    int32_t Ko;
+    int32_t act;              /* STGCN_ACT_*                                                                    */
+    int32_t training;
+    float droprate;
+    float ln_eps;
+    int32_t need_dx;
+    int32_t reserved;
+} stgcn_outblock_desc;
+
+/* state_dict keys under "output.": tc_w tmp_conv1.causal_conv.weight (2*c0, c_in, Ko, 1), tc_b .bias,
+ * tc_aw/tc_ab tmp_conv1.align.align_conv.{weight,bias} [read iff c_in > c0], ln_w/ln_b tc1_ln.{weight,bias} (N, c0),
+ * fc1_w fc1.weight (c1, c0), fc1_b fc1.bias or NULL, fc2_w fc2.weight (1, c1), fc2_b fc2.bias or NULL              */
+typedef struct stgcn_outblock_params {
+    const float *tc_w, *tc_b, *tc_aw, *tc_ab, *ln_w, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} stgcn_outblock_params;
+typedef struct stgcn_outblock_grads {
+    float *tc_w, *tc_b, *tc_aw, *tc_ab, *ln_w, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} stgcn_outblock_grads;
+
+typedef struct stgcn_outblock_plan {
+    int64_t T1, rows, rows_in;        /* T1 = T-Ko+1, rows = B*T1*N, rows_in = B*T*N                             */
+    int64_t out_floats;               /* rows * c_end                                                           */
+    int64_t saved_floats, ws_floats;
+    int64_t sv_U, sv_S;               /* [rows][c0]                                                             */
+    int64_t sv_mean, sv_rstd;         /* [B*T1]                                                                 */
+    int64_t sv_yln;                   /* [rows][c0] LayerNorm output                                            */
+    int64_t sv_hd;                    /* [rows][c1] dropout(relu(fc1))                                          */
+    int64_t ws_Wp, ws_Wd, ws_b, ws_W1p, ws_W1d;
+    int64_t ws_c1, ws_c2, ws_dh1, ws_dyln, ws_dZ, ws_part, part_floats;
+} stgcn_outblock_plan;
+
+int stgcn_outblock_plan_query(const stgcn_outblock_desc* desc, stgcn_outblock_plan* plan);
+/* out: (B, T1, N) (= logical (B, 1, T1, N)); dropout element index = row * c1 / 4 + c / 4                        */
+int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x, float* out,
+                           float* saved, float* ws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
+int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
+                            const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
+                            void* stream);
+
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the
  * recorded events, writes {"<kernel label>": {"calls": n, "total_ms": t}, ...} as JSON and resets.      */

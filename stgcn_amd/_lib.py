@@ -50,6 +50,32 @@ class StblockPlan(C.Structure):
     _fields_ = [(n, C.c_int64) for n in PLAN_FIELDS]
 
 
+class OutblockDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("c_end", C.c_int32), ("Ko", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float),
+                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32)]
+
+
+HEAD_PARAM_FIELDS = ["tc_w", "tc_b", "tc_aw", "tc_ab", "ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+
+
+class OutblockParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in HEAD_PARAM_FIELDS]
+
+
+class OutblockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in HEAD_PARAM_FIELDS]
+
+
+HEAD_PLAN_FIELDS = ["T1", "rows", "rows_in", "out_floats", "saved_floats", "ws_floats", "sv_U", "sv_S", "sv_mean", "sv_rstd", "sv_yln",
+                    "sv_hd", "ws_Wp", "ws_Wd", "ws_b", "ws_W1p", "ws_W1d", "ws_c1", "ws_c2", "ws_dh1", "ws_dyln", "ws_dZ", "ws_part",
+                    "part_floats"]
+
+
+class OutblockPlan(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in HEAD_PLAN_FIELDS]
+
+
 class StgcnError(RuntimeError):
     pass
 
@@ -74,6 +100,13 @@ class _Lib:
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
                                              C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        d.stgcn_outblock_plan_query.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockPlan)]
+        d.stgcn_outblock_forward.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        d.stgcn_outblock_backward.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.POINTER(OutblockGrads), C.c_void_p, C.c_void_p]
+        for f in ("stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward"):
+            getattr(d, f).restype = C.c_int
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int
         d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]
@@ -114,4 +147,4 @@ def lib() -> _Lib:
 
 EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
-                    "stgcn_profile_collect"]
+                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward"]

@@ -9,6 +9,7 @@
 
 #include "stgcn_kernels_bwd.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
+#include "stgcn_kernels_head.hip.h"
 
 using namespace stgcn;
 
@@ -153,20 +154,28 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
     return STGCN_OK;
 }
 
-int launch_ln_fwd(const LnFwdArgs& ln, int64_t slabs, hipStream_t st) {
+int launch_ln_fwd(const char* label, const LnFwdArgs& ln, int64_t slabs, hipStream_t st) {
     const dim3 grid((unsigned)slabs), blk(kThreads);
     const int n4 = ln.n / 4;
-    if (n4 <= 16 * kThreads) STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<16>), grid, blk, 64, ln);
-    else if (n4 <= 32 * kThreads) STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<32>), grid, blk, 64, ln);
-    else STGCN_LAUNCH("ln_fwd", st, (ln_fwd_kernel<0>), grid, blk, 64, ln);
+    if (n4 <= 16 * kThreads) STGCN_LAUNCH(label, st, (ln_fwd_kernel<16>), grid, blk, 64, ln);
+    else if (n4 <= 32 * kThreads) STGCN_LAUNCH(label, st, (ln_fwd_kernel<32>), grid, blk, 64, ln);
+    else STGCN_LAUNCH(label, st, (ln_fwd_kernel<0>), grid, blk, 64, ln);
     return STGCN_OK;
 }
 
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
-    const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
-    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout) * sizeof(float);
-    if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2>), grid, blk, lds, a);
-    else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4>), grid, blk, lds, a);
+    // 64-row tiles when that still fills the chip, else 32-row tiles (the output head has only B*N rows)
+    const bool small = cdiv(a.ts.rows, kTileRows) < 256;
+    const int tr = small ? 32 : kTileRows;
+    const dim3 grid(cdiv(a.ts.rows, tr)), blk(kThreads);
+    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
+    if (a.Cout == 64) {
+        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 2>), grid, blk, lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 4>), grid, blk, lds, a);
+    } else {
+        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 2>), grid, blk, lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 4>), grid, blk, lds, a);
+    }
     return STGCN_OK;
 }
 
@@ -380,11 +389,12 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     ln.n = d->N * d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
     ln.eps = d->ln_eps; ln.keep_scale = 1.0f / (1.0f - d->droprate); ln.thresh = drop_thresh(d->droprate);
     ln.seed = seed; ln.offset = offset; ln.offset_dev = offset_dev;
-    rc = launch_ln_fwd(ln, v.slabs2, st);
+    rc = launch_ln_fwd("ln_fwd", ln, v.slabs2, st);
     if (rc) return rc;
     return STGCN_OK;
 }
 
 #include "stgcn_capi_bwd.inc"
+#include "stgcn_capi_head.inc"
 
 }  // extern "C"

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);
     int* rowt = rowbase + 64;
-    float* At = stgcn_smem + 128;
+    float* At = stgcn_smem + kTileHdr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
     const long row0 = (long)blockIdx.x * kTileRows;
     const int mt0 = LAYOUT == 0 ? 0 : (LAYOUT == 1 ? wave : 2 * (wave >> 1));
@@ -224,7 +224,19 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
 
     tile_rowinfo(a.ts, row0, rowbase, rowt);
     __syncthreads();
-
+    // taps whose source time step t - tap is out of range for EVERY row of this tile contribute exact zeros:
+    // skip their K segments (the head has T1 = 1: 3 of its 4 taps are empty for any given output step)
+    if (wave == 0) {
+        unsigned m = 0;
+        const int t = rowt[lane];   // 64 rows == 64 lanes
+        for (int tap = 0; tap < a.ts.taps && tap < 32; ++tap) {
+            const int tt = t - tap;
+            if (tt >= 0 && tt < a.ts.Tsrc) m |= 1u << tap;
+        }
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) m |= __shfl_xor(m, x);
+        if (lane == 0) rowbase[128] = (int)m;   // scratch word 0 of the tile header
+    }
     f32x4 acc[WM][NT], acc2[WM][NT];   // two accumulator sets (even / odd chunks) for MFMA ILP
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -233,10 +245,18 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
             acc[i][j] = zero4();
             acc2[i][j] = zero4();
         }
+    __syncthreads();
+    const unsigned tapmask = (unsigned)rowbase[128];
     const int KP = a.KCH * 16;
+    bool first = true;
     for (int k0 = 0; k0 < KP; k0 += kSegMax) {
         const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
-        if (k0 > 0) __syncthreads();
+        const int tap_lo = k0 / a.ts.C, tap_hi = (k0 + kseg - 1) / a.ts.C;
+        bool any = false;
+        for (int tap = tap_lo; tap <= tap_hi; ++tap) any = any || tap >= 32 || ((tapmask >> tap) & 1u);
+        if (!any) continue;   // uniform over the workgroup
+        if (!first) __syncthreads();
+        first = false;
         tile_load_segment(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
         __syncthreads();
         const int half = (kseg >> 4) >> 1, rest = (kseg >> 4) - half;

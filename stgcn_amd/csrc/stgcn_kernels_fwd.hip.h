@@ -14,7 +14,8 @@ namespace stgcn {
 //     Wp[((nt*KCH + kc)*64 + lane)*4 + s] = W[kc*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
 // so a wave fetches one (nt, kc) fragment with a single coalesced 1 KiB load (16 B per lane).
 // ================================================================================================
-enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5 };
+enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5,
+                PK_LIN_FWD = 6, PK_LIN_BWD = 7 };   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
 
 struct PackJob {
     int kind;
@@ -67,8 +68,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             if (col < j.Cin) v = tconv_weff(j, kidx / NC, col, kidx % NC);
         } else if (j.kind == PK_ALIGN_FWD) {   // A = H @ Wa : K = c0 (=Cin), cols = c1 (=Cout)
             if (kidx < j.Cin && col < j.Cout) v = (j.Cin > j.Cout) ? j.w[(size_t)col * j.Cin + kidx] : (kidx == col ? 1.f : 0.f);
-        } else {                                // PK_ALIGN_BWD: dH = dA @ Wa^T : K = c1, cols = c0
+        } else if (j.kind == PK_ALIGN_BWD) {   // dH = dA @ Wa^T : K = c1, cols = c0
             if (kidx < j.Cout && col < j.Cin) v = (j.Cin > j.Cout) ? j.w[(size_t)kidx * j.Cin + col] : (kidx == col ? 1.f : 0.f);
+        } else if (j.kind == PK_LIN_FWD) {     // K = in (Cin), cols = out (Cout): B[k][o] = weight[o][k]
+            if (kidx < j.Cin && col < j.Cout) v = j.w[(size_t)col * j.Cin + kidx];
+        } else {                                // PK_LIN_BWD: K = out, cols = in: B[o][i] = weight[o][i]
+            if (kidx < j.Cout && col < j.Cin) v = j.w[(size_t)kidx * j.Cin + col];
         }
     }
     j.dst[e] = v;
@@ -100,9 +105,10 @@ struct TapSrc {
 
 // per-tile row bookkeeping in LDS: rowbase[r] = flat source row of tap 0, rowt[r] = t (or -2^20 if the
 // row is beyond the tensor, which makes every tap invalid)
+template <int TR = kTileRows>
 __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, int* rowbase, int* rowt) {
     const int r = threadIdx.x;
-    if (r < kTileRows) {
+    if (r < TR) {
         const long R = tile_row0 + r;
         int base = 0, t = -(1 << 20);
         if (R < ts.rows) {
@@ -117,13 +123,14 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
     }
 }
 
-// Stage columns [k0, k0 + kseg) of the implicit matrix for the 64 rows of the tile into At[64][lda].
+// Stage columns [k0, k0 + kseg) of the implicit matrix for the TR rows of the tile into At[TR][lda].
+template <int TR = kTileRows>
 __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                   float* At, int lda) {
     const int K = ts.taps * ts.C;
     if ((ts.C & 3) == 0) {
         const int q4 = kseg >> 2;
-        for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kThreads) {
+        for (int idx = threadIdx.x; idx < TR * q4; idx += kThreads) {
             const int r = idx / q4, q = idx - r * q4;
             const int kidx = k0 + 4 * q;
             f32x4 v = zero4();
@@ -135,7 +142,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             st4(At + r * lda + 4 * q, v);
         }
     } else {   // narrow inputs (C = 1 for the first block): scalar gather
-        for (int idx = threadIdx.x; idx < kTileRows * kseg; idx += kThreads) {
+        for (int idx = threadIdx.x; idx < TR * kseg; idx += kThreads) {
             const int r = idx / kseg, q = idx - r * kseg;
             const int kidx = k0 + q;
             float v = 0.f;
@@ -170,11 +177,12 @@ __device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, i
     }
 }
 
-// LDS carve for the row-tile GEMM kernels (floats): [rowbase 64 ints][rowt 64 ints][At 64 x (kSegMax+4)]
+// LDS carve for the row-tile GEMM kernels (floats): [rowbase 64 ints][rowt 64 ints][4 scratch words][At 64 x (kSegMax+4)]
+constexpr int kTileHdr = 132;
 // (tconv_fwd re-uses At as its [64][NC + 4] epilogue tile: tile_lds_floats(NC))
 constexpr int kLdaMax = kSegMax + 4;
-constexpr int kTileLdsFloats = 128 + kTileRows * kLdaMax;
-inline int tile_lds_floats(int nc) { return 128 + kTileRows * ((nc > kSegMax ? nc : kSegMax) + 4); }
+constexpr int kTileLdsFloats = kTileHdr + kTileRows * kLdaMax;
+inline int tile_lds_floats(int nc, int rows = kTileRows) { return kTileHdr + rows * ((nc > kSegMax ? nc : kSegMax) + 4); }
 
 // ================================================================================================
 // F1: gated temporal convolution  Z = im2col(x) @ W_eff + b_eff ; U = Z[:, :Cout] ; S = sigmoid(Z[:, Cout:])
@@ -197,21 +205,22 @@ struct TconvFwdArgs {
     int c1;
 };
 
-template <int NT>
+template <int NT, int WM>
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
+    constexpr int TR = WM * 16;   // rows per tile
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);
     int* rowt = rowbase + 64;
-    float* At = stgcn_smem + 128;
+    float* At = stgcn_smem + kTileHdr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)blockIdx.x * kTileRows;
+    const long row0 = (long)blockIdx.x * TR;
 
-    tile_rowinfo(a.ts, row0, rowbase, rowt);
+    tile_rowinfo<TR>(a.ts, row0, rowbase, rowt);
     __syncthreads();
 
-    f32x4 acc[4][NT];
+    f32x4 acc[WM][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
 
@@ -219,9 +228,9 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
     for (int k0 = 0; k0 < KP; k0 += kSegMax) {
         const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
         if (k0 > 0) __syncthreads();   // previous segment fully consumed
-        tile_load_segment(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        tile_load_segment<TR>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
         __syncthreads();
-        seg_mma<4, NT>(acc, At, kseg + 4, 0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+        seg_mma<WM, NT>(acc, At, kseg + 4, 0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
     }
 
     // ---- epilogue: accumulators -> LDS tile Zt[64][NC + 4] -> row-major float4 pass (coalesced U/S/H stores) ----
@@ -233,13 +242,13 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
     for (int j = 0; j < NT; ++j) {
         const int col = (wave + 4 * j) * 16 + l15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
     }
     __syncthreads();
     const int c4n = Cout >> 2;
-    for (int idx = threadIdx.x; idx < kTileRows * c4n; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < TR * c4n; idx += kThreads) {
         const int row = idx / c4n, c4 = idx - row * c4n;
         const long R = row0 + row;
         const f32x4 p = ld4(Zt + row * ldz + 4 * c4), q = ld4(Zt + row * ldz + Cout + 4 * c4);
@@ -263,7 +272,8 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
     __syncthreads();
     const int ldh = ldz;
 
-    // ---- align epilogue: A[64 x c1] = H[64 x Cout] @ Wa + ba ; wave w owns rows 16w..16w+15 -------
+    // ---- align epilogue: A[TR x c1] = H[TR x Cout] @ Wa + ba ; wave w (< WM) owns rows 16w..16w+15 -------
+    if (wave >= WM) return;
     const int KCHa = Cout >> 4;
     for (int nt = 0; nt < (a.c1 >> 4); ++nt) {
         f32x4 c0 = zero4(), c1v = zero4();

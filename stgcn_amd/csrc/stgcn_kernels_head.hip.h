@@ -1,0 +1,182 @@
+// Kernels of the fused output head ('TNFF' OutputBlock, reference model/layers.py:260-284):
+//   temporal conv (Ko taps) + GLU  -> tconv_fwd_kernel (stgcn_kernels_fwd.hip.h)
+//   LayerNorm([N, c0])             -> ln_fwd_kernel
+//   fc1 + ReLU + dropout + fc2     -> fc_fwd_kernel            (layers.py:279-282)
+// and their backward: fc_bwd_kernel here, LayerNorm / conv backward from stgcn_kernels_bwd.hip.h.
+#pragma once
+#include "stgcn_kernels_fwd.hip.h"
+
+namespace stgcn {
+
+// ================================================================================================
+// fc1 (c0 -> c1) + ReLU + inverted dropout + fc2 (c1 -> 1) on TR-row tiles of the LayerNorm output.
+//   hd  = dropout(relu(yln @ W1^T + b1))      saved for backward
+//   out = hd @ w2 + b2                        one value per (b, n) row
+// wave w owns output-channel tiles w + 4j (NT = c1 / 64); c1 must be 128 (32 float4 columns per row, one
+// per lane of a half-wave, so the fc2 dot product is a half-wave shuffle reduction).
+// ================================================================================================
+struct FcFwdArgs {
+    TapSrc ts;            // yln [rows][c0] (taps = 1)
+    const float* W1p;     // packed PK_LIN_FWD: K = c0, cols = c1
+    const float* b1;      // [c1] or null
+    const float* w2;      // [c1]
+    const float* b2;      // [1] or null
+    float* hd;            // [rows][c1]
+    float* out;           // [rows]
+    int KCH, c1, training;
+    float keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+    const uint64_t* offset_dev;
+};
+
+template <int WM>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
+    constexpr int TR = WM * 16, NT = 2;
+    extern __shared__ float stgcn_smem[];
+    int* rowbase = reinterpret_cast<int*>(stgcn_smem);
+    int* rowt = rowbase + 64;
+    float* At = stgcn_smem + kTileHdr;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const long row0 = (long)blockIdx.x * TR;
+    tile_rowinfo<TR>(a.ts, row0, rowbase, rowt);
+    __syncthreads();
+    const int KP = a.KCH * 16;   // = c0 <= 128: one segment
+    tile_load_segment<TR>(a.ts, rowbase, rowt, 0, KP, At, KP + 4);
+    __syncthreads();
+    f32x4 acc[WM][NT];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+    seg_mma<WM, NT>(acc, At, KP + 4, 0, a.KCH, a.W1p, 0, a.KCH, wave, 4);
+    __syncthreads();
+    const int c1 = a.c1, ldz = c1 + 4;
+    float* Zt = At;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+    const int c4n = c1 >> 2;   // 32
+    const float b2 = a.b2 ? a.b2[0] : 0.f;
+    for (int idx = threadIdx.x; idx < TR * c4n; idx += kThreads) {
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        const long R = row0 + row;
+        f32x4 h = ld4(Zt + row * ldz + 4 * c4);
+        const f32x4 w2 = ld4(a.w2 + 4 * c4);
+        if (a.b1) {
+            const f32x4 b1 = ld4(a.b1 + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] += b1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = fmaxf(h[i], 0.f);
+        if (a.training) {
+            const f32x4 k = dropout_scale4((uint64_t)R * c4n + c4, a.seed, off, a.thresh, a.keep_scale);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] *= k[i];
+        }
+        float p = h[0] * w2[0] + h[1] * w2[1] + h[2] * w2[2] + h[3] * w2[3];
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) p += __shfl_xor(p, m);   // the 32 lanes of a half-wave hold one row
+        if (R < a.ts.rows) {
+            st4(a.hd + (size_t)R * c1 + 4 * c4, h);
+            if (c4 == 0) a.out[R] = p + b2;
+        }
+    }
+}
+
+// ================================================================================================
+// Backward of fc2 / dropout / ReLU / fc1 on TR-row tiles (grid-stride, so that partials stay few):
+//   dh1 = dout[row] * w2[c] * (hd != 0 ? keep_scale : 0)            (relu' and the dropout mask in one test)
+//   dyln = dh1 @ W1                                                   -> [rows][c0]
+//   partials: dw2[c] = sum_rows dout * hd ; db2 = sum_rows dout       (dW1 / db1 come from tconv_bwd_weight_kernel)
+// ================================================================================================
+struct FcBwdArgs {
+    const float* dout;    // [rows]
+    const float* hd;      // [rows][c1]
+    const float* w2;      // [c1]
+    const float* W1d;     // packed PK_LIN_BWD: K = c1, cols = c0
+    float* dh1;           // [rows][c1]
+    float* dyln;          // [rows][c0]
+    float* part;          // [wgs][c1 + 1]
+    long rows;
+    int c0, c1, KCH;      // KCH = c1 / 16
+    float grad_scale;     // keep_scale when dropout was active, else 1
+};
+
+template <int WM, int NT>
+__global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
+    constexpr int TR = WM * 16;
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int c1 = a.c1, c0 = a.c0, lda = c1 + 4, c4n = c1 >> 2;
+    float* At = stgcn_smem;                // [TR][lda]
+    float* red = stgcn_smem + TR * lda;    // [8][c1] + [8]
+    const long tiles = (a.rows + TR - 1) / TR;
+    const int c4 = tid % c4n, rsub = tid / c4n;            // c4n == 32 -> rsub in 0..7, fixed channel group per thread
+    f32x4 dw2 = zero4();
+    float db2 = 0.f;
+    const f32x4 w2 = ld4(a.w2 + 4 * c4);
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long row0 = t * TR;
+        __syncthreads();
+        for (int row = rsub; row < TR; row += kThreads / c4n) {
+            const long R = row0 + row;
+            f32x4 d = zero4();
+            if (R < a.rows) {
+                const float go = a.dout[R];
+                const f32x4 h = ld4(a.hd + (size_t)R * c1 + 4 * c4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d[i] = h[i] != 0.f ? go * w2[i] * a.grad_scale : 0.f;
+                    dw2[i] += go * h[i];
+                }
+                if (c4 == 0) db2 += go;
+                st4(a.dh1 + (size_t)R * c1 + 4 * c4, d);
+            }
+            st4(At + row * lda + 4 * c4, d);
+        }
+        __syncthreads();
+        f32x4 acc[WM][NT];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+        seg_mma<WM, NT>(acc, At, lda, 0, a.KCH, a.W1d, 0, a.KCH, wave, 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long R = row0 + i * 16 + 4 * g + r;
+                    if (R < a.rows && col < c0) a.dyln[(size_t)R * c0 + col] = acc[i][j][r];
+                }
+        }
+    }
+    __syncthreads();
+    st4(red + rsub * c1 + 4 * c4, dw2);
+    if (c4 == 0) red[8 * c1 + rsub] = db2;
+    __syncthreads();
+    float* part = a.part + (size_t)blockIdx.x * (c1 + 1);
+    if (tid < c1) {
+        float s = 0.f;
+        for (int k = 0; k < kThreads / c4n; ++k) s += red[k * c1 + tid];
+        part[tid] = s;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int k = 0; k < kThreads / c4n; ++k) s += red[8 * c1 + k];
+        part[c1] = s;
+    }
+}
+
+}  // namespace stgcn

@@ -8,9 +8,9 @@ Reference map (hazdzz/STGCN, model/layers.py):
     GraphConv :174-206 | GraphConvLayer :208-231 | STConvBlock :233-258 | OutputBlock :260-284
 
 The sub-layer modules own the parameters (that is what fixes the checkpoint keys).  Their own
-``forward`` methods are plain tensor expressions kept for API completeness and for the output head
-(``OutputBlock`` -- SURVEY.md section 8f "next #1": it still runs as stock PyTorch-ROCm ops); the ST blocks never
-call them -- ``STConvBlock.forward`` hands the parameter pointers to ``stgcn_stblock_forward``.
+``forward`` methods are plain tensor expressions kept for API completeness; neither the ST blocks nor the
+output head call them -- ``STConvBlock.forward`` / ``OutputBlock.forward`` hand the parameter pointers to
+``stgcn_stblock_forward`` / ``stgcn_outblock_forward``.
 """
 from __future__ import annotations
 
@@ -263,7 +263,9 @@ class STConvBlock(nn.Module):
 
 
 class OutputBlock(nn.Module):
-    """'TNFF' head (layers.py:260-284).  Still stock PyTorch-ROCm ops (SURVEY.md section 8f next #1)."""
+    """'TNFF' head (layers.py:260-284) as one fused HIP operator (fwd) + one (bwd) for the reference's
+    channel plan ([128, 128] -> 1).  Other channel plans are outside what the kernels cover and run the same
+    arithmetic as composed PyTorch-ROCm ops (``_forward_composed``)."""
 
     def __init__(self, Ko, last_block_channel, channels, end_channel, n_vertex, act_func, bias, droprate):
         super().__init__()
@@ -273,11 +275,31 @@ class OutputBlock(nn.Module):
         self.tc1_ln = nn.LayerNorm([n_vertex, channels[0]], eps=1e-12)
         self.relu = nn.ReLU()
         self.dropout = nn.Dropout(p=droprate)
+        self.cfg = ops.HeadConfig(Ko=Ko, n_vertex=n_vertex, c_in=last_block_channel, channels=(channels[0], channels[1]),
+                                  end_channel=end_channel, act_func=act_func, droprate=float(droprate), ln_eps=self.tc1_ln.eps)
+        self._ws = ops.WorkspaceCache()
+        self._site = DropoutStream.new_site()
 
-    def forward(self, x):
+    def _params(self):
+        t = self.tmp_conv1
+        return [t.causal_conv.weight, t.causal_conv.bias, t.align.align_conv.weight, t.align.align_conv.bias,
+                self.tc1_ln.weight, self.tc1_ln.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
+
+    def _forward_composed(self, x):
         x = self.tmp_conv1(x)
         x = self.tc1_ln(x.permute(0, 2, 3, 1))
         x = self.fc1(x)
         x = self.relu(x)
         x = self.dropout(x)
         return self.fc2(x).permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        if not ops.head_supported(self.cfg):
+            return self._forward_composed(x)
+        training = self.training and self.cfg.droprate > 0.0
+        counter = DropoutStream.counter if training else None
+        if counter is not None:
+            offset = self._site
+        else:
+            offset = DropoutStream.next_offset() if training else 0
+        return ops.output_block(x, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)

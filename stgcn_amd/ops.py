@@ -15,7 +15,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import PARAM_FIELDS, StblockDesc, StblockGrads, StblockParams, StblockPlan
+from ._lib import (HEAD_PARAM_FIELDS, PARAM_FIELDS, OutblockDesc, OutblockGrads, OutblockParams, OutblockPlan, StblockDesc,
+                   StblockGrads, StblockParams, StblockPlan)
 
 
 @dataclass(frozen=True)
@@ -207,3 +208,116 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     x_cl = x.permute(0, 2, 3, 1).contiguous()       # no copy when x is already channels-last (or c_in == 1)
     y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, offset_dev, wsc, *params)
     return y_cl.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------------ output head
+@dataclass(frozen=True)
+class HeadConfig:
+    """Static configuration of OutputBlock (constructor arguments at model/layers.py:267)."""
+    Ko: int
+    n_vertex: int
+    c_in: int
+    channels: Tuple[int, int]
+    end_channel: int
+    act_func: str
+    droprate: float
+    ln_eps: float = 1e-12
+
+
+def head_supported(cfg: HeadConfig) -> bool:
+    return (cfg.channels[0] in (64, 128) and cfg.channels[1] == 128 and cfg.end_channel == 1 and cfg.act_func in _lib.ACT
+            and (cfg.c_in % 4 == 0 or cfg.Ko * cfg.c_in <= 16))
+
+
+def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool) -> OutblockDesc:
+    if cfg.act_func not in _lib.ACT:
+        raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")
+    d = OutblockDesc()
+    d.B, d.T, d.N, d.c_in = B, T, cfg.n_vertex, cfg.c_in
+    d.c0, d.c1 = cfg.channels
+    d.c_end, d.Ko = cfg.end_channel, cfg.Ko
+    d.act = _lib.ACT[cfg.act_func]
+    d.training = 1 if training else 0
+    d.droprate, d.ln_eps = float(cfg.droprate), float(cfg.ln_eps)
+    d.need_dx = 1 if need_dx else 0
+    return d
+
+
+_head_plan_cache: Dict[tuple, OutblockPlan] = {}
+
+
+def query_head_plan(desc: OutblockDesc) -> OutblockPlan:
+    key = tuple(getattr(desc, f) for f, _ in OutblockDesc._fields_)
+    p = _head_plan_cache.get(key)
+    if p is None:
+        L = _lib.lib()
+        p = OutblockPlan()
+        L.check(L.dll.stgcn_outblock_plan_query(C.byref(desc), C.byref(p)), "stgcn_outblock_plan_query")
+        _head_plan_cache[key] = p
+    return p
+
+
+def _head_struct(cls, tensors):
+    s = cls()
+    for name, t in zip(HEAD_PARAM_FIELDS, tensors):
+        setattr(s, name, None if t is None else t.data_ptr())
+    return s
+
+
+class _OutBlockFn(torch.autograd.Function):
+    """x_cl: (B, T, N, c_in) contiguous -> out: (B, T1, N)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, cfg: HeadConfig, training: bool, seed: int, offset: int, offset_dev, wsc: WorkspaceCache, *params):
+        L = _lib.lib()
+        B, T, N, c_in = x_cl.shape
+        need_dx = bool(x_cl.requires_grad)
+        desc = make_head_desc(cfg, B, T, training, need_dx)
+        plan = query_head_plan(desc)
+        dev = x_cl.device
+        ps = [None if p is None else p.detach() for p in params]
+        out = torch.empty(B, plan.T1, N, dtype=torch.float32, device=dev)
+        saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=dev)
+        ws = wsc.get(plan.ws_floats, dev)
+        pst = _head_struct(OutblockParams, ps)
+        L.check(L.dll.stgcn_outblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), out.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+                                             seed, offset, _optr(offset_dev), _stream_of(x_cl)), "stgcn_outblock_forward")
+        ctx.save_for_backward(x_cl, saved, *[p for p in params if p is not None])
+        ctx.param_present = [p is not None for p in params]
+        ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
+        ctx.cfg, ctx.training, ctx.ws, ctx.need_dx = cfg, training, ws, need_dx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x_cl, saved, *present = ctx.saved_tensors
+        it = iter(present)
+        params = [next(it) if pr else None for pr in ctx.param_present]
+        cfg = ctx.cfg
+        B, T, N, c_in = x_cl.shape
+        desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx)
+        dout = dout.contiguous()
+        used = {"tc_aw": c_in > cfg.channels[0], "tc_ab": c_in > cfg.channels[0]}
+        grads = []
+        for name, p, need in zip(HEAD_PARAM_FIELDS, params, ctx.param_needs_grad):
+            grads.append(torch.empty_like(p) if (p is not None and need and used.get(name, True)) else None)
+        dx = torch.empty_like(x_cl) if ctx.need_dx else None
+        pst = _head_struct(OutblockParams, [None if p is None else p.detach() for p in params])
+        gst = _head_struct(OutblockGrads, grads)
+        L.check(L.dll.stgcn_outblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
+                                              ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(), _stream_of(x_cl)),
+                "stgcn_outblock_backward")
+        return (dx, None, None, None, None, None, None, *grads)
+
+
+def output_block(x: torch.Tensor, cfg: HeadConfig, params, training: bool, seed: int, offset: int, wsc: WorkspaceCache,
+                 offset_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused OutputBlock.forward (model/layers.py:276-284): logical (B, c_in, T, N) -> (B, 1, T-Ko+1, N).
+    ``params`` follows HEAD_PARAM_FIELDS order."""
+    _check_device(x, "x")
+    if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
+        raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
+    x_cl = x.permute(0, 2, 3, 1).contiguous()
+    out = _OutBlockFn.apply(x_cl, cfg, training, seed, offset, offset_dev, wsc, *params)
+    return out.unsqueeze(1)        # (B, 1, T1, N) == fc2(x).permute(0, 3, 1, 2) with end_channel 1

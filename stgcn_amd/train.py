@@ -113,6 +113,7 @@ class GraphedTrainStep:
         self.y.copy_(y_example)
         if DropoutStream.counter is None or DropoutStream.counter.device != dev:
             DropoutStream.use_device_counter(dev)
+        self.counter = DropoutStream.counter     # the captured kernels hold this address: keep it alive with the graph
         self.loss = None
         self.flat = None
         side = torch.cuda.Stream(device=dev)

@@ -18,6 +18,7 @@ CASES = [
     (64, (64, 16, 64), 3, 3, "graph_conv", "gtu", 35, 1, 5),
     (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5),
     (1, (64, 16, 64), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5),
+    (1, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 300, 6, 12),   # >= 256 row tiles: exercises the 64-row tile path
 ]
 
 

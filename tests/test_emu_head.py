@@ -1,0 +1,55 @@
+"""Fused output head (OutputBlock) on the CPU emulator vs the autograd oracle (float64), with the library's
+own dropout mask."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stgcn_oracle as orc
+from stgcn_amd import _lib, ops
+from tests.emu_util import bind_emulator
+
+CASES = [
+    # c_in, (c0, c1), Ko, N, B, T, act, training
+    (64, (128, 128), 4, 21, 2, 4, "glu", True),
+    (64, (128, 128), 3, 9, 1, 5, "gtu", False),      # T1 = 3 > 1
+    (16, (64, 128), 2, 33, 2, 2, "glu", True),
+]
+
+
+@pytest.mark.parametrize("c_in,channels,Ko,N,B,T,act,training", CASES)
+def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training):
+    bind_emulator()
+    T1 = T - Ko + 1
+    n_his = Ko          # makes cfg.Ko == Ko with zero ST blocks
+    cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=n_his, act_func=act, droprate=0.5, blocks=[[c_in], list(channels), [1]])
+    assert cfg.n_st_blocks == 0 and cfg.Ko == Ko
+    p = {k: v for k, v in orc.random_params(cfg, N, seed=5, dtype=torch.float32).items() if k.startswith("output.")}
+    rs = np.random.RandomState(2)
+    x_np = rs.standard_normal((B, c_in, T, N)).astype(np.float32)
+    dout_np = rs.standard_normal((B, 1, T1, N)).astype(np.float32)
+    hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=c_in, channels=tuple(channels), end_channel=1, act_func=act, droprate=0.5)
+    names = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight",
+             "tmp_conv1.align.align_conv.bias", "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    params = [p["output." + n].clone().requires_grad_(True) for n in names]
+    x = torch.from_numpy(x_np).requires_grad_(True)
+    seed, offset = 77, 5
+    out = ops.output_block(x, hcfg, params, training, seed, offset, ops.WorkspaceCache())
+    assert out.shape == (B, 1, T1, N)
+    out.backward(torch.from_numpy(dout_np))
+
+    keep = None
+    if training:
+        ks = ops.dropout_mask(B * T1 * N * channels[1], 0.5, seed, offset, "cpu").reshape(B, T1, N, channels[1])
+        keep = (ks > 0).double()
+    leaves = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    xr = torch.from_numpy(x_np).double().requires_grad_(True)
+    ref = orc.output_block(xr, leaves, "output.", cfg, Ko, c_in, channels, 1, keep)
+    gr = torch.autograd.grad(ref, [xr] + [leaves["output." + n] for n in names], torch.from_numpy(dout_np).double(), allow_unused=True)
+    assert (out.detach().double() - ref.detach()).abs().max() < 5e-5
+    rel = lambda a, b: float((a.double() - b).abs().max() / max(1e-30, float(b.abs().max())))
+    assert rel(x.grad, gr[0]) < 2e-4, "dx"
+    for n, prm, g in zip(names, params, gr[1:]):
+        if g is None:
+            assert prm.grad is None, n
+        else:
+            assert prm.grad is not None and rel(prm.grad, g) < 2e-4, (n, rel(prm.grad, g))
