@@ -95,10 +95,11 @@ typedef struct stgcn_stblock_plan {
     int64_t sv_G;                     /* [rows1][c1] relu(graph conv + residual)                       */
     int64_t sv_U2, sv_S2;             /* [rows2][c2]                                                   */
     int64_t sv_mean, sv_rstd;         /* [B*T2]                                                        */
+    int64_t sv_rowstat;               /* [rows2][2] per-row LayerNorm partials (mean, M2) of tmp_conv2 output */
     /* ws: packed weights */
     int64_t ws_W1p, ws_W1d, ws_b1, ws_Wap, ws_WaT, ws_ba, ws_W2p, ws_W2d, ws_b2;
     /* ws: backward temporaries */
-    int64_t ws_c1, ws_c2;             /* [B*T2] LayerNorm backward slab means                          */
+    int64_t ws_rowstat_b;             /* [rows2][2] LayerNorm backward row partials (sum g, sum g*xhat)    */
     int64_t ws_dZ2;                   /* [rows2][2*c2]                                                 */
     int64_t ws_dYg;                   /* [rows1][c1]  d(relu out) masked                               */
     int64_t ws_dA;                    /* [rows1][c1]                                                   */
@@ -169,8 +170,9 @@ typedef struct stgcn_outblock_plan {
     int64_t sv_mean, sv_rstd;         /* [B*T1]                                                                 */
     int64_t sv_yln;                   /* [rows][c0] LayerNorm output                                            */
     int64_t sv_hd;                    /* [rows][c1] dropout(relu(fc1))                                          */
+    int64_t sv_rowstat;               /* [rows][2]                                                              */
     int64_t ws_Wp, ws_Wd, ws_b, ws_W1p, ws_W1d;
-    int64_t ws_c1, ws_c2, ws_dh1, ws_dyln, ws_dZ, ws_part, part_floats;
+    int64_t ws_rowstat_b, ws_dh1, ws_dyln, ws_dZ, ws_part, part_floats;
 } stgcn_outblock_plan;
 
 int stgcn_outblock_plan_query(const stgcn_outblock_desc* desc, stgcn_outblock_plan* plan);
@@ -180,6 +182,21 @@ int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock
 int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                             const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
                             void* stream);
+
+/* ---- Optimizer step: torch.optim.AdamW(lr, weight_decay) as main.py:148 configures it (betas (0.9, 0.999), eps 1e-8,
+ *      amsgrad False), applied by optimizer.step() at main.py:169.  `tensors` is a HOST array of `count` entries (device
+ *      pointers inside); only parameters that received a gradient are listed (the reference skips grad-None tensors).
+ *      step is the 1-based update count; step_dev / lr_dev (nullable DEVICE scalars) override step / lr at run time so a
+ *      captured hipGraph keeps counting and follows the LR schedule.                                                      */
+typedef struct stgcn_adamw_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} stgcn_adamw_tensor;
+int stgcn_adamw_step(const stgcn_adamw_tensor* tensors, int32_t count, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int64_t step, const int64_t* step_dev, const float* lr_dev, void* stream);
 
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the

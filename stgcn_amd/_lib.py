@@ -41,9 +41,9 @@ class StblockGrads(C.Structure):
 
 
 PLAN_FIELDS = ["T1", "T2", "rows1", "rows2", "NP", "y_floats", "saved_floats", "ws_floats",
-               "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd",
+               "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd", "sv_rowstat",
                "ws_W1p", "ws_W1d", "ws_b1", "ws_Wap", "ws_WaT", "ws_ba", "ws_W2p", "ws_W2d", "ws_b2",
-               "ws_c1", "ws_c2", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats"]
+               "ws_rowstat_b", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats"]
 
 
 class StblockPlan(C.Structure):
@@ -68,12 +68,16 @@ class OutblockGrads(C.Structure):
 
 
 HEAD_PLAN_FIELDS = ["T1", "rows", "rows_in", "out_floats", "saved_floats", "ws_floats", "sv_U", "sv_S", "sv_mean", "sv_rstd", "sv_yln",
-                    "sv_hd", "ws_Wp", "ws_Wd", "ws_b", "ws_W1p", "ws_W1d", "ws_c1", "ws_c2", "ws_dh1", "ws_dyln", "ws_dZ", "ws_part",
+                    "sv_hd", "sv_rowstat", "ws_Wp", "ws_Wd", "ws_b", "ws_W1p", "ws_W1d", "ws_rowstat_b", "ws_dh1", "ws_dyln", "ws_dZ", "ws_part",
                     "part_floats"]
 
 
 class OutblockPlan(C.Structure):
     _fields_ = [(n, C.c_int64) for n in HEAD_PLAN_FIELDS]
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64)]
 
 
 class StgcnError(RuntimeError):
@@ -107,6 +111,9 @@ class _Lib:
                                               C.c_void_p, C.POINTER(OutblockGrads), C.c_void_p, C.c_void_p]
         for f in ("stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward"):
             getattr(d, f).restype = C.c_int
+        d.stgcn_adamw_step.argtypes = [C.POINTER(AdamwTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        d.stgcn_adamw_step.restype = C.c_int
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int
         d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]
@@ -147,4 +154,4 @@ def lib() -> _Lib:
 
 EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
-                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward"]
+                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step"]

@@ -154,12 +154,11 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
     return STGCN_OK;
 }
 
-int launch_ln_fwd(const char* label, const LnFwdArgs& ln, int64_t slabs, hipStream_t st) {
-    const dim3 grid((unsigned)slabs), blk(kThreads);
+int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st) {
     const int n4 = ln.n / 4;
-    if (n4 <= 16 * kThreads) STGCN_LAUNCH(label, st, (ln_fwd_kernel<16>), grid, blk, 64, ln);
-    else if (n4 <= 32 * kThreads) STGCN_LAUNCH(label, st, (ln_fwd_kernel<32>), grid, blk, 64, ln);
-    else STGCN_LAUNCH(label, st, (ln_fwd_kernel<0>), grid, blk, 64, ln);
+    ln.per = 1024;                                   // float4 columns per workgroup (4 per thread)
+    const dim3 grid(cdiv(n4, ln.per), (unsigned)slabs), blk(kThreads);
+    STGCN_LAUNCH(label, st, ln_norm_kernel, grid, blk, 64, ln);
     return STGCN_OK;
 }
 
@@ -295,6 +294,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->sv_S2 = take(v.rows2 * d->c2);
     p->sv_mean = take(v.slabs2);
     p->sv_rstd = take(v.slabs2);
+    p->sv_rowstat = take(2 * v.rows2);
     p->saved_floats = o;
     o = 0;
     p->ws_W1p = take((int64_t)v.NC1 * v.KP1);
@@ -306,8 +306,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2p = take((int64_t)v.NC2 * v.KP2);
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
-    p->ws_c1 = take(v.slabs2);
-    p->ws_c2 = take(v.slabs2);
+    p->ws_rowstat_b = take(2 * v.rows2);
     p->ws_dZ2 = take(v.rows2 * v.NC2);
     p->ws_dYg = take(v.rows1 * d->c1);
     p->ws_dA = take(v.rows1 * d->c1);
@@ -377,7 +376,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     t2.ts.src = saved + pl.sv_G; t2.ts.C = d->c1; t2.ts.taps = d->Kt; t2.ts.N = d->N; t2.ts.Tsrc = v.T1; t2.ts.Tdst = v.T2; t2.ts.dir = 1;
     t2.ts.rows = v.rows2;
     t2.Wp = ws + pl.ws_W2p; t2.bias = ws + pl.ws_b2; t2.KCH = v.KP2 / 16; t2.Cout = d->c2; t2.act = d->act;
-    t2.U = saved + pl.sv_U2; t2.S = saved + pl.sv_S2;
+    t2.U = saved + pl.sv_U2; t2.S = saved + pl.sv_S2; t2.rowstat = reinterpret_cast<float2*>(saved + pl.sv_rowstat);
     rc = launch_tconv_fwd("tconv_fwd.tc2", t2, st);
     if (rc) return rc;
 
@@ -385,8 +384,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     LnFwdArgs ln;
     memset(&ln, 0, sizeof(ln));
     ln.U = saved + pl.sv_U2; ln.S = saved + pl.sv_S2; ln.gamma = P->ln_w; ln.beta = P->ln_b; ln.y = y;
-    ln.mean = saved + pl.sv_mean; ln.rstd = saved + pl.sv_rstd;
-    ln.n = d->N * d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
+    ln.mean = saved + pl.sv_mean; ln.rstd = saved + pl.sv_rstd; ln.rowstat = reinterpret_cast<const float2*>(saved + pl.sv_rowstat);
+    ln.n = d->N * d->c2; ln.N = d->N; ln.C = d->c2; ln.act = d->act; ln.training = d->training && d->droprate > 0.f;
     ln.eps = d->ln_eps; ln.keep_scale = 1.0f / (1.0f - d->droprate); ln.thresh = drop_thresh(d->droprate);
     ln.seed = seed; ln.offset = offset; ln.offset_dev = offset_dev;
     rc = launch_ln_fwd("ln_fwd", ln, v.slabs2, st);

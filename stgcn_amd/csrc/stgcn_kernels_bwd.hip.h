@@ -83,7 +83,8 @@ inline int64_t bwd_partial_floats(int B, int T, int N, int c_in, int c0, int c1,
 }
 
 // ================================================================================================
-// B1a: per-slab means of g = dy_m * gamma and g * xhat (LayerNorm backward)
+// B1a: per-ROW partial sums of g = dy_m * gamma and g * xhat (LayerNorm backward).
+//      Fully parallel streaming kernel (one float4 per thread; the C/4 lanes of a row reduce by shuffles).
 // ================================================================================================
 struct LnBwdArgs {
     const float* dy;     // [slabs][n]
@@ -92,12 +93,11 @@ struct LnBwdArgs {
     const float* gamma;
     const float* mean;
     const float* rstd;
-    float* c1;           // [slabs]
-    float* c2;
+    float2* rowstat;     // [slabs*N]  (sum g, sum g*xhat) per row
     float* dZ;           // [slabs*N][2*C]
     float* dgam_part;    // [sg][n]
     float* dbet_part;
-    int n, C, act, training, spg;
+    int n, N, C, act, training, spg;
     long slabs;
     float keep_scale;
     uint32_t thresh;
@@ -105,19 +105,21 @@ struct LnBwdArgs {
     const uint64_t* offset_dev;
 };
 
-__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(LnBwdArgs a) {
-    extern __shared__ float stgcn_smem[];
-    const long slab = blockIdx.x;
-    const int n4 = a.n >> 2, tid = threadIdx.x;
-    const size_t base = (size_t)slab * a.n;
-    const float mean = a.mean[slab], rstd = a.rstd[slab];
-    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+__global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
+    const int n4 = a.n >> 2, c4n = a.C >> 2;
+    const long total = a.slabs * (long)n4;
+    const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = e < total;
+    const long slab = valid ? e / n4 : 0;
+    const int q = valid ? (int)(e - slab * n4) : 0;
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll 4
-    for (int q = tid; q < n4; q += kThreads) {
-        f32x4 dy = ld4(a.dy + base + 4 * q);
-        const f32x4 u = ld4(a.U + base + 4 * q), s = ld4(a.S + base + 4 * q), ga = ld4(a.gamma + 4 * q);
+    if (valid) {
+        const size_t base = (size_t)slab * a.n + 4 * (size_t)q;
+        f32x4 dy = ld4(a.dy + base);
+        const f32x4 u = ld4(a.U + base), s = ld4(a.S + base), ga = ld4(a.gamma + 4 * q);
+        const float mean = a.mean[slab], rstd = a.rstd[slab];
         if (a.training) {
+            const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
             const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dy[i] *= k[i];
@@ -130,31 +132,50 @@ __global__ __launch_bounds__(256) void ln_bwd_stats_kernel(LnBwdArgs a) {
             s2 += gg * xh;
         }
     }
-    block_sum2(s1, s2, stgcn_smem);
-    if (tid == 0) {
-        a.c1[slab] = s1 / (float)a.n;
-        a.c2[slab] = s2 / (float)a.n;
+    for (int m = c4n >> 1; m >= 1; m >>= 1) {   // the c4n lanes of one row are contiguous and aligned
+        s1 += __shfl_xor(s1, m);
+        s2 += __shfl_xor(s2, m);
     }
+    if (valid && (q % c4n) == 0) a.rowstat[slab * a.N + q / c4n] = make_float2(s1, s2);
 }
 
 // ================================================================================================
 // B1b: dH = rstd * (g - c1 - xhat * c2), gate backward -> dZ = [dU | dQ]; partial dgamma / dbeta.
+// c1 = mean(g), c2 = mean(g * xhat) of each slab are rebuilt from the row partials by the workgroup.
 // A thread owns one float4 column of the [N*C] slab and walks `spg` consecutive slabs.
-// grid = (ceil(n/4 / 256), sg)
+// grid = (ceil(n/4 / 256), sg); dynamic LDS: 8 + 2*spg floats
 // ================================================================================================
 __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    float* cs = stgcn_smem + 8;
     const int n4 = a.n >> 2;
     const int q = (int)blockIdx.x * kThreads + (int)threadIdx.x;
-    if (q >= n4) return;
+    const bool valid = q < n4;
     const int sg = blockIdx.y;
+    long s0 = (long)sg * a.spg, s1 = s0 + a.spg;
+    if (s1 > a.slabs) s1 = a.slabs;
+    for (long slab = s0; slab < s1; ++slab) {
+        float x = 0.f, y = 0.f;
+        const float2* rs = a.rowstat + slab * a.N;
+        for (int r = threadIdx.x; r < a.N; r += kThreads) {
+            const float2 v = rs[r];
+            x += v.x;
+            y += v.y;
+        }
+        block_sum2(x, y, stgcn_smem);
+        if (threadIdx.x == 0) {
+            cs[2 * (slab - s0)] = x / (float)a.n;
+            cs[2 * (slab - s0) + 1] = y / (float)a.n;
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
     const int c4n = a.C >> 2;
     const int node = q / c4n, c4 = q - node * c4n;
     const f32x4 ga = ld4(a.gamma + 4 * q);
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     f32x4 dg = zero4(), db = zero4();
-    long s0 = (long)sg * a.spg, s1 = s0 + a.spg;
-    if (s1 > a.slabs) s1 = a.slabs;
-    const int N = a.n / a.C;
+    const int N = a.N;
     // one-slab software prefetch: the loads of slab+1 are issued before the stores of slab
     f32x4 dy_n = zero4(), u_n = zero4(), s_n = zero4();
     if (s0 < s1) {
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
             const size_t nb = (size_t)(slab + 1) * a.n + 4 * (size_t)q;
             dy_n = ld4(a.dy + nb); u_n = ld4(a.U + nb); s_n = ld4(a.S + nb);
         }
-        const float mean = a.mean[slab], rstd = a.rstd[slab], c1 = a.c1[slab], c2 = a.c2[slab];
+        const float mean = a.mean[slab], rstd = a.rstd[slab], c1 = cs[2 * (slab - s0)], c2 = cs[2 * (slab - s0) + 1];
         if (a.training) {
             const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll

@@ -203,6 +203,7 @@ struct TconvFwdArgs {
     const float* ba;      // [c1]
     float* A;             // [rows][c1]
     int c1;
+    float2* rowstat;      // [rows] (mean over the row's Cout channels of H, sum of squared deviations) or null
 };
 
 template <int NT, int WM>
@@ -265,6 +266,16 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
             if (a.U) st4(a.U + o, u);
             if (a.S) st4(a.S + o, sg);
             if (a.H) st4(a.H + o, h);
+        }
+        if (a.rowstat) {   // per-row LayerNorm partials: the c4n lanes holding one row are contiguous in the wave
+            float sr = (h[0] + h[1]) + (h[2] + h[3]);
+            for (int m = c4n >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
+            const float mr = sr / (float)Cout;
+            float d2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
+            for (int m = c4n >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
+            if (c4 == 0 && R < a.ts.rows) a.rowstat[R] = make_float2(mr, d2);
         }
         if (do_align) st4(Zt + row * ldz + 4 * c4, h);   // H tile in place of the P half
     }
@@ -434,123 +445,76 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
 }
 
 // ================================================================================================
-// F4: LayerNorm over the joint [N, C] axes of one (b, t) slab (biased variance, eps 1e-12,
+// F4: LayerNorm over the joint [N, C] axes of each (b, t) slab (biased variance, eps 1e-12,
 //     layers.py:246/255) of H = act(U) * S, followed by inverted dropout (layers.py:256).
-//     Exact two-pass statistics; the slab (<= a few hundred KB) is re-read from L2.
+//     Slab statistics come from the per-row partials (mean_r, M2_r) the conv epilogue wrote:
+//         mu = mean_r averaged over rows ;  M2 = sum_r M2_r + C * sum_r (mean_r - mu)^2   (exact pairwise merge)
+//     so the normalisation itself is a fully parallel streaming kernel: grid = (chunks, slabs).
 // ================================================================================================
 struct LnFwdArgs {
     const float* U;      // [slabs][n]   n = N*C
     const float* S;
     const float* gamma;  // [n]
     const float* beta;
+    const float2* rowstat;   // [slabs*N]
     float* y;            // [slabs][n]
     float* mean;         // [slabs]
     float* rstd;
-    int n, act, training;
+    int n, N, C, act, training, per;   // per = float4 columns per chunk
     float eps, keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
     const uint64_t* offset_dev;   // optional device-side step counter added to `offset` (graph replay safe)
 };
 
-// MAXV > 0: the slab's n/4 float4 columns fit in MAXV registers per thread -> one read of U and S with every
-// load in flight at once (the kernel is latency-bound otherwise: one workgroup streams the whole slab).
-// MAXV == 0: generic three-pass variant for large slabs (re-reads come from L2).
-template <int MAXV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
-    extern __shared__ float stgcn_smem[];
-    const long slab = blockIdx.x;
-    const int n4 = a.n >> 2, tid = threadIdx.x;
-    const float* U = a.U + (size_t)slab * a.n;
-    const float* S = a.S + (size_t)slab * a.n;
-    float* y = a.y + (size_t)slab * a.n;
-    float s1 = 0.f, s2 = 0.f, dummy = 0.f;
-    constexpr int NV = MAXV > 0 ? MAXV : 1;
-    f32x4 h[NV];
-    if (MAXV > 0) {
-        f32x4 u[NV], s[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int q = tid + v * kThreads;
-            u[v] = q < n4 ? ld4(U + 4 * q) : zero4();
-            s[v] = q < n4 ? ld4(S + 4 * q) : zero4();
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h[v][i] = gate_fwd(u[v][i], s[v][i], a.act);   // 0 for the padding columns (u = s = 0)
-                s1 += h[v][i];
-            }
-        }
-    } else {
-        for (int q = tid; q < n4; q += kThreads) {
-            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s1 += gate_fwd(u[i], s[i], a.act);
-        }
-    }
-    block_sum2(s1, dummy, stgcn_smem);
-    const float mean = s1 / (float)a.n;
+// mean / rstd of one slab from its row partials; all 256 threads must call; red: >= 8 floats of LDS
+__device__ __forceinline__ void slab_stats_from_rows(const float2* rs, int N, int C, float eps, float* red, float& mean, float& rstd) {
+    float sm = 0.f, dummy = 0.f;
+    for (int r = threadIdx.x; r < N; r += kThreads) sm += rs[r].x;
+    block_sum2(sm, dummy, red);
+    mean = sm / (float)N;
+    float m2 = 0.f;
     dummy = 0.f;
-    if (MAXV > 0) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (tid + v * kThreads < n4) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float d = h[v][i] - mean;
-                    s2 += d * d;
-                }
-            }
-        }
-    } else {
-        for (int q = tid; q < n4; q += kThreads) {
-            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float d = gate_fwd(u[i], s[i], a.act) - mean;
-                s2 += d * d;
-            }
-        }
+    for (int r = threadIdx.x; r < N; r += kThreads) {
+        const float2 v = rs[r];
+        m2 += v.y + (float)C * (v.x - mean) * (v.x - mean);
     }
-    block_sum2(s2, dummy, stgcn_smem);
-    const float rstd = 1.0f / sqrtf(s2 / (float)a.n + a.eps);
-    if (tid == 0) {
+    block_sum2(m2, dummy, red);
+    rstd = 1.0f / sqrtf(m2 / ((float)N * (float)C) + eps);
+}
+
+__global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const long slab = blockIdx.y;
+    const int chunk = blockIdx.x, tid = threadIdx.x, n4 = a.n >> 2;
+    float mean, rstd;
+    slab_stats_from_rows(a.rowstat + (size_t)slab * a.N, a.N, a.C, a.eps, stgcn_smem, mean, rstd);
+    if (chunk == 0 && tid == 0) {
         a.mean[slab] = mean;
         a.rstd[slab] = rstd;
     }
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-    auto emit = [&](int q, const f32x4& hv) {
-        const f32x4 ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
+    const float* U = a.U + (size_t)slab * a.n;
+    const float* S = a.S + (size_t)slab * a.n;
+    float* y = a.y + (size_t)slab * a.n;
+    int q1 = (chunk + 1) * a.per;
+    if (q1 > n4) q1 = n4;
+#pragma unroll 2
+    for (int q = chunk * a.per + tid; q < q1; q += kThreads) {
+        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q), ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
         f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (hv[i] - mean) * rstd * ga[i] + be[i];
+        for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], s[i], a.act) - mean) * rstd * ga[i] + be[i];
         if (a.training) {
             const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] *= k[i];
         }
         st4(y + 4 * q, o);
-    };
-    if (MAXV > 0) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int q = tid + v * kThreads;
-            if (q < n4) emit(q, h[v]);
-        }
-    } else {
-        for (int q = tid; q < n4; q += kThreads) {
-            const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q);
-            f32x4 hv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = gate_fwd(u[i], s[i], a.act);
-            emit(q, hv);
-        }
     }
 }
 
-// keep-scale mask exactly as ln_fwd_kernel draws it (test / debugging aid; also used by the oracle
+// keep-scale mask exactly as ln_norm_kernel draws it (test / debugging aid; also used by the oracle
 // comparison in training mode): out[e] in {0, 1/(1-p)}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* out, long n4, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                                            uint32_t thresh, float keep_scale) {

@@ -179,4 +179,53 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
     }
 }
 
+// ================================================================================================
+// Multi-tensor AdamW (torch.optim.AdamW as configured at main.py:148: amsgrad False, maximize False):
+//     p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// One launch updates every live parameter tensor (those with a gradient); the pointer table travels in the
+// kernel arguments.  t and lr may come from device memory so that a captured hipGraph stays correct.
+// ================================================================================================
+struct AdamwTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+};
+constexpr int kAdamwMaxTensors = 48;
+constexpr int kAdamwChunk = 2048;
+struct AdamwArgs {
+    AdamwTensor t[kAdamwMaxTensors];
+    int start[kAdamwMaxTensors + 1];
+    int count;
+    float lr, b1, b2, eps, wd;
+    long step;
+    const long* step_dev;
+    const float* lr_dev;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
+    int jb = 0;
+    while (jb + 1 < a.count && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
+    const AdamwTensor& T = a.t[jb];
+    const long base = ((long)blockIdx.x - a.start[jb]) * kAdamwChunk;
+    const double t = (double)(a.step_dev ? *a.step_dev : a.step);
+    const float lr = a.lr_dev ? *a.lr_dev : a.lr;
+    const float bc1 = (float)(1.0 - pow((double)a.b1, t));
+    const float rs2 = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, t)));
+    const float decay = 1.0f - lr * a.wd, step_size = lr / bc1;
+#pragma unroll
+    for (int k = 0; k < kAdamwChunk / kThreads; ++k) {
+        const long e = base + k * kThreads + threadIdx.x;
+        if (e < T.n) {
+            const float g = T.g[e];
+            const float m = a.b1 * T.m[e] + (1.0f - a.b1) * g;
+            const float v = a.b2 * T.v[e] + (1.0f - a.b2) * g * g;
+            T.m[e] = m;
+            T.v[e] = v;
+            T.p[e] = T.p[e] * decay - step_size * (m / (sqrtf(v) * rs2 + a.eps));
+        }
+    }
+}
+
 }  // namespace stgcn

@@ -1,0 +1,72 @@
+"""AdamW whose whole step is ONE HIP kernel (``stgcn_adamw_step``) instead of the per-tensor loops /
+multi-tensor launches of ``torch.optim.AdamW`` (reference: main.py:147-148, step at main.py:169).
+
+Semantics follow torch.optim.AdamW with amsgrad=False, maximize=False: decoupled weight decay, bias-corrected
+moments, and -- like the reference's optimizer -- parameters whose ``.grad`` is None are skipped entirely (no
+decay, no state).  It subclasses ``torch.optim.Optimizer`` so LR schedulers (StepLR at main.py:156) work.
+
+``capturable=True`` keeps the step count and the learning rate in device memory so that ``step()`` can be
+recorded into a hipGraph; call ``sync_lr()`` after a scheduler changed ``param_groups[i]['lr']``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0.0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = capturable
+        self._dev = {}     # per group: (step tensor, lr tensor) on the device (capturable mode)
+
+    def sync_lr(self):
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._dev:
+                self._dev[gi][1].fill_(float(group["lr"]))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for gi, group in enumerate(self.param_groups):
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            dev = live[0].device
+            for p in live:
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("stgcn_amd.optim.AdamW handles contiguous float32 parameters only")
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            step_dev = lr_dev = None
+            if self.capturable and dev.type == "cuda":
+                if gi not in self._dev:
+                    self._dev[gi] = (torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), float(group["lr"]), device=dev))
+                step_t, lr_t = self._dev[gi]
+                step_t.add_(1)
+                step_dev, lr_dev = step_t.data_ptr(), lr_t.data_ptr()
+                step = 0
+            else:
+                group["_step"] = group.get("_step", 0) + 1
+                step = group["_step"]
+            table = (_lib.AdamwTensor * len(live))()
+            for i, p in enumerate(live):
+                st = self.state[p]
+                table[i].param, table[i].grad = p.data_ptr(), p.grad.data_ptr()
+                table[i].exp_avg, table[i].exp_avg_sq, table[i].numel = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+            b1, b2 = group["betas"]
+            L.check(L.dll.stgcn_adamw_step(table, len(live), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           float(group["weight_decay"]), step, step_dev, lr_dev, stream), "stgcn_adamw_step")
+        return loss

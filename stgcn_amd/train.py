@@ -66,11 +66,9 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-3, weight_decay: float
     """main.py:147-154 (adamw is the default; nadamw is NAdam with decoupled decay).
     ``capturable``: keep the step counters on the device so that ``step()`` can live inside a hipGraph."""
     params = list(model.parameters())
-    on_gpu = len(params) > 0 and params[0].is_cuda
     if name == "adamw":
-        if on_gpu:
-            return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True, capturable=capturable)
-        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+        from .optim import AdamW        # one HIP kernel per step (stgcn_adamw_step)
+        return AdamW(params, lr=lr, weight_decay=weight_decay, capturable=capturable)
     if name == "nadamw":
         return torch.optim.NAdam(params, lr=lr, weight_decay=weight_decay, decoupled_weight_decay=True)
     raise ValueError(f"ERROR: The {name} optimizer is undefined.")   # main.py:154
