@@ -85,6 +85,7 @@ int check_desc(const stgcn_stblock_desc* d) {
         return fail(STGCN_ERR_UNSUPPORTED, "temporal-conv output channels must be 64 or 128 (got c0=%d c2=%d)", d->c0, d->c2);
     if (d->c1 != 16) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv channels c1 must be 16 (got %d)", d->c1);
     if (d->N > 512) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 512: slab-resident graph conv needs the tiled variant", d->N);
+    if ((int64_t)d->B * d->T * d->N >= (1ll << 31) / 256) return fail(STGCN_ERR_UNSUPPORTED, "B*T*N too large for 32-bit row indexing");
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
     if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
         return fail(STGCN_ERR_UNSUPPORTED, "c_in=%d: input channels must be a multiple of 4 unless Kt*c_in <= 16", d->c_in);
@@ -163,17 +164,20 @@ int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st
 }
 
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
-    // 64-row tiles when that still fills the chip, else 32-row tiles (the output head has only B*N rows)
-    const bool small = cdiv(a.ts.rows, kTileRows) < 256;
+    // 32-row tiles / 4 waves measured fastest on MI355X for every shape of the model (more, lighter workgroups per CU);
+    // 64-row tiles / 8 waves are kept selectable (STGCN_TCONV_TR=64) for larger problems.
+    static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;   // tuning knob
+    const bool small = force_tr ? force_tr == 32 : true;
     const int tr = small ? 32 : kTileRows;
-    const dim3 grid(cdiv(a.ts.rows, tr)), blk(kThreads);
+    const dim3 grid(cdiv(a.ts.rows, tr));
     const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
+    // 64-row tiles run with 8 waves (2 per SIMD and workgroup), 32-row tiles with 4
     if (a.Cout == 64) {
-        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 2>), grid, blk, lds, a);
-        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 4>), grid, blk, lds, a);
+        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 2, 4>), grid, dim3(256), lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 4, 8>), grid, dim3(512), lds, a);
     } else {
-        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 2>), grid, blk, lds, a);
-        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 4>), grid, blk, lds, a);
+        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 2, 4>), grid, dim3(256), lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 4, 8>), grid, dim3(512), lds, a);
     }
     return STGCN_OK;
 }
@@ -196,8 +200,8 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
     const size_t lds = kTileLdsFloats * sizeof(float);
     if (ntt == 1) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, a);
     else if (ntt == 2) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, a);
-    else if (ntt == 4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<4, 1, 0>), grid, blk, lds, a);
-    else if (ntt == 8) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<4, 2, 0>), grid, blk, lds, a);
+    else if (ntt == 4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 0, 8>), grid, dim3(512), lds, a);
+    else if (ntt == 8) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 2, 0, 8>), grid, dim3(512), lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "backward-data with %d input channel tiles (supported: 1, 2, 4, 8)", ntt);
     return STGCN_OK;
 }
@@ -217,7 +221,7 @@ int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
 template <int MTW>
 int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     const dim3 grid(w.chunks, w.mchunks), blk(kThreads);
-    size_t lds = (size_t)16 * ((MTW * 16 + 4) + (a.NC + 4)) * sizeof(float);
+    size_t lds = (size_t)kWgradStepRows * ((MTW * 16 + 4) + (a.NC + 4)) * sizeof(float);
     if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
     if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2>), grid, blk, lds, a);
     else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4>), grid, blk, lds, a);

@@ -41,7 +41,7 @@ inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
     long target = 256 / g.mchunks;
     if (target < 1) target = 1;
     long rpc = (rows + target - 1) / target;
-    rpc = (rpc + 15) / 16 * 16;
+    rpc = (rpc + 63) / 64 * 64;   // whole 64-row reduction steps
     if (rpc < 64) rpc = 64;
     g.rows_per_chunk = (int)rpc;
     g.chunks = (int)((rows + rpc - 1) / rpc);
@@ -232,22 +232,27 @@ struct TconvBwdDataArgs {
     float* dX;            // [rows][Cin]
 };
 
-template <int WM, int NT, int LAYOUT>
-__global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a) {
+// WAVES = 8 (LAYOUT 0 only): the second half of the workgroup owns m-tiles 2..3 of every n-tile column, i.e. WM = 2.
+template <int WM, int NT, int LAYOUT, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void tconv_bwd_data_kernel(TconvBwdDataArgs a) {
+    constexpr int THREADS = WAVES * 64;
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);
     int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const int wv = threadIdx.x >> 6, wave = wv & 3, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
     const long row0 = (long)blockIdx.x * kTileRows;
-    const int mt0 = LAYOUT == 0 ? 0 : (LAYOUT == 1 ? wave : 2 * (wave >> 1));
+    const int mt0 = LAYOUT == 0 ? (wv >> 2) * WM : (LAYOUT == 1 ? wave : 2 * (wave >> 1));
     const int nt0 = LAYOUT == 0 ? wave : (LAYOUT == 1 ? 0 : (wave & 1));
 
+    STGCN_PHASE(2, 0);
+    stagger_start();
     tile_rowinfo(a.ts, row0, rowbase, rowt);
     __syncthreads();
+    STGCN_PHASE(2, 1);
     // taps whose source time step t - tap is out of range for EVERY row of this tile contribute exact zeros:
     // skip their K segments (the head has T1 = 1: 3 of its 4 taps are empty for any given output step)
-    if (wave == 0) {
+    if (wv == 0) {
         unsigned m = 0;
         const int t = rowt[lane];   // 64 rows == 64 lanes
         for (int tap = 0; tap < a.ts.taps && tap < 32; ++tap) {
@@ -269,6 +274,39 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
     __syncthreads();
     const unsigned tapmask = (unsigned)rowbase[128];
     const int KP = a.KCH * 16;
+#if STGCN_PIPE_BWD
+    {
+        auto next_seg = [&](int from) {   // next segment with an in-range tap for some row of the tile; KP if none
+            for (int k0 = from; k0 < KP; k0 += kSegMax) {
+                const int ks = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+                for (int tap = k0 / a.ts.C; tap <= (k0 + ks - 1) / a.ts.C; ++tap)
+                    if (tap >= 32 || ((tapmask >> tap) & 1u)) return k0;
+            }
+            return KP;
+        };
+        TileRegs<kTileRows, THREADS> regs;
+        int k0 = next_seg(0);
+        if (k0 < KP) {
+            const int ks0 = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+            tile_prefetch_segment<kTileRows, THREADS>(a.ts, rowbase, rowt, k0, ks0, regs);
+            tile_commit_segment<kTileRows, THREADS>(ks0, regs, At, ks0 + 4);
+        }
+        while (k0 < KP) {   // uniform over the workgroup
+            const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+            const int kn = next_seg(k0 + kSegMax), ksegn = (KP - kn) < kSegMax ? (KP - kn) : kSegMax;
+            SegWeights<NT> w;
+            seg_load_weights<NT>(w, kseg >> 4, a.Wp, k0 >> 4, a.KCH, nt0, 4);
+            if (kn < KP) tile_prefetch_segment<kTileRows, THREADS>(a.ts, rowbase, rowt, kn, ksegn, regs);
+            __syncthreads();
+            seg_mma_w<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, w);
+            if (kn < KP) {
+                __syncthreads();
+                tile_commit_segment<kTileRows, THREADS>(ksegn, regs, At, ksegn + 4);
+            }
+            k0 = kn;
+        }
+    }
+#else
     bool first = true;
     for (int k0 = 0; k0 < KP; k0 += kSegMax) {
         const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
@@ -278,12 +316,16 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
         if (!any) continue;   // uniform over the workgroup
         if (!first) __syncthreads();
         first = false;
-        tile_load_segment(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        tile_load_segment<kTileRows, THREADS>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
         __syncthreads();
+        STGCN_PHASE(2, 2 + 2 * ((k0 / kSegMax) % 6));
         const int half = (kseg >> 4) >> 1, rest = (kseg >> 4) - half;
         seg_mma<WM, NT>(acc, At, kseg + 4, mt0, rest, a.Wp, k0 >> 4, a.KCH, nt0, 4);
         if (half > 0) seg_mma<WM, NT>(acc2, At + rest * 16, kseg + 4, mt0, half, a.Wp, (k0 >> 4) + rest, a.KCH, nt0, 4);
+        STGCN_PHASE(2, 3 + 2 * ((k0 / kSegMax) % 6));
     }
+#endif
+    STGCN_PHASE(2, 14);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -300,6 +342,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_data_kernel(TconvBwdDataArgs a)
                 }
             }
         }
+    STGCN_PHASE(2, 15);
 }
 
 // ================================================================================================
@@ -484,9 +527,12 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
     for (int j = 0; j < NTA; ++j) wacc[j] = zero4();
     float bsum = 0.f;                            // thread (rg = tid >> 4, jj = tid & 15): column jj, rows rg, rg+16, ..
     const int c4n = c0 >> 2;
+    STGCN_PHASE(6, 0);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * kTileRows;
+        const bool ph = t == blockIdx.x;
         __syncthreads();   // previous tile fully consumed
+        if (ph) STGCN_PHASE(6, 1);
         for (int idx = tid; idx < kTileRows * (c1 >> 2); idx += kThreads) {
             const int r = idx / (c1 >> 2), q = idx - r * (c1 >> 2);
             st4(dAt + r * LDA + 4 * q, row0 + r < a.rows ? ld4(a.dA + (size_t)(row0 + r) * c1 + 4 * q) : zero4());
@@ -512,6 +558,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
                 for (int r = 0; r < 4; ++r) Ht[(i * 16 + 4 * g + r) * LDH + col] = acc[i][j][r];
         }
         __syncthreads();
+        if (ph) STGCN_PHASE(6, 2);
         // row-major pass with 16-byte global accesses: gate backward -> dZ, H back into the tile
         for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
             const int row = idx / c4n, c4 = idx - row * c4n;
@@ -535,6 +582,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
             st4(Ht + row * LDH + 4 * c4, h);
         }
         __syncthreads();
+        if (ph) STGCN_PHASE(6, 3);
         // dWa[i][j] += sum_rows H[row][i] dA[row][j] : A[row_op = i (l15)][kk = row 4g+s], B[kk = row][col = j (l15)]
 #pragma unroll
         for (int j = 0; j < NTA; ++j) {
@@ -548,6 +596,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
             }
         }
     }
+    STGCN_PHASE(6, 4);
     float* part = a.part + (size_t)blockIdx.x * (c0 * c1 + c1);
 #pragma unroll
     for (int j = 0; j < NTA; ++j)
@@ -570,6 +619,10 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
 // step's global loads in flight (register prefetch).  Output: per-chunk partials.
 // wave w owns n-tiles w*NTW .. w*NTW+NTW-1 (NTW = NC/64) of all MTW m-tiles of this m-chunk.
 // ================================================================================================
+#ifndef STGCN_WGRAD_SR
+#define STGCN_WGRAD_SR 64
+#endif
+constexpr int kWgradStepRows = STGCN_WGRAD_SR;   // rows reduced per barrier interval (build-time tunable)
 struct TconvBwdWeightArgs {
     TapSrc ts;           // x viewed through Kt taps (dir = +1): implicit [rows][K = Kt*Cin]
     const float* dZ;     // [rows][NC]
@@ -581,49 +634,64 @@ template <int MTW, int NTW>
 __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    constexpr int SR = kWgradStepRows;   // rows reduced per barrier interval
     constexpr int MC = MTW * 16, LDC = MC + 4;
     const int NC = a.NC, LDZ = NC + 4;
-    float* ct = stgcn_smem;              // [16][LDC]
-    float* zt = stgcn_smem + 16 * LDC;   // [16][LDZ]
+    float* ct = stgcn_smem;              // [SR][LDC]
+    float* zt = stgcn_smem + SR * LDC;   // [SR][LDZ]
     const int chunk = blockIdx.x, mchunk = blockIdx.y, m0 = mchunk * MC;
     const long crow0 = (long)chunk * a.rows_per_chunk;
     long crow1 = crow0 + a.rows_per_chunk;
     if (crow1 > a.ts.rows) crow1 = a.ts.rows;
-    const int nsteps = (int)((crow1 - crow0 + 15) / 16);
+    const int nsteps = (int)((crow1 - crow0 + SR - 1) / SR);
     const int K = a.ts.taps * a.ts.C;
     const bool vec = (a.ts.C & 3) == 0;
     const long per_b = (long)a.ts.Tdst * a.ts.N;
 
-    // staging registers: one float4 (or scalar) of the im2col tile, NZ float4 of the dZ tile per thread
-    constexpr int NZ = NTW;              // 16 * NC / 4 / 256 = NC / 64
-    f32x4 creg = zero4(), zreg[NZ];
+    // staging registers (next step's tiles are fetched while the current step's MFMAs run)
+    constexpr int NCR = (SR * (MC / 4) + kThreads - 1) / kThreads;   // float4 of the im2col tile per thread (vector path)
+    constexpr int NCS = (SR * MC + kThreads - 1) / kThreads;         // scalars per thread (narrow-input path, MC == 16)
+    constexpr int NCV = NCR > NCS ? NCR : NCS;
+    constexpr int NZ = SR * NTW * 16 / kThreads;                      // SR * NC / 4 / 256 with NC = 64 * NTW
+    f32x4 creg[NCV], zreg[NZ];
     auto load_regs = [&](int step) {
-        const long r0 = crow0 + (long)step * 16;
-        // im2col element of this thread
-        creg = zero4();
+        const long r0 = crow0 + (long)step * SR;
         if (vec) {
-            const int r = tid / (MC / 4), q = tid - r * (MC / 4);
-            if (r < 16) {
-                const long R = r0 + r;
-                const int kidx = m0 + 4 * q;
-                if (R < crow1 && kidx < K) {
-                    const int b = (int)(R / per_b);
-                    const long rem = R - (long)b * per_b;
-                    const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
-                    creg = ld4(a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+#pragma unroll
+            for (int i = 0; i < NCR; ++i) {
+                const int idx = tid + i * kThreads;
+                const int r = idx / (MC / 4), q = idx - r * (MC / 4);
+                f32x4 v = zero4();
+                if (r < SR) {
+                    const long R = r0 + r;
+                    const int kidx = m0 + 4 * q;
+                    if (R < crow1 && kidx < K) {
+                        const int b = (int)(R / per_b);
+                        const long rem = R - (long)b * per_b;
+                        const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                        v = ld4(a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+                    }
                 }
+                creg[i] = v;
             }
         } else {
-            const int r = tid / MC, q = tid - r * MC;
-            if (r < 16) {
-                const long R = r0 + r;
-                const int kidx = m0 + q;
-                if (R < crow1 && kidx < K) {
-                    const int b = (int)(R / per_b);
-                    const long rem = R - (long)b * per_b;
-                    const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
-                    creg[0] = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+#pragma unroll
+            for (int i = 0; i < NCS; ++i) {
+                const int idx = tid + i * kThreads;
+                const int r = idx / MC, q = idx - r * MC;
+                float v = 0.f;
+                if (r < SR) {
+                    const long R = r0 + r;
+                    const int kidx = m0 + q;
+                    if (R < crow1 && kidx < K) {
+                        const int b = (int)(R / per_b);
+                        const long rem = R - (long)b * per_b;
+                        const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                        v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+                    }
                 }
+                creg[i] = zero4();
+                creg[i][0] = v;
             }
         }
 #pragma unroll
@@ -636,11 +704,19 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
     };
     auto store_regs = [&]() {
         if (vec) {
-            const int r = tid / (MC / 4), q = tid - r * (MC / 4);
-            if (r < 16) st4(ct + r * LDC + 4 * q, creg);
+#pragma unroll
+            for (int i = 0; i < NCR; ++i) {
+                const int idx = tid + i * kThreads;
+                const int r = idx / (MC / 4), q = idx - r * (MC / 4);
+                if (r < SR) st4(ct + r * LDC + 4 * q, creg[i]);
+            }
         } else {
-            const int r = tid / MC, q = tid - r * MC;
-            if (r < 16) ct[r * LDC + q] = creg[0];
+#pragma unroll
+            for (int i = 0; i < NCS; ++i) {
+                const int idx = tid + i * kThreads;
+                const int r = idx / MC, q = idx - r * MC;
+                if (r < SR) ct[r * LDC + q] = creg[i][0];
+            }
         }
 #pragma unroll
         for (int z = 0; z < NZ; ++z) {
@@ -656,10 +732,12 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4();
     // bias partial: NC columns, tpc = 256 / NC threads per column (NC = 128 -> 2, NC = 256 -> 1)
-    const int tpc = kThreads / NC, bcol = tid % NC, bpart = tid / NC, rpt = 16 / tpc;
+    const int tpc = kThreads / NC, bcol = tid % NC, bpart = tid / NC, rpt = SR / tpc;
     float bsum = 0.f;
 
+    STGCN_PHASE(3, 0);
     if (nsteps > 0) load_regs(0);
+    STGCN_PHASE(3, 1);
     for (int step = 0; step < nsteps; ++step) {
         if (step > 0) __syncthreads();   // previous step's tiles consumed
         store_regs();
@@ -668,19 +746,26 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
         if (mchunk == 0) {
             for (int r = 0; r < rpt; ++r) bsum += zt[(bpart * rpt + r) * LDZ + bcol];
         }
+        // A[m = l15][kk = g] = ct[row][m], B[kk = g][o = l15] = zt[row][o] with row = 16*k16 + 4g + s: lanes with
+        // g = 0..3 read rows 4 apart, which the LDC/LDZ = 4 (mod 8) padding spreads over distinct banks
+#pragma unroll 1
+        for (int k16 = 0; k16 < SR / 16; ++k16) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float av[MTW], bv[NTW];
+            for (int sx = 0; sx < 4; ++sx) {
+                const int row = k16 * 16 + 4 * g + sx;
+                float av[MTW], bv[NTW];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) av[i] = ct[(4 * g + s) * LDC + i * 16 + l15];
+                for (int i = 0; i < MTW; ++i) av[i] = ct[row * LDC + i * 16 + l15];
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) bv[j] = zt[(4 * g + s) * LDZ + (wave * NTW + j) * 16 + l15];
+                for (int j = 0; j < NTW; ++j) bv[j] = zt[row * LDZ + (wave * NTW + j) * 16 + l15];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i)
+                for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+            }
         }
     }
+    STGCN_PHASE(3, 2);
     float* part = a.part + (size_t)chunk * a.Mpad * NC;
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -702,6 +787,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
             }
         }
     }
+    STGCN_PHASE(3, 3);
 }
 
 // ================================================================================================

@@ -111,12 +111,12 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
     if (r < TR) {
         const long R = tile_row0 + r;
         int base = 0, t = -(1 << 20);
-        if (R < ts.rows) {
-            const long per_b = (long)ts.Tdst * ts.N;
-            const int b = (int)(R / per_b);
-            const int rem = (int)(R - (long)b * per_b);
-            t = rem / ts.N;
-            base = b * ts.Tsrc * ts.N + rem;   // = (b*Tsrc + t)*N + n
+        if (R < ts.rows) {   // rows < 2^31 (checked on the host): 32-bit divisions only
+            const unsigned per_b = (unsigned)(ts.Tdst * ts.N), Ru = (unsigned)R;
+            const unsigned b = Ru / per_b;
+            const unsigned rem = Ru - b * per_b;
+            t = (int)(rem / (unsigned)ts.N);
+            base = (int)(b * (unsigned)(ts.Tsrc * ts.N) + rem);   // = (b*Tsrc + t)*N + n
         }
         rowbase[r] = base;
         rowt[r] = t;
@@ -124,14 +124,15 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
 }
 
 // Stage columns [k0, k0 + kseg) of the implicit matrix for the TR rows of the tile into At[TR][lda].
-template <int TR = kTileRows>
+template <int TR = kTileRows, int THREADS = kThreads>
 __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                   float* At, int lda) {
     const int K = ts.taps * ts.C;
     if ((ts.C & 3) == 0) {
         const int q4 = kseg >> 2;
-        for (int idx = threadIdx.x; idx < TR * q4; idx += kThreads) {
-            const int r = idx / q4, q = idx - r * q4;
+        const bool full = kseg == kSegMax;   // q4 == 32: shifts instead of integer divisions
+        for (int idx = threadIdx.x; idx < TR * q4; idx += THREADS) {
+            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
             const int kidx = k0 + 4 * q;
             f32x4 v = zero4();
             if (kidx < K) {
@@ -142,7 +143,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             st4(At + r * lda + 4 * q, v);
         }
     } else {   // narrow inputs (C = 1 for the first block): scalar gather
-        for (int idx = threadIdx.x; idx < TR * kseg; idx += kThreads) {
+        for (int idx = threadIdx.x; idx < TR * kseg; idx += THREADS) {
             const int r = idx / kseg, q = idx - r * kseg;
             const int kidx = k0 + q;
             float v = 0.f;
@@ -152,6 +153,104 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
                 if (tt >= 0 && tt < ts.Tsrc) v = ts.src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
             }
             At[r * lda + q] = v;
+        }
+    }
+}
+
+// Workgroups that share a CU start together and would run their load / MFMA / epilogue phases in lockstep (the MFMA
+// pipe then idles during every load phase).  Block b, b+256, b+512, .. land on the same CU; delaying them by a
+// different fraction of a phase interleaves the phases.  (experiment knob: -DSTGCN_STAGGER=<units of 2048 cycles>)
+#ifndef STGCN_STAGGER
+#define STGCN_STAGGER 0
+#endif
+// STGCN_PIPE_FWD / STGCN_PIPE_BWD: software-pipelined K-segment loop (weights -> registers, next tile segment in flight
+// during the MFMAs).  Measured on MI355X (profiles/): helps the transposed conv (3+ segments), hurts the forward conv.
+#ifndef STGCN_PIPE_FWD
+#define STGCN_PIPE_FWD 0
+#endif
+#ifndef STGCN_PIPE_BWD
+#define STGCN_PIPE_BWD 1
+#endif
+__device__ __forceinline__ void stagger_start() {
+#if STGCN_STAGGER > 0
+    const int k = ((int)(blockIdx.x >> 8) & 3) * STGCN_STAGGER;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+}
+
+// Split staging: global -> registers (in flight during the MFMA loop) and registers -> LDS.
+template <int TR, int THREADS>
+struct TileRegs {
+    f32x4 v[(TR * (kSegMax / 4) + THREADS - 1) / THREADS];
+};
+template <int TR, int THREADS>
+__device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
+                                                      TileRegs<TR, THREADS>& regs) {
+    constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
+    const int K = ts.taps * ts.C, q4 = kseg >> 2;
+    const bool full = kseg == kSegMax;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * THREADS;
+        f32x4 v = zero4();
+        if (idx < TR * q4) {
+            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
+            const int kidx = k0 + 4 * q;
+            if (kidx < K) {
+                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tt = rowt[r] + ts.dir * tap;
+                if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+            }
+        }
+        regs.v[i] = v;
+    }
+}
+template <int TR, int THREADS>
+__device__ __forceinline__ void tile_commit_segment(int kseg, const TileRegs<TR, THREADS>& regs, float* At, int lda) {
+    constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
+    const int q4 = kseg >> 2;
+    const bool full = kseg == kSegMax;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + i * THREADS;
+        if (idx < TR * q4) {
+            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
+            st4(At + r * lda + 4 * q, regs.v[i]);
+        }
+    }
+}
+
+// Weight fragments of a whole segment (<= 8 chunks) held in registers: loaded BEFORE the next segment's tile prefetch is
+// issued, so that waiting for them (in-order vmcnt) does not drain the prefetch.
+template <int NT>
+struct SegWeights {
+    f32x4 b[kSegMax / 16][NT];
+};
+template <int NT>
+__device__ __forceinline__ void seg_load_weights(SegWeights<NT>& w, int kcs, const float* Wp, int kc0, int KCH, int nt0, int nts) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kc = 0; kc < kSegMax / 16; ++kc)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            w.b[kc][j] = kc < kcs ? ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
+}
+template <int WM, int NT>
+__device__ __forceinline__ void seg_mma_w(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int kcs, const SegWeights<NT>& w) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = At + (mt0 * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
+#pragma unroll
+    for (int kc = 0; kc < kSegMax / 16; ++kc) {
+        if (kc < kcs) {
+            f32x4 a[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], w.b[kc][j][s], acc[i][j]);
         }
     }
 }
@@ -206,18 +305,23 @@ struct TconvFwdArgs {
     float2* rowstat;      // [rows] (mean over the row's Cout channels of H, sum of squared deviations) or null
 };
 
-template <int NT, int WM>
-__global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
-    constexpr int TR = WM * 16;   // rows per tile
+// TM = m-tiles (16 rows) per tile; WAVES = 4 or 8.  With 8 waves the two halves of the workgroup (wave >> 2) own
+// the two halves of the tile's rows: twice the waves in flight per CU at the same LDS footprint.
+template <int NT, int TM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
+    constexpr int TR = TM * 16, THREADS = WAVES * 64, WM = TM / (WAVES / 4);   // rows per tile, m-tiles per wave
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);
     int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const int wv = threadIdx.x >> 6, wave = wv & 3, mt0 = (wv >> 2) * WM, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
     const long row0 = (long)blockIdx.x * TR;
 
+    STGCN_PHASE(1, 0);
+    stagger_start();
     tile_rowinfo<TR>(a.ts, row0, rowbase, rowt);
     __syncthreads();
+    STGCN_PHASE(1, 1);
 
     f32x4 acc[WM][NT];
 #pragma unroll
@@ -226,12 +330,37 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
 
     const int KP = a.KCH * 16;
+#if STGCN_PIPE_FWD
+    if ((a.ts.C & 3) == 0) {
+        // software pipeline over the K segments (single LDS buffer): weight fragments of segment s -> registers, then the
+        // tile loads of segment s+1 are issued and stay in flight while the MFMAs of segment s run.
+        TileRegs<TR, THREADS> regs;
+        int kseg = KP < kSegMax ? KP : kSegMax;
+        tile_prefetch_segment<TR, THREADS>(a.ts, rowbase, rowt, 0, kseg, regs);
+        tile_commit_segment<TR, THREADS>(kseg, regs, At, kseg + 4);
+        for (int k0 = 0; k0 < KP; k0 += kSegMax) {
+            kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
+            const int kn = k0 + kSegMax, ksegn = (KP - kn) < kSegMax ? (KP - kn) : kSegMax;
+            SegWeights<NT> w;
+            seg_load_weights<NT>(w, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+            if (kn < KP) tile_prefetch_segment<TR, THREADS>(a.ts, rowbase, rowt, kn, ksegn, regs);
+            __syncthreads();                       // At (segment k0) committed by every thread
+            seg_mma_w<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, w);
+            if (kn < KP) {
+                __syncthreads();                   // every wave done reading At
+                tile_commit_segment<TR, THREADS>(ksegn, regs, At, ksegn + 4);
+            }
+        }
+    } else
+#endif
     for (int k0 = 0; k0 < KP; k0 += kSegMax) {
         const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
         if (k0 > 0) __syncthreads();   // previous segment fully consumed
-        tile_load_segment<TR>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        tile_load_segment<TR, THREADS>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
         __syncthreads();
-        seg_mma<WM, NT>(acc, At, kseg + 4, 0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+        STGCN_PHASE(1, 2 + 2 * (k0 / kSegMax));
+        seg_mma<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+        STGCN_PHASE(1, 3 + 2 * (k0 / kSegMax));
     }
 
     // ---- epilogue: accumulators -> LDS tile Zt[64][NC + 4] -> row-major float4 pass (coalesced U/S/H stores) ----
@@ -245,11 +374,11 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) Zt[((mt0 + i) * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
     }
     __syncthreads();
     const int c4n = Cout >> 2;
-    for (int idx = threadIdx.x; idx < TR * c4n; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < TR * c4n; idx += THREADS) {
         const int row = idx / c4n, c4 = idx - row * c4n;
         const long R = row0 + row;
         const f32x4 p = ld4(Zt + row * ldz + 4 * c4), q = ld4(Zt + row * ldz + Cout + 4 * c4);
@@ -279,18 +408,19 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
         }
         if (do_align) st4(Zt + row * ldz + 4 * c4, h);   // H tile in place of the P half
     }
+    STGCN_PHASE(1, 12);
     if (!do_align) return;
     __syncthreads();
     const int ldh = ldz;
 
-    // ---- align epilogue: A[TR x c1] = H[TR x Cout] @ Wa + ba ; wave w (< WM) owns rows 16w..16w+15 -------
-    if (wave >= WM) return;
+    // ---- align epilogue: A[TR x c1] = H[TR x Cout] @ Wa + ba ; wave wv (< TM) owns rows 16wv..16wv+15 -------
+    if (wv >= TM) return;
     const int KCHa = Cout >> 4;
     for (int nt = 0; nt < (a.c1 >> 4); ++nt) {
         f32x4 c0 = zero4(), c1v = zero4();
         for (int kc = 0; kc < KCHa; ++kc) {
             const f32x4 b = ld4(a.Wap + ((size_t)(nt * KCHa + kc) * 64 + lane) * 4);
-            const f32x4 av = ld4(At + (wave * 16 + l15) * ldh + kc * 16 + 4 * g);
+            const f32x4 av = ld4(At + (wv * 16 + l15) * ldh + kc * 16 + 4 * g);
             c0 = mfma4(av[0], b[0], c0);
             c1v = mfma4(av[1], b[1], c1v);
             c0 = mfma4(av[2], b[2], c0);
@@ -300,10 +430,11 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(TconvFwdArgs a) {
         const float bb = a.ba[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long R = row0 + wave * 16 + 4 * g + r;
+            const long R = row0 + wv * 16 + 4 * g + r;
             if (R < a.ts.rows) a.A[(size_t)R * a.c1 + col] = c0[r] + c1v[r] + bb;
         }
     }
+    STGCN_PHASE(1, 13);
 }
 
 // ================================================================================================
@@ -339,6 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
     float* const XT0 = stgcn_smem;   // three rotating transposed buffers XT(k) = XT0 + (k % 3) * 16 * LDX
 
+    STGCN_PHASE(4, 0);
     // stage X0 transposed
     const float* Asl = a.A + (size_t)slab * N * 16;
     for (int idx = tid; idx < NP * 4; idx += THREADS) {
@@ -348,6 +480,7 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         for (int i = 0; i < 4; ++i) XT0[(c4 * 4 + i) * LDX + n] = v[i];
     }
     __syncthreads();
+    STGCN_PHASE(4, 1);
 
     f32x4 yacc[MAXQ], res[MAXQ];
 #pragma unroll
@@ -379,6 +512,7 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             continue;
         }
         if (k >= 2) __syncthreads();   // X_{k-1} complete in LDS
+        STGCN_PHASE(4, 2 * k);
         const float* Xprev = XT0 + ((k - 1) % 3) * 16 * LDX;
         f32x4 acc[MAXQ];
 #pragma unroll
@@ -407,6 +541,7 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
                 }
             }
         }
+        STGCN_PHASE(4, 2 * k + 1);
         float* Xcur = XT0 + (k % 3) * 16 * LDX;
         const float* Xpp = XT0 + ((k + 1) % 3) * 16 * LDX;   // == (k-2) % 3
 #pragma unroll
@@ -442,6 +577,7 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             }
         }
     }
+    STGCN_PHASE(4, 15);
 }
 
 // ================================================================================================

@@ -9,7 +9,8 @@ from tests.emu.build_emu import build
 
 
 def bind_emulator():
-    L = _lib.use_library(build())
+    import os
+    L = _lib.use_library(os.environ.get("STGCN_EMU_LIB") or build())   # STGCN_EMU_LIB: emulated build of an experiment variant
     assert L.is_emulator
     return L
 

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Per-phase cycle stamps of the main kernels (diagnostic build -DSTGCN_PHASE_TIMING) at C2 shapes.
+Prints, per kernel: number of workgroups that stamped, the mean duration (cycles) between consecutive phase
+stamps, and the span first-start -> last-end (= kernel duration in shader cycles)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = "/tmp/libstgcn_phase.so"
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", '-DSTGCN_BACKEND_NAME="hip-gfx950"',
+                "-DSTGCN_PHASE_TIMING", os.path.join(ROOT, "stgcn_amd/csrc/stgcn_capi.hip"), "-o", LIB], check=True)
+os.environ["STGCN_AMD_LIB"] = LIB
+from stgcn_amd import _lib, ops  # noqa: E402
+from tests.emu_util import block_case, params_in_field_order  # noqa: E402
+from tests.helpers import real_gso  # noqa: E402
+
+L = _lib.lib()
+dev = "cuda:0"
+NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd"}
+
+
+def run_block(c_in, T):
+    cfg, p = block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T)
+    gso = real_gso("metr_la.cheb_sym_norm_lap")
+    bcfg = ops.BlockConfig(Kt=3, Ks=3, n_vertex=207, c_in=c_in, channels=(64, 16, 64), act_func="glu", graph_conv_type="cheb_graph_conv",
+                           droprate=0.5)
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev))
+    params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", "cheb_graph_conv")]
+    x = torch.randn(32, c_in, T, 207, device=dev).requires_grad_(c_in > 1)
+    wsc = ops.WorkspaceCache()
+
+    def go():
+        y = ops.st_conv_block(x, gp, gt, bcfg, params, True, 1, 1, wsc)
+        y.backward(torch.randn_like(y))
+        torch.cuda.synchronize()
+    return go
+
+
+def report(kid, which, go):
+    for _ in range(2):
+        go()
+    L.dll.stgcn_debug_phase_select(kid)
+    go()
+    buf = (C.c_longlong * (4096 * 16))()
+    L.dll.stgcn_debug_phase_read(buf)
+    a = np.frombuffer(buf, dtype=np.int64).reshape(4096, 16)
+    used = a[(a != 0).any(axis=1)]
+    if len(used) == 0:
+        print(NAMES[kid], which, "no stamps")
+        return
+    t0 = used[used > 0].min()
+    span = used.max() - t0
+    cols = [i for i in range(16) if (used[:, i] != 0).mean() > 0.5]
+    line = []
+    prev = None
+    for i in cols:
+        v = used[:, i]
+        if prev is not None:
+            ok = (v != 0) & (used[:, prev] != 0)
+            line.append(f"p{prev}->p{i}: {np.mean(v[ok] - used[:, prev][ok]):.0f}")
+        prev = i
+    start_spread = (used[:, cols[0]] - t0)
+    print(f"{NAMES[kid]:18s} {which:10s} wgs={len(used):5d} span={span} cyc  start mean={start_spread.mean():.0f} max={start_spread.max()}  | " + "  ".join(line))
+    print(f"   (the LAST of several launches of this kernel in the step overwrote earlier ones)")
+
+
+go1 = run_block(64, 8)
+go0 = run_block(1, 12)
+for kid in (1, 2, 3, 4, 6):
+    report(kid, "blk1", go1)
+for kid in (1, 3, 6):
+    report(kid, "blk0", go0)

@@ -49,10 +49,11 @@ def main():
     print(json.dumps({"device": torch.cuda.get_device_name(0), "backend": L.backend, "torch": torch.__version__}))
 
     # 1. parity report at C2 full size (no asserts)
-    from tests.gpu_util import run_block_case
     from tests.helpers import real_gso
     gso_np = real_gso("metr_la.cheb_sym_norm_lap")
-    for blk, (c_in, T) in enumerate(((1, 12), (64, 8))):
+    quick = "--quick" in sys.argv
+    for blk, (c_in, T) in enumerate(() if quick else ((1, 12), (64, 8))):
+        from tests.gpu_util import run_block_case
         try:
             err = run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, True, gso=gso_np)
             print(json.dumps({"parity_c2_block": blk, "errors": {k: float(f"{v:.3e}") for k, v in err.items()}}))
@@ -86,6 +87,8 @@ def main():
             rep[k]["tflops"] = round(flops[k] / (us * 1e-6) / 1e12, 2)
     print(json.dumps({"kernel_profile": rep, "sum_us": round(sum(r["us_per_step"] for r in rep.values()), 1)}))
 
+    if quick:
+        return
     # forward-only / eval timing
     model.eval()
     with torch.no_grad():
