@@ -51,7 +51,7 @@ typedef struct stgcn_stblock_desc {
     float droprate;           /* p of nn.Dropout                                                     */
     float ln_eps;             /* 1e-12 in the reference (layers.py:246)                              */
     int32_t need_dx;          /* backward: also produce the input gradient                           */
-    int32_t reserved;
+    int32_t reserved;         /* free-form tag (e.g. block index); only used to label the built-in kernel timer   */
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -98,6 +98,8 @@ typedef struct stgcn_stblock_plan {
     int64_t sv_rowstat;               /* [rows2][2] per-row LayerNorm partials (mean, M2) of tmp_conv2 output */
     /* ws: packed weights */
     int64_t ws_W1p, ws_W1d, ws_b1, ws_Wap, ws_WaT, ws_ba, ws_W2p, ws_W2d, ws_b2;
+    int64_t ws_W1dense;               /* [KP1][2*c0] W_eff row major (cheap first conv: gate inputs recomputed in backward) */
+    int64_t recompute_tc1;            /* 1: U1/S1 are not stored (Kt*c_in <= 16)                          */
     /* ws: backward temporaries */
     int64_t ws_rowstat_b;             /* [rows2][2] LayerNorm backward row partials (sum g, sum g*xhat)    */
     int64_t ws_dZ2;                   /* [rows2][2*c2]                                                 */
@@ -114,7 +116,8 @@ const char* stgcn_last_error(void); /* thread-local message of the last failing 
 
 int stgcn_stblock_plan_query(const stgcn_stblock_desc* desc, stgcn_stblock_plan* plan);
 
-/* gso: dense (N, N) row-major.  gso_pad / gso_t_pad: (NP, NP), NP = roundup16(N).                    */
+/* gso: dense (N, N) row-major.  gso_pad / gso_t_pad: NP*NP floats each, NP = roundup16(N): the operator and its
+ * transpose, zero padded and stored in MFMA fragment order (layout: stgcn_kernels_fwd.hip.h, gso_pad_kernel).    */
 int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream);
 
 /* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
@@ -200,7 +203,7 @@ int stgcn_adamw_step(const stgcn_adamw_tensor* tensors, int32_t count, float lr,
 
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the
- * recorded events, writes {"<kernel label>": {"calls": n, "total_ms": t}, ...} as JSON and resets.      */
+ * recorded events, writes {"<kernel label>@<tag>": {"calls": n, "total_ms": t}, ...} as JSON and resets.      */
 int stgcn_profile_enable(int on);
 int stgcn_profile_collect(char* json_buf, size_t cap);
 

@@ -29,7 +29,8 @@ inline int64_t rup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel timing: hipEvent pairs around every launch (off by default) ---------------
-struct ProfSlot { const char* name; hipEvent_t e0, e1; };
+struct ProfSlot { const char* name; int tag; hipEvent_t e0, e1; };
+int g_prof_tag = 0;   // caller-supplied tag (desc->reserved: e.g. the block index) appended to the kernel label
 constexpr int kProfMax = 8192;
 ProfSlot* g_prof = nullptr;
 int g_prof_n = 0, g_prof_on = 0, g_prof_cap = 0;
@@ -48,6 +49,7 @@ inline int prof_begin(const char* name, hipStream_t st) {
     }
     const int i = g_prof_n++;
     g_prof[i].name = name;
+    g_prof[i].tag = g_prof_tag;
     hipEventRecord(g_prof[i].e0, st);
     return i;
 }
@@ -150,6 +152,7 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
     add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
         d->Kt * v.NC2 / 16);
     add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
+    if (pl.recompute_tc1) add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
     pa.njobs = nj;
     STGCN_LAUNCH("pack", st, pack_kernel, dim3(pa.start[nj]), dim3(kThreads), 0, pa);
     return STGCN_OK;
@@ -252,8 +255,8 @@ int stgcn_profile_enable(int on) {
 
 int stgcn_profile_collect(char* buf, size_t cap) {
     if (!buf || cap < 64) return fail(STGCN_ERR_INVALID, "stgcn_profile_collect: buffer too small");
-    struct Agg { const char* name; int calls; double ms; };
-    Agg agg[64];
+    struct Agg { const char* name; int tag; int calls; double ms; };
+    Agg agg[96];
     int na = 0;
     for (int i = 0; i < g_prof_n; ++i) {
         hipEventSynchronize(g_prof[i].e1);
@@ -261,10 +264,10 @@ int stgcn_profile_collect(char* buf, size_t cap) {
         hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
         int k = 0;
         for (; k < na; ++k)
-            if (strcmp(agg[k].name, g_prof[i].name) == 0) break;
+            if (agg[k].tag == g_prof[i].tag && strcmp(agg[k].name, g_prof[i].name) == 0) break;
         if (k == na) {
-            if (na == 64) continue;
-            agg[na].name = g_prof[i].name; agg[na].calls = 0; agg[na].ms = 0.0;
+            if (na == 96) continue;
+            agg[na].name = g_prof[i].name; agg[na].tag = g_prof[i].tag; agg[na].calls = 0; agg[na].ms = 0.0;
             ++na;
         }
         agg[k].calls++;
@@ -273,7 +276,7 @@ int stgcn_profile_collect(char* buf, size_t cap) {
     size_t o = 0;
     o += snprintf(buf + o, cap - o, "{");
     for (int k = 0; k < na && o + 96 < cap; ++k)
-        o += snprintf(buf + o, cap - o, "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", k ? ", " : "", agg[k].name, agg[k].calls, agg[k].ms);
+        o += snprintf(buf + o, cap - o, "%s\"%s@%d\": {\"calls\": %d, \"total_ms\": %.6f}", k ? ", " : "", agg[k].name, agg[k].tag, agg[k].calls, agg[k].ms);
     snprintf(buf + o, cap - o, "}");
     g_prof_n = 0;
     return STGCN_OK;
@@ -289,8 +292,9 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->y_floats = v.rows2 * d->c2;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t at = o; o += rup(n, 64); return at; };   // 256-byte aligned carve
-    p->sv_U1 = take(v.rows1 * d->c0);
-    p->sv_S1 = take(v.rows1 * d->c0);
+    p->recompute_tc1 = (d->Kt * d->c_in <= 16) ? 1 : 0;   // K <= 16: recomputing Z in backward beats storing 2 x rows1 x c0
+    p->sv_U1 = take(p->recompute_tc1 ? 0 : v.rows1 * d->c0);
+    p->sv_S1 = take(p->recompute_tc1 ? 0 : v.rows1 * d->c0);
     p->sv_A = take(v.rows1 * d->c1);
     p->sv_Xk = take((int64_t)(v.terms - 1) * v.rows1 * d->c1);
     p->sv_G = take(v.rows1 * d->c1);
@@ -310,6 +314,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2p = take((int64_t)v.NC2 * v.KP2);
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
+    p->ws_W1dense = take(p->recompute_tc1 ? (int64_t)v.KP1 * v.NC1 : 0);
     p->ws_rowstat_b = take(2 * v.rows2);
     p->ws_dZ2 = take(v.rows2 * v.NC2);
     p->ws_dYg = take(v.rows1 * d->c1);
@@ -350,6 +355,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     if (d->c1 > d->c2 && !P->tc2_aw) return fail(STGCN_ERR_INVALID, "tc2_aw required when c1 > c2");
     const Derived v = derive(d);
     hipStream_t st = (hipStream_t)stream;
+    g_prof_tag = d->reserved;
 
     rc = launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
@@ -360,7 +366,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     t1.ts.src = x; t1.ts.C = d->c_in; t1.ts.taps = d->Kt; t1.ts.N = d->N; t1.ts.Tsrc = d->T; t1.ts.Tdst = v.T1; t1.ts.dir = 1;
     t1.ts.rows = v.rows1;
     t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
-    t1.U = saved + pl.sv_U1; t1.S = saved + pl.sv_S1; t1.H = nullptr;
+    t1.U = pl.recompute_tc1 ? nullptr : saved + pl.sv_U1; t1.S = pl.recompute_tc1 ? nullptr : saved + pl.sv_S1; t1.H = nullptr;
     t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;
     rc = launch_tconv_fwd("tconv_fwd.tc1", t1, st);
     if (rc) return rc;

@@ -62,7 +62,7 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
-    g.al_wgs = (int)(tiles1 < 256 ? tiles1 : 256);
+    g.al_wgs = (int)(tiles1 < 1024 ? tiles1 : 1024);   // 23.5 KB of LDS each: several per CU for latency hiding
     long o = 0;
     auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };
     g.off_ln_g = take((long)g.ln_sg * n);
@@ -356,7 +356,7 @@ struct GconvBwdArgs {
     const float* dY;     // [slabs][N][16]
     const float* X0;     // [slabs][N][16]   (A)
     const float* Xk;     // [terms-1][slabs][N][16]
-    const float* LTp;    // [NP][NP]
+    const float* LTp;    // fragment-packed transposed operator
     const float* W;
     float* dA;           // [slabs][N][16]
     float* part;         // [slabs][(terms+1)*256]
@@ -431,20 +431,23 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
         f32x4 acc[MAXQ];
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
-        f32x4 bnext[MAXQ];
+        f32x4 bn1[MAXQ], bn2[MAXQ];   // operator fragments two chunks ahead
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
-            bnext[q] = ht < HT ? ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + 4 * g) : zero4();
+            const float* lrow = a.LTp + ((size_t)ht * KCH * 64 + lane) * 4;   // fragment-packed transposed operator
+            bn1[q] = ht < HT ? ld4(lrow) : zero4();
+            bn2[q] = (ht < HT && KCH > 1) ? ld4(lrow + 256) : zero4();
         }
         for (int kc = 0; kc < KCH; ++kc) {
             const f32x4 af = ld4(Gk + l15 * LDX + kc * 16 + 4 * g);
             f32x4 bf[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                bf[q] = bnext[q];
+                bf[q] = bn1[q];
+                bn1[q] = bn2[q];
                 const int ht = wave + WAVES * q;
-                if (kc + 1 < KCH && ht < HT) bnext[q] = ld4(a.LTp + (size_t)(ht * 16 + l15) * NP + (kc + 1) * 16 + 4 * g);
+                if (kc + 2 < KCH && ht < HT) bn2[q] = ld4(a.LTp + ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4);
             }
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
@@ -504,8 +507,12 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
 // ================================================================================================
 struct AlignBwdArgs {
     const float* dA;     // [rows][c1]
-    const float* U;      // [rows][c0]
+    const float* U;      // [rows][c0]  (null: recompute U, S from x -- first block, Kt*c_in <= 16)
     const float* S;
+    TapSrc ts;           // x viewed through Kt taps (recompute path)
+    const float* Wd;     // dense W_eff [KPd][2*c0] (recompute path)
+    const float* bias;   // b_eff [2*c0]
+    int KPd;
     const float* WaT;    // packed: K = c1 (KCH chunks), cols = c0
     float* dZ;           // [rows][2*c0]
     float* part;         // [wgs][c0*c1 + c1]
@@ -566,7 +573,31 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
             f32x4 h = zero4();
             if (R < a.rows) {
                 const f32x4 dh = ld4(Ht + row * LDH + 4 * c4);
-                const f32x4 u = ld4(a.U + (size_t)R * c0 + 4 * c4), s = ld4(a.S + (size_t)R * c0 + 4 * c4);
+                f32x4 u, s;
+                if (a.U) {
+                    u = ld4(a.U + (size_t)R * c0 + 4 * c4);
+                    s = ld4(a.S + (size_t)R * c0 + 4 * c4);
+                } else {   // cheap conv (K <= 16): Z = im2col(x) @ W_eff + b_eff recomputed instead of stored
+                    const long per_b = (long)a.ts.Tdst * a.ts.N;
+                    const int b = (int)(R / per_b);
+                    const long rem = R - (long)b * per_b;
+                    const float* xr = a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem) * a.ts.C;
+                    u = ld4(a.bias + 4 * c4);
+                    f32x4 qv = ld4(a.bias + c0 + 4 * c4);
+                    const int K = a.ts.taps * a.ts.C;
+                    for (int kidx = 0; kidx < K; ++kidx) {
+                        const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                        const float xv = xr[(size_t)tap * a.ts.N * a.ts.C + ch];
+                        const f32x4 wp = ld4(a.Wd + (size_t)kidx * 2 * c0 + 4 * c4), wq = ld4(a.Wd + (size_t)kidx * 2 * c0 + c0 + 4 * c4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            u[i] = fmaf(xv, wp[i], u[i]);
+                            qv[i] = fmaf(xv, wq[i], qv[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] = sigmoid_f(qv[i]);
+                }
                 f32x4 du, dq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

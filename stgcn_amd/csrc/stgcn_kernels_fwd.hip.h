@@ -15,7 +15,8 @@ namespace stgcn {
 // so a wave fetches one (nt, kc) fragment with a single coalesced 1 KiB load (16 B per lane).
 // ================================================================================================
 enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5,
-                PK_LIN_FWD = 6, PK_LIN_BWD = 7 };   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
+                PK_LIN_FWD = 6, PK_LIN_BWD = 7,
+                PK_TCONV_DENSE = 8 };   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
 
 struct PackJob {
     int kind;
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
         if (j.Cin > j.Cout && e < j.Cout && j.ab) v += j.ab[e];
     } else if (j.kind == PK_ALIGN_BIAS) {
         v = (j.Cin > j.Cout && j.b) ? j.b[e] : 0.f;
+    } else if (j.kind == PK_TCONV_DENSE) {
+        const int kidx = e / NC, o = e - kidx * NC;
+        if (kidx < j.Kt * j.Cin) v = tconv_weff(j, kidx / j.Cin, kidx % j.Cin, o);
     } else {
         const int s = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
         const int kc = rest % j.KCH, nt = rest / j.KCH;
@@ -79,16 +83,21 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     j.dst[e] = v;
 }
 
-// Zero-padded copies of the graph shift operator: Lp[h][i] = L[h][i], LTp[h][i] = L[i][h], both
-// [NP][NP] with NP = roundup(N, 16) so that fragment loads are 16-byte aligned and padding rows /
-// columns contribute exact zeros.
-__global__ __launch_bounds__(256) void gso_pad_kernel(const float* L, int N, int NP, float* Lp, float* LTp) {
+// The graph shift operator is constant, so it is rewritten ONCE into MFMA B-operand fragment order, zero padded to
+// NP = roundup(N, 16):   Lf[((ht*KCH + kc)*64 + lane)*4 + s] = L[ht*16 + (lane&15)][kc*16 + 4*(lane>>4) + s]
+// (and the same for L^T, used by backward).  One (node tile ht, k chunk kc) fragment is then a contiguous 1 KiB
+// wave load (8 full cache lines) instead of 16 row segments of 64 B (half of 16 lines): the operator is streamed
+// through L1 by every workgroup, so this halves the dominant L2 -> L1 traffic of the graph-conv kernels.
+__global__ __launch_bounds__(256) void gso_pad_kernel(const float* L, int N, int NP, float* Lf, float* LTf) {
     const int e = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     if (e >= NP * NP) return;
-    const int h = e / NP, i = e % NP;
+    const int KCH = NP >> 4;
+    const int s = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+    const int kc = rest % KCH, ht = rest / KCH;
+    const int h = ht * 16 + (lane & 15), i = kc * 16 + 4 * (lane >> 4) + s;
     const bool in = h < N && i < N;
-    Lp[e] = in ? L[(size_t)h * N + i] : 0.f;
-    LTp[e] = in ? L[(size_t)i * N + h] : 0.f;
+    Lf[e] = in ? L[(size_t)h * N + i] : 0.f;
+    LTf[e] = in ? L[(size_t)i * N + h] : 0.f;
 }
 
 // ================================================================================================
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 // ================================================================================================
 struct GconvFwdArgs {
     const float* A;      // [slabs][N][16]
-    const float* Lp;     // [NP][NP] zero padded
+    const float* Lp;     // fragment-packed operator (gso_pad_kernel), NP*NP floats
     const float* W;      // cheb: [Ks][16][16] ; kipf: [16][16]
     const float* bias;   // [16] or null
     float* Xk;           // [Ks-1][slabs][N][16]   (X1..X_{Ks-1}, saved for backward; nullable)
@@ -517,20 +526,24 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         f32x4 acc[MAXQ];
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
-        f32x4 bnext[MAXQ];
+        // operator fragments are requested two chunks ahead (L2 latency >> one chunk of MFMAs)
+        f32x4 bn1[MAXQ], bn2[MAXQ];
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
-            bnext[q] = ht < HT ? ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + 4 * g) : zero4();
+            const float* lrow = a.Lp + ((size_t)ht * KCH * 64 + lane) * 4;   // fragment-packed operator
+            bn1[q] = ht < HT ? ld4(lrow) : zero4();
+            bn2[q] = (ht < HT && KCH > 1) ? ld4(lrow + 256) : zero4();
         }
         for (int kc = 0; kc < KCH; ++kc) {
             const f32x4 af = ld4(Xprev + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
             f32x4 bf[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                bf[q] = bnext[q];                                           // B[node][h = l15]
+                bf[q] = bn1[q];                                             // B[node][h = l15]
+                bn1[q] = bn2[q];
                 const int ht = wave + WAVES * q;
-                if (kc + 1 < KCH && ht < HT) bnext[q] = ld4(a.Lp + (size_t)(ht * 16 + l15) * NP + (kc + 1) * 16 + 4 * g);
+                if (kc + 2 < KCH && ht < HT) bn2[q] = ld4(a.Lp + ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4);
             }
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {

@@ -21,6 +21,8 @@ class _STGCNBase(nn.Module):
             layers.STConvBlock(args.Kt, args.Ks, n_vertex, blocks[l][-1], blocks[l + 1], args.act_func,
                                args.graph_conv_type, args.gso, args.enable_bias, args.droprate)
             for l in range(n_st)])
+        for l, blk in enumerate(self.st_blocks):
+            blk.cfg = blk.cfg.__class__(**{**blk.cfg.__dict__, "tag": l})      # block index, for the kernel timer labels
         self.Ko = args.n_his - n_st * 2 * (args.Kt - 1)
         if self.Ko > 1:
             self.output = layers.OutputBlock(self.Ko, blocks[-3][-1], blocks[-2], blocks[-1][0], n_vertex,

@@ -31,6 +31,7 @@ class BlockConfig:
     graph_conv_type: str
     droprate: float
     ln_eps: float = 1e-12
+    tag: int = 0          # block index: labels the library's kernel timer only
 
 
 def _stream_of(t: torch.Tensor) -> Optional[int]:
@@ -65,6 +66,7 @@ def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool) -
     d.droprate = float(cfg.droprate)
     d.ln_eps = float(cfg.ln_eps)
     d.need_dx = 1 if need_dx else 0
+    d.reserved = int(cfg.tag)
     return d
 
 

@@ -27,13 +27,24 @@ def dist_env():
 
 
 def init_distributed(backend: Optional[str] = None):
+    """One process per GPU.  The device is bound BEFORE the process group is created so that RCCL builds its
+    communicator on the right GPU (and the first collective does not have to guess)."""
     rank, local_rank, world = dist_env()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver stack
+        if backend == "nccl":
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except TypeError:      # older signature without device_id
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -139,6 +150,10 @@ class GraphedTrainStep:
                 torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
                 self.opt.step()
                 DropoutStream.advance()
+        # one full replay inside the constructor: a capture / replay problem surfaces here (where the caller can
+        # still fall back to eager launches of the same kernels), not inside a timed loop
+        self(x_example, y_example)
+        torch.cuda.synchronize(dev)
 
     def _fwd_bwd(self):
         y_pred = self.model(self.x).reshape(len(self.x), -1)

@@ -165,6 +165,49 @@ def real_gsos(utility):
     return out
 
 
+def pipeline_case(models, utility, gsos):
+    """The reference's data path end to end on a synthetic vel series (BASELINE.md section 4 recipe, shortened):
+    dataloader.data_transform, StandardScaler, model eval, utility.evaluate_metric -- plus calc_gso inputs/outputs."""
+    from script import dataloader
+    from sklearn import preprocessing
+    n, rows, n_his, n_pred, bs = 207, 420, 12, 3, 32
+    rng = np.random.default_rng(0)
+    t = np.arange(rows)[:, None]
+    phi = rng.uniform(0, 2 * np.pi, size=(1, n))
+    vel = np.clip(55 + 10 * np.sin(2 * np.pi * t / 288 + phi) + rng.normal(0, 3, size=(rows, n)), 0, 80)
+    len_val = int(np.floor(rows * 0.15)); len_test = len_val; len_train = rows - len_val - len_test      # main.py:108-114
+    train, val, test = vel[:len_train], vel[len_train:len_train + len_val], vel[len_train + len_val:]
+    z = preprocessing.StandardScaler()
+    train_s, test_s = z.fit_transform(train), z.transform(test)
+    x_tr, y_tr = dataloader.data_transform(train_s, n_his, n_pred, "cpu")
+    x_te, y_te = dataloader.data_transform(test_s, n_his, n_pred, "cpu")
+    base = dict(Kt=3, Ks=3, act="glu", gct="cheb_graph_conv", n_his=12, droprate=0.5,
+                blocks=[[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]])
+    gso = gsos["metr_la.cheb_sym_norm_lap"]
+    ocfg = orc.OracleConfig(Kt=3, Ks=3, n_his=12, droprate=0.5, blocks=base["blocks"])
+    params = orc.random_params(ocfg, n, seed=21)
+    model = models.STGCNChebGraphConv(make_args(base, torch.from_numpy(gso)), base["blocks"], n)
+    model.load_state_dict(params, strict=True)
+    it = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x_te, y_te), batch_size=bs, shuffle=False)
+    mse = utility.evaluate_model(model, torch.nn.MSELoss(), it)
+    mae, rmse, wmape = utility.evaluate_metric(model, it, z)
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([model(x).view(len(x), -1) for x, _ in it]).numpy()
+    adj = sp.load_npz(os.path.join(REF, "data", "metr-la", "adj.npz")).tocoo()
+    out = {"meta_versions": versions(), "vel": vel.astype(np.float32), "n_his": n_his, "n_pred": n_pred, "batch_size": bs, "param_seed": 21,
+           "param_checksum": np.array(orc.param_checksums(params)),
+           "len_train": len_train, "len_val": len_val, "zscore_mean": z.mean_, "zscore_scale": z.scale_,
+           "x_train_first": x_tr[:2].numpy(), "y_train_first": y_tr[:2].numpy(), "x_train_last": x_tr[-1:].numpy(),
+           "n_train_windows": len(x_tr), "n_test_windows": len(x_te), "y_test": y_te.numpy(),
+           "pred_test": pred, "metrics": np.array([mse, mae, rmse, wmape]),
+           "adj_row": adj.row.astype(np.int16), "adj_col": adj.col.astype(np.int16), "adj_val": adj.data.astype(np.float32),
+           "gso_sym_norm_lap": utility.calc_gso(sp.load_npz(os.path.join(REF, "data", "metr-la", "adj.npz")).tocsc(), "sym_norm_lap").toarray().astype(np.float32)}
+    path = os.path.join(HERE, "pipeline_metr_la.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)  metrics mse/mae/rmse/wmape = {mse:.6f} {mae:.6f} {rmse:.6f} {wmape:.8f}")
+
+
 def main():
     layers, models, utility = import_reference()
     torch.set_num_threads(1)       # bit-reproducible reductions
@@ -172,6 +215,7 @@ def main():
     base = dict(Kt=3, Ks=3, act="glu", gct="cheb_graph_conv", n_his=12, droprate=0.0, blocks=std_blocks)
 
     gsos = real_gsos(utility)
+    pipeline_case(models, utility, gsos)
 
     # 1. tiny standard-channel model, non-symmetric GSO: fwd, all sub-layer activations, full grads, 3 AdamW steps
     run_case(models, "tiny_cheb_f32", base, synth_gso(20, 1), B=2, seed=10, train_steps=3, store_acts=("st_blocks", "sub"))

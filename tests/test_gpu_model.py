@@ -133,3 +133,40 @@ def test_training_trajectory_matches_oracle():
         assert abs(float(v.double().abs().sum()) - ref[1]) <= 1e-4 * ref[1] + 1e-9, k
         if ("steps.param." + k) in fx:
             assert maxabs(v.cpu().numpy(), fx["steps.param." + k]) <= 1e-4, k
+
+
+def test_mae_rmse_match_reference_on_metr_la_windows():
+    """north star: MAE/RMSE of the MI355X path match the reference CPU path within 1e-4 on the same METR-LA input
+    windows (synthetic series on the real graph; predictions/metrics of the reference stored by make_golden.py)."""
+    import types
+    from oracle import stgcn_oracle as orc
+    from stgcn_amd import data, models
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    fx = load_fixture("pipeline_metr_la")
+    n_his, n_pred, bs = int(fx["n_his"]), int(fx["n_pred"]), int(fx["batch_size"])
+    blocks = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
+    cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=n_his, droprate=0.5, blocks=blocks)
+    params = orc.random_params(cfg, 207, seed=int(fx["param_seed"]))
+    s, a = orc.param_checksums(params)
+    assert abs(a - fx["param_checksum"][1]) <= 1e-6 * a
+    gso = torch.from_numpy(real_gso("metr_la.cheb_sym_norm_lap")).to(DEV)
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True,
+                                 droprate=0.5, n_his=n_his)
+    model = models.STGCNChebGraphConv(args, blocks, 207)
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV)
+    vel = fx["vel"].astype(np.float64)
+    len_train, len_val, _ = data.split_lengths(len(vel))
+    z = data.ZScore().fit(vel[:len_train])
+    test = z.transform(vel[len_train + len_val:])
+    sampler = data.WindowSampler(test, n_his, n_pred, DEV)            # device-side windowing
+    assert len(sampler) == int(fx["n_test_windows"])
+    model.eval()
+    with torch.no_grad():
+        pred = torch.cat([model(x).view(len(x), -1) for x, _ in sampler.batches(bs)]).cpu().numpy()
+    assert maxabs(pred, fx["pred_test"]) <= 1e-4
+    mse = data.evaluate_model(model, torch.nn.MSELoss(), sampler.batches(bs))
+    mae, rmse, wmape = data.evaluate_metric(model, sampler.batches(bs), z)
+    mse_ref, mae_ref, rmse_ref, wmape_ref = fx["metrics"]
+    assert abs(mse - mse_ref) <= 1e-4 and abs(mae - mae_ref) <= 1e-4 and abs(rmse - rmse_ref) <= 1e-4 and abs(wmape - wmape_ref) <= 1e-5

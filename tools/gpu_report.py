@@ -85,6 +85,7 @@ def main():
         rep[k] = {"us_per_step": round(us, 2), "calls_per_step": v["calls"] / 20}
         if flops.get(k):
             rep[k]["tflops"] = round(flops[k] / (us * 1e-6) / 1e12, 2)
+            rep[k]["mfma_frac"] = round(rep[k]["tflops"] / 157.3, 3)
     print(json.dumps({"kernel_profile": rep, "sum_us": round(sum(r["us_per_step"] for r in rep.values()), 1)}))
 
     if quick:
