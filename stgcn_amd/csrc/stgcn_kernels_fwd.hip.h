@@ -172,6 +172,11 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
 #ifndef STGCN_STAGGER
 #define STGCN_STAGGER 0
 #endif
+// STGCN_ABL: timing-only ablations (results are WRONG): 1 gconv without operator loads, 2 gconv without term MFMAs,
+// 3 tconv_fwd without U/S/A stores, 4 tconv_fwd without tile loads, 5 tconv_fwd without MFMAs, 6 gconv without X0 staging + stores
+#ifndef STGCN_ABL
+#define STGCN_ABL 0
+#endif
 // STGCN_PIPE_FWD / STGCN_PIPE_BWD: software-pipelined K-segment loop (weights -> registers, next tile segment in flight
 // during the MFMAs).  Measured on MI355X (profiles/): helps the transposed conv (3+ segments), hurts the forward conv.
 #ifndef STGCN_PIPE_FWD
@@ -365,10 +370,18 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
     for (int k0 = 0; k0 < KP; k0 += kSegMax) {
         const int kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
         if (k0 > 0) __syncthreads();   // previous segment fully consumed
+#if STGCN_ABL == 4
+        for (int idx = threadIdx.x; idx < TR * (kseg + 4); idx += THREADS) At[idx] = 0.5f;
+#else
         tile_load_segment<TR, THREADS>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+#endif
         __syncthreads();
         STGCN_PHASE(1, 2 + 2 * (k0 / kSegMax));
+#if STGCN_ABL == 5
+        acc[0][0][0] += At[threadIdx.x];
+#else
         seg_mma<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+#endif
         STGCN_PHASE(1, 3 + 2 * (k0 / kSegMax));
     }
 
@@ -399,12 +412,16 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
             sg[i] = sigmoid_f(q[i] + bq[i]);
             h[i] = gate_fwd(u[i], sg[i], a.act);
         }
+#if STGCN_ABL == 3
+        if (R < a.ts.rows && u[0] == 12345.678f) st4(a.U + (size_t)R * Cout + 4 * c4, sg);
+#else
         if (R < a.ts.rows) {
             const size_t o = (size_t)R * Cout + 4 * c4;
             if (a.U) st4(a.U + o, u);
             if (a.S) st4(a.S + o, sg);
             if (a.H) st4(a.H + o, h);
         }
+#endif
         if (a.rowstat) {   // per-row LayerNorm partials: the c4n lanes holding one row are contiguous in the wave
             float sr = (h[0] + h[1]) + (h[2] + h[3]);
             for (int m = c4n >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
@@ -532,8 +549,12 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
             const float* lrow = a.Lp + ((size_t)ht * KCH * 64 + lane) * 4;   // fragment-packed operator
+#if STGCN_ABL == 1
+            (void)lrow; bn1[q] = zero4(); bn2[q] = zero4();
+#else
             bn1[q] = ht < HT ? ld4(lrow) : zero4();
             bn2[q] = (ht < HT && KCH > 1) ? ld4(lrow + 256) : zero4();
+#endif
         }
         for (int kc = 0; kc < KCH; ++kc) {
             const f32x4 af = ld4(Xprev + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
@@ -543,14 +564,21 @@ __global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
                 bf[q] = bn1[q];                                             // B[node][h = l15]
                 bn1[q] = bn2[q];
                 const int ht = wave + WAVES * q;
+#if STGCN_ABL != 1
                 if (kc + 2 < KCH && ht < HT) bn2[q] = ld4(a.Lp + ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4);
+#endif
             }
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
                 const int ht = wave + WAVES * q;
                 if (ht < HT) {
+#if STGCN_ABL == 2
+                    asm volatile("" ::"v"(af[0]), "v"(bf[q][0]), "v"(bf[q][3]));
+                    acc[q][0] += af[1];
+#else
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[q][s], acc[q]);
+#endif
                 }
             }
         }
