@@ -39,11 +39,12 @@ def test_graph_replay_equals_eager_and_masks_change():
     init = {k: v.clone() for k, v in m1.state_dict().items()}
     o1 = make_optimizer(m1, capturable=True)
     gs = GraphedTrainStep(m1, o1, xs[0], ys[0], warmup=2)
-    # GraphedTrainStep's warm-up already trained 2 steps on xs[0]; replicate that eagerly on the twin
+    # GraphedTrainStep's constructor already trained on xs[0]: 2 warm-up steps + 1 verification replay;
+    # replicate that eagerly on the twin
     DropoutStream.disable_device_counter()
     m2 = _make(0.0)
     o2 = make_optimizer(m2, capturable=True)
-    for _ in range(2):
+    for _ in range(3):
         train_step(m2, o2, xs[0], ys[0])
     l1 = [float(gs(xs[i], ys[i]).item()) for i in range(1, 6)]
     l2 = [float(train_step(m2, o2, xs[i], ys[i]).item()) for i in range(1, 6)]
