@@ -100,6 +100,8 @@ typedef struct stgcn_stblock_plan {
     int64_t ws_W1p, ws_W1d, ws_b1, ws_Wap, ws_WaT, ws_ba, ws_W2p, ws_W2d, ws_b2;
     int64_t ws_W1dense;               /* [KP1][2*c0] W_eff row major (cheap first conv: gate inputs recomputed in backward) */
     int64_t recompute_tc1;            /* 1: U1/S1 are not stored (Kt*c_in <= 16)                          */
+    int64_t ws_WaDense;               /* [c0][c1] dense Align map (thin first-layer kernels)               */
+    int64_t thin_tc1;                 /* 1: first layer runs the thin (thread-per-row) kernels             */
     /* ws: backward temporaries */
     int64_t ws_rowstat_b;             /* [rows2][2] LayerNorm backward row partials (sum g, sum g*xhat)    */
     int64_t ws_dZ2;                   /* [rows2][2*c2]                                                 */

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include "stgcn_kernels_bwd.hip.h"
@@ -171,9 +172,15 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
     // 64-row tiles / 8 waves are kept selectable (STGCN_TCONV_TR=64) for larger problems.
     static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;   // tuning knob
     const bool small = force_tr ? force_tr == 32 : true;
-    const int tr = small ? 32 : kTileRows;
+    const bool tiny = !force_tr && cdiv(a.ts.rows, 32) < 256;     // fewer than one 32-row tile per CU: 16-row tiles
+    const int tr = tiny ? 16 : (small ? 32 : kTileRows);
     const dim3 grid(cdiv(a.ts.rows, tr));
     const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
+    if (tiny) {
+        if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 1, 4>), grid, dim3(256), lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 1, 4>), grid, dim3(256), lds, a);
+        return STGCN_OK;
+    }
     // 64-row tiles run with 8 waves (2 per SIMD and workgroup), 32-row tiles with 4
     if (a.Cout == 64) {
         if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 2, 4>), grid, dim3(256), lds, a);
@@ -315,6 +322,8 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
     p->ws_W1dense = take(p->recompute_tc1 ? (int64_t)v.KP1 * v.NC1 : 0);
+    p->thin_tc1 = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms).thin;
+    p->ws_WaDense = take(p->thin_tc1 ? (int64_t)d->c0 * d->c1 : 0);
     p->ws_rowstat_b = take(2 * v.rows2);
     p->ws_dZ2 = take(v.rows2 * v.NC2);
     p->ws_dYg = take(v.rows1 * d->c1);
@@ -361,15 +370,17 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     if (rc) return rc;
 
     // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------
-    TconvFwdArgs t1;
-    memset(&t1, 0, sizeof(t1));
-    t1.ts.src = x; t1.ts.C = d->c_in; t1.ts.taps = d->Kt; t1.ts.N = d->N; t1.ts.Tsrc = d->T; t1.ts.Tdst = v.T1; t1.ts.dir = 1;
-    t1.ts.rows = v.rows1;
-    t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
-    t1.U = pl.recompute_tc1 ? nullptr : saved + pl.sv_U1; t1.S = pl.recompute_tc1 ? nullptr : saved + pl.sv_S1; t1.H = nullptr;
-    t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;
-    rc = launch_tconv_fwd("tconv_fwd.tc1", t1, st);
-    if (rc) return rc;
+    {
+        TconvFwdArgs t1;
+        memset(&t1, 0, sizeof(t1));
+        t1.ts.src = x; t1.ts.C = d->c_in; t1.ts.taps = d->Kt; t1.ts.N = d->N; t1.ts.Tsrc = d->T; t1.ts.Tdst = v.T1; t1.ts.dir = 1;
+        t1.ts.rows = v.rows1;
+        t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
+        t1.U = pl.recompute_tc1 ? nullptr : saved + pl.sv_U1; t1.S = pl.recompute_tc1 ? nullptr : saved + pl.sv_S1; t1.H = nullptr;
+        t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;
+        rc = launch_tconv_fwd("tconv_fwd.tc1", t1, st);
+        if (rc) return rc;
+    }
 
     // ---- graph conv + residual + relu -----------------------------------------------------------
     GconvFwdArgs gc;

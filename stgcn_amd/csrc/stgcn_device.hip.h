@@ -41,7 +41,8 @@ __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): a full-precision IEEE divide costs ~10 instructions per element in the epilogues
+__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 // ---- gate math (reference model/layers.py:105 GLU, :109 GTU) --------------------------------
 // forward: h = act(u) * s ; act = identity (glu) or tanh (gtu)

@@ -26,7 +26,8 @@ struct BwdGeom {
     WgradGeom w1, w2;
     long off_ln_g, off_ln_b, off_gc, off_al, total;
     int gc_stride;           // floats per slab in the graph-conv partials: (terms + 1) * 256
-    int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1
+    int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1 (+ 16*2*c0 + 2*c0 on the thin path)
+    int thin;                // first layer handled by thin_tc1_bwd_kernel (Kt*c_in <= 16, c0 == 64)
 };
 
 inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
@@ -69,7 +70,8 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.off_ln_b = take((long)g.ln_sg * n);
     g.gc_stride = (terms + 1) * 256;
     g.off_gc = take(slabs1 * g.gc_stride);
-    g.al_stride = c0 * c1 + c1;
+    g.thin = (Kt * c_in <= 16 && c0 == 64 && c1 == 16) ? 1 : 0;
+    g.al_stride = c0 * c1 + c1 + (g.thin ? 16 * 2 * c0 + 2 * c0 : 0);
     g.off_al = take((long)g.al_wgs * g.al_stride);
     g.w1 = wgrad_geom(rows1, Kt * c_in, 2 * c0, 0);
     g.w1.off = take(g.w1.floats);
@@ -640,6 +642,151 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
         float s = 0.f;
         for (int rg = 0; rg < 16; ++rg) s += red[rg * c1 + tid];
         part[c0 * c1 + tid] = s;
+    }
+}
+
+// ================================================================================================
+// B4-thin: backward of the thin first layer (K = Kt*c_in <= 16), everything in one kernel per 64-row tile:
+//   recompute U, S, H from x;  dH = dA Wa^T;  gate backward -> dZ tile (kept in LDS; written to HBM only if an input
+//   gradient is needed);  partial dWa, dba (as align_gate_bwd_kernel);  partial dW_eff = im2col(x)^T dZ by MFMA
+//   (M = 16 padded taps x N = 2*c0 x K = 64 rows) and db_eff = column sums of dZ.
+// Replaces align_gate_bwd + tconv_bwd_weight for that layer and removes the dZ1 round trip through HBM.
+// ================================================================================================
+struct ThinBwdArgs {
+    const float* dA;     // [rows][16]
+    TapSrc ts;           // x through Kt taps
+    const float* Wd;     // dense W_eff [16][2*c0]
+    const float* bias;   // b_eff [2*c0]
+    const float* WaT;    // packed PK_ALIGN_BWD: K = 16, cols = c0
+    float* dZ;           // [rows][2*c0] or null
+    float* part;         // [wgs][c0*16 + 16 + 16*2*c0 + 2*c0] : dWa | dba | dW_eff (16 rows) | db_eff
+    long rows;
+    int c0, act;
+};
+
+__global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int c0 = a.c0, NC = 2 * c0, LDA = 20, LDH = c0 + 4, LDZ = NC + 4, LDX = 20;
+    float* dAt = stgcn_smem;                     // [64][LDA]
+    float* Ht = dAt + 64 * LDA;                  // [64][LDH]  dH, then H
+    float* Zt = Ht + 64 * LDH;                   // [64][LDZ]  dZ = [dU | dQ]
+    float* xt = Zt + 64 * LDZ;                   // [64][LDX]  im2col rows of x (16 padded taps)
+    float* red = xt + 64 * LDX;                  // [256]
+    const long tiles = (a.rows + kTileRows - 1) / kTileRows;
+    const int K = a.ts.taps * a.ts.C, c4n = c0 >> 2;
+    const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N);
+    f32x4 wacc = zero4();                        // dWa tile rows wave*16.. (c0 == 64: one column tile of H per wave)
+    f32x4 gacc[2] = {zero4(), zero4()};          // dW_eff tiles: n-tiles 2*wave, 2*wave+1 (NC == 128)
+    float bsum = 0.f, zsum = 0.f;                // dba column (tid&15), db_eff column (tid % NC)
+    const int zcol = tid % NC, zpart = tid / NC, zrows = 64 / (kThreads / NC);
+    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long row0 = t * kTileRows;
+        __syncthreads();
+        for (int idx = tid; idx < kTileRows * 4; idx += kThreads) {
+            const int r = idx >> 2, q = idx & 3;
+            st4(dAt + r * LDA + 4 * q, row0 + r < a.rows ? ld4(a.dA + (size_t)(row0 + r) * 16 + 4 * q) : zero4());
+        }
+        for (int idx = tid; idx < kTileRows * 16; idx += kThreads) {
+            const int r = idx >> 4, k = idx & 15;
+            const long R = row0 + r;
+            float v = 0.f;
+            if (R < a.rows && k < K) {
+                const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
+                const int tap = k / a.ts.C, ch = k - tap * a.ts.C;
+                v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+            }
+            xt[r * LDX + k] = v;
+        }
+        __syncthreads();
+        {
+            const int rg = tid >> 4, jj = tid & 15;
+            bsum += dAt[rg * LDA + jj] + dAt[(rg + 16) * LDA + jj] + dAt[(rg + 32) * LDA + jj] + dAt[(rg + 48) * LDA + jj];
+        }
+        // dH = dA @ Wa^T (K = 16: one chunk; wave w: column tile w, 4 m-tiles) -> LDS
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] = zero4();
+        seg_mma<4, 1>(acc, dAt, LDA, 0, 1, a.WaT, 0, 1, wave, 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ht[(i * 16 + 4 * g + r) * LDH + wave * 16 + l15] = acc[i][0][r];
+        __syncthreads();
+        // row-major pass: recompute gate inputs, gate backward, dZ / H tiles
+        for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            const long R = row0 + row;
+            f32x4 h = zero4(), du = zero4(), dq = zero4();
+            if (R < a.rows) {
+                const f32x4 dh = ld4(Ht + row * LDH + 4 * c4);
+                f32x4 u = ld4(a.bias + 4 * c4), qv = ld4(a.bias + c0 + 4 * c4);
+                for (int k = 0; k < K; ++k) {
+                    const float xv = xt[row * LDX + k];
+                    const f32x4 wp = ld4(a.Wd + (size_t)k * NC + 4 * c4), wq = ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u[i] = fmaf(xv, wp[i], u[i]);
+                        qv[i] = fmaf(xv, wq[i], qv[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sg = sigmoid_f(qv[i]);
+                    float du_, dq_;
+                    gate_bwd(dh[i], u[i], sg, a.act, du_, dq_);
+                    du[i] = du_;
+                    dq[i] = dq_;
+                    h[i] = gate_fwd(u[i], sg, a.act);
+                }
+                if (a.dZ) {
+                    st4(a.dZ + (size_t)R * NC + 4 * c4, du);
+                    st4(a.dZ + (size_t)R * NC + c0 + 4 * c4, dq);
+                }
+            }
+            st4(Ht + row * LDH + 4 * c4, h);
+            st4(Zt + row * LDZ + 4 * c4, du);
+            st4(Zt + row * LDZ + c0 + 4 * c4, dq);
+        }
+        __syncthreads();
+        for (int r = 0; r < zrows; ++r) zsum += Zt[(zpart * zrows + r) * LDZ + zcol];
+        // dWa[i][j] += H^T dA ; dW_eff[k][o] += xcol^T dZ   (K dimension = the 64 rows of the tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rbase = i * 16 + 4 * g;
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const int row = rbase + sx;
+                wacc = mfma4(Ht[row * LDH + wave * 16 + l15], dAt[row * LDA + l15], wacc);
+                const float xa = xt[row * LDX + l15];
+                gacc[0] = mfma4(xa, Zt[row * LDZ + (2 * wave) * 16 + l15], gacc[0]);
+                gacc[1] = mfma4(xa, Zt[row * LDZ + (2 * wave + 1) * 16 + l15], gacc[1]);
+            }
+        }
+    }
+    const int pstride = c0 * 16 + 16 + 16 * NC + NC;
+    float* part = a.part + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[(wave * 16 + 4 * g + r) * 16 + l15] = wacc[r];                                    // dWa[i][j]
+        part[c0 * 16 + 16 + (4 * g + r) * NC + (2 * wave) * 16 + l15] = gacc[0][r];            // dW_eff[k][o]
+        part[c0 * 16 + 16 + (4 * g + r) * NC + (2 * wave + 1) * 16 + l15] = gacc[1][r];
+    }
+    __syncthreads();
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 16) {
+        float sacc = 0.f;
+        for (int rg = 0; rg < 16; ++rg) sacc += red[rg * 16 + tid];
+        part[c0 * 16 + tid] = sacc;
+    }
+    __syncthreads();
+    red[tid] = zsum;
+    __syncthreads();
+    if (tid < NC) {
+        float sacc = 0.f;
+        for (int pz = 0; pz < kThreads / NC; ++pz) sacc += red[pz * NC + tid];
+        part[c0 * 16 + 16 + 16 * NC + tid] = sacc;
     }
 }
 

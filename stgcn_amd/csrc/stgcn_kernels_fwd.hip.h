@@ -16,7 +16,7 @@ namespace stgcn {
 // ================================================================================================
 enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5,
                 PK_LIN_FWD = 6, PK_LIN_BWD = 7,
-                PK_TCONV_DENSE = 8 };   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
+                PK_TCONV_DENSE = 8, PK_ALIGN_DENSE = 9 };   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
 
 struct PackJob {
     int kind;
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     } else if (j.kind == PK_TCONV_DENSE) {
         const int kidx = e / NC, o = e - kidx * NC;
         if (kidx < j.Kt * j.Cin) v = tconv_weff(j, kidx / j.Cin, kidx % j.Cin, o);
+    } else if (j.kind == PK_ALIGN_DENSE) {   // Wa[i][jj] row major, i < Cin (= c0), jj < Cout (= c1)
+        const int i = e / j.Cout, jj = e - i * j.Cout;
+        v = (j.Cin > j.Cout) ? j.w[(size_t)jj * j.Cin + i] : (i == jj ? 1.f : 0.f);
     } else {
         const int s = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
         const int kc = rest % j.KCH, nt = rest / j.KCH;

@@ -199,6 +199,7 @@ struct AdamwArgs {
     int start[kAdamwMaxTensors + 1];
     int count;
     float lr, b1, b2, eps, wd;
+    float lb1, lb2;       // log(beta1), log(beta2) computed in double on the host
     long step;
     const long* step_dev;
     const float* lr_dev;
@@ -209,10 +210,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
     while (jb + 1 < a.count && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
     const AdamwTensor& T = a.t[jb];
     const long base = ((long)blockIdx.x - a.start[jb]) * kAdamwChunk;
-    const double t = (double)(a.step_dev ? *a.step_dev : a.step);
+    // bias corrections 1 - beta^t: -expm1f(t * log(beta)) keeps full relative accuracy for small t (a double-precision
+    // pow() here is a multi-microsecond serial latency chain in every thread of a kernel that moves only 1 MB)
+    const float t = (float)(a.step_dev ? *a.step_dev : a.step);
     const float lr = a.lr_dev ? *a.lr_dev : a.lr;
-    const float bc1 = (float)(1.0 - pow((double)a.b1, t));
-    const float rs2 = (float)(1.0 / sqrt(1.0 - pow((double)a.b2, t)));
+    const float bc1 = -expm1f(t * a.lb1);
+    const float rs2 = rsqrtf(-expm1f(t * a.lb2));
     const float decay = 1.0f - lr * a.wd, step_size = lr / bc1;
 #pragma unroll
     for (int k = 0; k < kAdamwChunk / kThreads; ++k) {

@@ -147,6 +147,7 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) { (vo
 
 #define __expf(x) expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

@@ -91,7 +91,8 @@ def run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None
     dA, _, _ = st.gconv_bwd(dG, sv["G"], sv["Xs"], g64, sv["Wk"])
     err["bwd.dA"] = rel(ws[plan.ws_dA:plan.ws_dA + dA.size].reshape(dA.shape), dA)
     dZ1 = st.gate_bwd(dA @ sv["Wa"].T, sv["U1"], sv["S1"], act)
-    err["bwd.dZ1"] = rel(ws[plan.ws_dZ1:plan.ws_dZ1 + dZ1.size].reshape(dZ1.shape), dZ1)
+    if not (plan.thin_tc1 and c_in == 1):      # the thin first layer keeps dZ1 on chip unless dx is needed
+        err["bwd.dZ1"] = rel(ws[plan.ws_dZ1:plan.ws_dZ1 + dZ1.size].reshape(dZ1.shape), dZ1)
     if c_in > 1:
         err["bwd.dx"] = rel(cl(x.grad.cpu().numpy()), dx_ref)
     for name, prm in zip(_lib.PARAM_FIELDS, params):

@@ -16,6 +16,7 @@ CASES = [
     (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5, True),
     (32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False),
     (128, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 10, 1, 5, True),
+    (4, (64, 16, 64), 3, 3, "cheb_graph_conv", "gtu", 10, 1, 6, False),     # thin first layer (K = 12) WITH an input gradient
 ]
 
 
@@ -71,8 +72,9 @@ def test_block_backward(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
     got = ws[plan.ws_dA:plan.ws_dA + dA.size].reshape(dA.shape)
     assert np.abs(got - dA).max() < 1e-4 * max(1.0, np.abs(dA).max()), "dA"
     dZ1 = st.gate_bwd(dA @ sv["Wa"].T, sv["U1"], sv["S1"], act)
-    got = ws[plan.ws_dZ1:plan.ws_dZ1 + dZ1.size].reshape(dZ1.shape)
-    assert np.abs(got - dZ1).max() < 1e-4 * max(1.0, np.abs(dZ1).max()), "dZ1"
+    if not (plan.thin_tc1 and c_in == 1):      # the thin first layer keeps dZ1 on chip unless dx is needed
+        got = ws[plan.ws_dZ1:plan.ws_dZ1 + dZ1.size].reshape(dZ1.shape)
+        assert np.abs(got - dZ1).max() < 1e-4 * max(1.0, np.abs(dZ1).max()), "dZ1"
 
     # ---- outputs -----------------------------------------------------------------------------------------
     if c_in > 1:

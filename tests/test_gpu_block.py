@@ -16,6 +16,7 @@ SMALL = [
     (128, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 10, 1, 5, True),
     (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 1, 1, 5, True),        # single vertex
     (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 300, 1, 5, False),      # 19 node tiles (MAXQ 6 path), ragged rows
+    (4, (64, 16, 64), 3, 3, "cheb_graph_conv", "gtu", 33, 2, 6, True),        # thin first layer (K = 12) with an input gradient
 ]
 
 
