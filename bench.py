@@ -119,6 +119,21 @@ def cpu_baseline(gso_np, budget_s=20.0):
             "sample": f"{n} steps of bs {B_LOCAL} (C2 shapes, dropout on, AdamW) in {el:.1f} s, torch CPU oracle, {cores} of {ncpu} host threads"}
 
 
+def pmc_traffic(label):
+    """HBM-side bytes per launch of ``label`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command:
+    counters cannot be sampled from inside the process being timed).  None when no summary covers the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))["per_launch"].get(label)
+        except (OSError, ValueError, KeyError):
+            continue
+        if rec:
+            return int(rec["hbm_bytes"]), os.path.basename(path)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +229,7 @@ def main():
            "config": {"workload": "C2: METR-LA 207 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=32 per GPU, fp32, "
                                   "dropout 0.5, AdamW lr 1e-3 wd 1e-3; full step zero_grad+fwd+MSE+bwd+opt",
                       "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
-                      "output_block": "stock PyTorch-ROCm ops (not yet fused)", "final_loss": round(loss_val, 5),
+                      "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
                       "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err}}
 
     if rank == 0 and not args.no_profile:
@@ -239,8 +254,10 @@ def main():
         dur_ms = prof[dom]["total_ms"] / prof[dom]["calls"]
         ach = flops[dom] / calls_per_step / (dur_ms * 1e-3) / 1e12
         tot_ms = sum(v for k, v in per_step.items() if not k.startswith(("head.", "adamw")))
+        traffic, traffic_src = pmc_traffic(dom)
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                           "traffic_source": traffic_src,
                            "avg_launch_us": round(dur_ms * 1e3, 2), "flops_per_launch": int(flops[dom] / calls_per_step),
                            "stblock_kernels_ms_per_step": round(tot_ms, 4), "all_kernels_ms_per_step": round(sum(per_step.values()), 4),
                            "stblock_fwd_bwd_frac": round(sum(flops.values()) / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -58,9 +58,20 @@ inline void prof_end(int i, hipStream_t st) {
     if (i >= 0) hipEventRecord(g_prof[i].e1, st);
 }
 
+// STGCN_LAUNCH_LOG=<file>: one line "label@tag <kernel> <workgroups> <threads>" per launch, so that an external profile
+// (rocprofv3 counters are keyed by kernel symbol + grid) can be joined with the library's labels (tools/pmc_traffic.py)
+inline void launch_log(const char* label, const char* kernel, dim3 grid, dim3 block) {
+    static FILE* f = getenv("STGCN_LAUNCH_LOG") ? fopen(getenv("STGCN_LAUNCH_LOG"), "w") : nullptr;
+    if (f) {
+        fprintf(f, "%s@%d\t%s\t%u\t%u\n", label, g_prof_tag, kernel, grid.x * grid.y * grid.z, block.x * block.y * block.z);
+        fflush(f);
+    }
+}
+
 // every kernel launch of the library goes through this macro
 #define STGCN_LAUNCH(label, st, kernel, grid, block, lds, ...)                                    \
     do {                                                                                          \
+        launch_log(label, #kernel, grid, block);                                                  \
         const int pi_ = prof_begin(label, st);                                                    \
         hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                            \
         prof_end(pi_, st);                                                                        \
@@ -172,10 +183,11 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
     // 64-row tiles / 8 waves are kept selectable (STGCN_TCONV_TR=64) for larger problems.
     static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;   // tuning knob
     const bool small = force_tr ? force_tr == 32 : true;
-    const bool tiny = !force_tr && cdiv(a.ts.rows, 32) < 256;     // fewer than one 32-row tile per CU: 16-row tiles
+    const bool tiny = force_tr == 16 || (!force_tr && cdiv(a.ts.rows, 32) < 256);     // fewer than one 32-row tile per CU: 16-row tiles
     const int tr = tiny ? 16 : (small ? 32 : kTileRows);
     const dim3 grid(cdiv(a.ts.rows, tr));
-    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
+    static const size_t lds_pad = getenv("STGCN_LDS_PAD") ? (size_t)atoi(getenv("STGCN_LDS_PAD")) : 0;   // occupancy experiments
+    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float) + lds_pad;
     if (tiny) {
         if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 1, 4>), grid, dim3(256), lds, a);
         else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 1, 4>), grid, dim3(256), lds, a);
@@ -207,7 +219,8 @@ int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
 
 int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
     const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
-    const size_t lds = kTileLdsFloats * sizeof(float);
+    static const size_t lds_pad = getenv("STGCN_LDS_PAD_BWD") ? (size_t)atoi(getenv("STGCN_LDS_PAD_BWD")) : 0;   // occupancy experiments
+    const size_t lds = kTileLdsFloats * sizeof(float) + lds_pad;
     if (ntt == 1) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, a);
     else if (ntt == 2) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, a);
     else if (ntt == 4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 0, 8>), grid, dim3(512), lds, a);

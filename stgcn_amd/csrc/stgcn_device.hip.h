@@ -41,6 +41,22 @@ __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
 }
+// XCD-aware work placement (speed only, never correctness): workgroup b is observed to run on XCD b % 8 and every XCD
+// has its own L2, so work items that re-read the same rows (the Kt taps of neighbouring time steps, the m-chunks of a
+// weight-gradient row chunk) are given to ONE XCD as a contiguous range: workgroup b of n takes item
+// start(b % 8) + b / 8, where XCD x owns n/8 (+1 if x < n % 8) consecutive items.
+#ifndef STGCN_XCD_MAP
+#define STGCN_XCD_MAP 1
+#endif
+__device__ __forceinline__ int xcd_item(int b, int n) {
+#if STGCN_XCD_MAP
+    const int x = b & 7, per = n >> 3, rem = n & 7;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+#else
+    return b;
+#endif
+}
+
 // v_exp_f32 + v_rcp_f32 (1 ulp each): a full-precision IEEE divide costs ~10 instructions per element in the epilogues
 __device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 

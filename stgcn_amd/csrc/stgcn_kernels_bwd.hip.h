@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_bwd_data_kernel(TconvBwdData
     int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
     const int wv = threadIdx.x >> 6, wave = wv & 3, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)blockIdx.x * kTileRows;
+    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * kTileRows;
     const int mt0 = LAYOUT == 0 ? (wv >> 2) * WM : (LAYOUT == 1 ? wave : 2 * (wave >> 1));
     const int nt0 = LAYOUT == 0 ? wave : (LAYOUT == 1 ? 0 : (wave & 1));
 
@@ -817,7 +817,9 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
     const int NC = a.NC, LDZ = NC + 4;
     float* ct = stgcn_smem;              // [SR][LDC]
     float* zt = stgcn_smem + SR * LDC;   // [SR][LDZ]
-    const int chunk = blockIdx.x, mchunk = blockIdx.y, m0 = mchunk * MC;
+    // the m-chunks of one row chunk re-read the same dZ rows: keep them adjacent on one XCD (xcd_item)
+    const int item = xcd_item((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int chunk = item / (int)gridDim.y, mchunk = item % (int)gridDim.y, m0 = mchunk * MC;
     const long crow0 = (long)chunk * a.rows_per_chunk;
     long crow1 = crow0 + a.rows_per_chunk;
     if (crow1 > a.ts.rows) crow1 = a.ts.rows;

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
     int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
     const int wv = threadIdx.x >> 6, wave = wv & 3, mt0 = (wv >> 2) * WM, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)blockIdx.x * TR;
+    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
 
     STGCN_PHASE(1, 0);
     stagger_start();

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)blockIdx.x * TR;
+    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
     tile_rowinfo<TR>(a.ts, row0, rowbase, rowt);
     __syncthreads();
     const int KP = a.KCH * 16;   // = c0 <= 128: one segment

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = "/tmp/libstgcn_phase.so"
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", '-DSTGCN_BACKEND_NAME="hip-gfx950"',
-                "-DSTGCN_PHASE_TIMING", os.path.join(ROOT, "stgcn_amd/csrc/stgcn_capi.hip"), "-o", LIB], check=True)
+                "-DSTGCN_PHASE_TIMING", *os.environ.get("STGCN_EXTRA_FLAGS", "").split(), os.path.join(ROOT, "stgcn_amd/csrc/stgcn_capi.hip"), "-o", LIB], check=True)
 os.environ["STGCN_AMD_LIB"] = LIB
 from stgcn_amd import _lib, ops  # noqa: E402
 from tests.emu_util import block_case, params_in_field_order  # noqa: E402
@@ -72,7 +72,9 @@ def report(kid, which, go):
 
 go1 = run_block(64, 8)
 go0 = run_block(1, 12)
-for kid in (1, 2, 3, 4, 6):
+KIDS = [int(k) for k in os.environ.get("STGCN_PHASE_KIDS", "1,2,3,4,6").split(",")]
+for kid in KIDS:
     report(kid, "blk1", go1)
-for kid in (1, 3, 6):
-    report(kid, "blk0", go0)
+for kid in KIDS:
+    if kid in (1, 3, 4, 6):
+        report(kid, "blk0", go0)

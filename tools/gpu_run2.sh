@@ -22,12 +22,13 @@ BENCH="python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-profil
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o trace -- $BENCH > $OUT/rocprof_trace.log 2>&1; echo "trace exit $?"
 python $REPO/tools/rocpd_summary.py /tmp/prof/trace_results.db > $OUT/kernel_stats.md 2>&1
 if [ "${2:-pmc}" = "pmc" ]; then
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/prof -o pmc_sq -- $BENCH > $OUT/rocprof_pmc_sq.log 2>&1; echo "pmc sq exit $?"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d /tmp/prof -o pmc_sq -- $BENCH > $OUT/rocprof_pmc_sq.log 2>&1; echo "pmc sq exit $?"
 python $REPO/tools/rocpd_pmc_summary.py /tmp/prof/pmc_sq_results.db > $OUT/pmc_sq.md 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o pmc_fetch -- $BENCH > $OUT/rocprof_pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
+timeout 300 env STGCN_LAUNCH_LOG=/tmp/prof/launch.log rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o pmc_fetch -- $BENCH > $OUT/rocprof_pmc_fetch.log 2>&1; echo "pmc fetch exit $?"
 python $REPO/tools/rocpd_pmc_summary.py /tmp/prof/pmc_fetch_results.db > $OUT/pmc_fetch.md 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof -o pmc_write -- $BENCH > $OUT/rocprof_pmc_write.log 2>&1; echo "pmc write exit $?"
 python $REPO/tools/rocpd_pmc_summary.py /tmp/prof/pmc_write_results.db > $OUT/pmc_write.md 2>&1
+python $REPO/tools/pmc_traffic.py /tmp/prof/pmc_fetch_results.db /tmp/prof/pmc_write_results.db /tmp/prof/launch.log > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
 fi
 head -30 $OUT/pmc_sq.md 2>/dev/null | cut -c1-400
 du -sh $OUT
