@@ -63,14 +63,17 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
-    g.al_wgs = (int)(tiles1 < 1024 ? tiles1 : 1024);   // 23.5 KB of LDS each: several per CU for latency hiding
+    g.thin = (Kt * c_in <= 16 && c0 == 64 && c1 == 16) ? 1 : 0;
+    // grid-stride workgroups of align_gate_bwd (23.5 KB of LDS each: several per CU for latency hiding).  The thin
+    // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there (measured).
+    const int al_cap = g.thin ? 512 : 1024;
+    g.al_wgs = (int)(tiles1 < al_cap ? tiles1 : al_cap);
     long o = 0;
     auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };
     g.off_ln_g = take((long)g.ln_sg * n);
     g.off_ln_b = take((long)g.ln_sg * n);
     g.gc_stride = (terms + 1) * 256;
     g.off_gc = take(slabs1 * g.gc_stride);
-    g.thin = (Kt * c_in <= 16 && c0 == 64 && c1 == 16) ? 1 : 0;
     g.al_stride = c0 * c1 + c1 + (g.thin ? 16 * 2 * c0 + 2 * c0 : 0);
     g.off_al = take((long)g.al_wgs * g.al_stride);
     g.w1 = wgrad_geom(rows1, Kt * c_in, 2 * c0, 0);
@@ -974,58 +977,85 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
 // Final deterministic reduction of the partials into gradients laid out like the reference's parameters.
 // A job enumerates a 3-D index (d0, d1, d2), d2 fastest and contiguous in the SOURCE (coalesced reads):
 //     dst[d0*t0 + d1*t1 + d2*t2] = sum_p src[p*pstride + d0*s0 + d1*s1 + d2*s2]
-// A workgroup owns 32 consecutive elements; its 8 slices (tid >> 5) walk the partials p = slice, slice+8, ..
-// and are combined through LDS in a fixed order (bitwise reproducible).
+// A workgroup owns 256/slices consecutive element GROUPS (a group = 4 consecutive d2 when the job's strides allow 16-byte
+// loads, else 1 element); its slices (8, or 32 for jobs with >= 128 partials: the walk over p is a serial latency chain)
+// take the partials p = slice, slice+slices, .. and are combined through LDS in a fixed order (bitwise reproducible).
 // ================================================================================================
 struct ReduceJob {
     const float* src;
     float* dst;
     int P;
+    int vec;      // 1: n2, pstride, s0, s1 are multiples of 4 and src is 16-byte aligned
+    int slices;   // 8 or 32
     long pstride;
     int n0, n1, n2;
     long s0, s1, s2;
     long t0, t1, t2;
 };
 constexpr int kMaxReduceJobs = 16;
-constexpr int kReduceElems = 32, kReduceSlices = kThreads / kReduceElems;
 struct ReduceArgs {
     ReduceJob job[kMaxReduceJobs];
     int start[kMaxReduceJobs + 1];
     int njobs;
 };
+// host: classify the job and return its workgroup count
+inline int reduce_job_setup(ReduceJob& j) {
+    j.vec = (j.n2 % 4 == 0 && j.s2 == 1 && j.pstride % 4 == 0 && j.s0 % 4 == 0 && j.s1 % 4 == 0 &&
+             (reinterpret_cast<uintptr_t>(j.src) & 15) == 0) ? 1 : 0;
+    j.slices = j.P >= 128 ? 32 : 8;
+    const long n = (long)j.n0 * j.n1 * j.n2, per = (long)(kThreads / j.slices) * (j.vec ? 4 : 1);
+    return (int)((n + per - 1) / per);
+}
 
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
-    extern __shared__ float stgcn_smem[];
+    extern __shared__ float stgcn_smem[];   // [slices][32] float4
     int jb = 0;
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
     const ReduceJob& j = a.job[jb];
-    const int el = threadIdx.x & (kReduceElems - 1), sl = threadIdx.x >> 5;
-    const long e = ((long)blockIdx.x - a.start[jb]) * kReduceElems + el;
+    const int kReduceSlices = j.slices, kReduceElems = kThreads / kReduceSlices;
+    const int el = threadIdx.x % kReduceElems, sl = threadIdx.x / kReduceElems;
+    const int W = j.vec ? 4 : 1;
+    const long e = (((long)blockIdx.x - a.start[jb]) * kReduceElems + el) * W;   // first element of this thread's group
     const long n = (long)j.n0 * j.n1 * j.n2;
-    float acc = 0.f;
+    f32x4 acc = zero4();
     long doff = 0;
     if (e < n) {
         const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
         const float* s = j.src + d0 * j.s0 + d1 * j.s1 + d2 * j.s2;
         doff = d0 * j.t0 + d1 * j.t1 + d2 * j.t2;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // 4 loads in flight per thread
         int p = sl;
-        for (; p + 3 * kReduceSlices < j.P; p += 4 * kReduceSlices) {
-            a0 += s[(size_t)p * j.pstride];
-            a1 += s[(size_t)(p + kReduceSlices) * j.pstride];
-            a2 += s[(size_t)(p + 2 * kReduceSlices) * j.pstride];
-            a3 += s[(size_t)(p + 3 * kReduceSlices) * j.pstride];
+        if (j.vec) {
+            f32x4 a0 = zero4(), a1 = zero4(), a2 = zero4(), a3 = zero4();   // 4 x 16 B in flight per thread
+            for (; p + 3 * kReduceSlices < j.P; p += 4 * kReduceSlices) {
+                a0 += ld4(s + (size_t)p * j.pstride);
+                a1 += ld4(s + (size_t)(p + kReduceSlices) * j.pstride);
+                a2 += ld4(s + (size_t)(p + 2 * kReduceSlices) * j.pstride);
+                a3 += ld4(s + (size_t)(p + 3 * kReduceSlices) * j.pstride);
+            }
+            for (; p < j.P; p += kReduceSlices) a0 += ld4(s + (size_t)p * j.pstride);
+            acc = (a0 + a1) + (a2 + a3);
+        } else {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (; p + 3 * kReduceSlices < j.P; p += 4 * kReduceSlices) {
+                a0 += s[(size_t)p * j.pstride];
+                a1 += s[(size_t)(p + kReduceSlices) * j.pstride];
+                a2 += s[(size_t)(p + 2 * kReduceSlices) * j.pstride];
+                a3 += s[(size_t)(p + 3 * kReduceSlices) * j.pstride];
+            }
+            for (; p < j.P; p += kReduceSlices) a0 += s[(size_t)p * j.pstride];
+            acc[0] = (a0 + a1) + (a2 + a3);
         }
-        for (; p < j.P; p += kReduceSlices) a0 += s[(size_t)p * j.pstride];
-        acc = (a0 + a1) + (a2 + a3);
     }
-    stgcn_smem[sl * kReduceElems + el] = acc;
+    st4(stgcn_smem + (sl * kReduceElems + el) * 4, acc);
     __syncthreads();
     if (sl == 0 && e < n) {
-        float t = 0.f;
+        f32x4 t = zero4();
+        for (int k = 0; k < kReduceSlices; ++k) t += ld4(stgcn_smem + (k * kReduceElems + el) * 4);
+        j.dst[doff] = t[0];
+        if (j.vec) {
 #pragma unroll
-        for (int k = 0; k < kReduceSlices; ++k) t += stgcn_smem[k * kReduceElems + el];
-        j.dst[doff] = t;
+            for (int i = 1; i < 4; ++i) j.dst[doff + i * j.t2] = t[i];
+        }
     }
 }
 

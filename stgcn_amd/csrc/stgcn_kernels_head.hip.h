@@ -193,7 +193,7 @@ struct AdamwTensor {
     long n;
 };
 constexpr int kAdamwMaxTensors = 48;
-constexpr int kAdamwChunk = 2048;
+constexpr int kAdamwChunk = 512;    // small chunks: ~500 workgroups for the 245 K parameters (the kernel is pure latency)
 struct AdamwArgs {
     AdamwTensor t[kAdamwMaxTensors];
     int start[kAdamwMaxTensors + 1];

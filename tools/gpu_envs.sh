@@ -15,6 +15,6 @@ for l in open(sys.argv[1]):
     d=json.loads(l)
     if 'kernel_profile' in d:
         kp=d['kernel_profile']
-        print("[%s]" % sys.argv[2], "sum_us", d['sum_us'], " ".join(f"{k}={v['us_per_step']:.1f}" for k,v in sorted(kp.items()) if 'tconv_fwd' in k or 'bwd_data' in k))
+        print("[%s]" % sys.argv[2], "sum_us", d['sum_us'], " ".join(f"{k}={v['us_per_step']:.1f}" for k,v in sorted(kp.items()) if __import__('re').search(__import__('os').environ.get('KFILTER', 'tconv_fwd|bwd_data'), k)))
 PY
 done
