@@ -204,16 +204,19 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
     return STGCN_OK;
 }
 
-constexpr int kGcWaves = 8;   // graph-conv workgroups: 8 waves (2 per SIMD)
+// graph-conv workgroups: one wave per 16-node tile up to 16 tiles (13 waves for 207 nodes: measured 10% faster than 8 waves
+// x 2 tiles), 8 waves x up to 4 tiles beyond
+inline int gc_waves(int HT) { return HT > 16 ? 8 : (HT < 4 ? 4 : HT); }
 
 int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, maxq = (HT + kGcWaves - 1) / kGcWaves;
+    const int HT = a.NP / 16, waves = gc_waves(HT), maxq = (HT + waves - 1) / waves;
     const size_t lds = (size_t)3 * 16 * (a.NP + 4) * sizeof(float);
-    const dim3 grid((unsigned)a.slabs), blk(kGcWaves * 64);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, kGcWaves>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, kGcWaves>), grid, blk, lds, a);
-    else if (maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, kGcWaves>), grid, blk, lds, a);
-    else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, kGcWaves>), grid, blk, lds, a);
+    const dim3 grid((unsigned)a.slabs), blk(waves * 64);
+    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, 16>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, 8>), grid, blk, lds, a);
+    else if (maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, 8>), grid, blk, lds, a);
+    else if (maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, 8>), grid, blk, lds, a);
+    else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
 
@@ -230,24 +233,29 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
 }
 
 int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, maxq = (HT + kGcWaves - 1) / kGcWaves;
+    const int HT = a.NP / 16, waves = gc_waves(HT), maxq = (HT + waves - 1) / waves;
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
-    const dim3 grid((unsigned)a.slabs), blk(kGcWaves * 64);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, kGcWaves>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, kGcWaves>), grid, blk, lds, a);
-    else if (maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, kGcWaves>), grid, blk, lds, a);
-    else STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, kGcWaves>), grid, blk, lds, a);
+    const dim3 grid((unsigned)a.slabs), blk(waves * 64);
+    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, 16>), grid, blk, lds, a);
+    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, 8>), grid, blk, lds, a);
+    else if (maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, 8>), grid, blk, lds, a);
+    else if (maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, 8>), grid, blk, lds, a);
+    else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
 
 template <int MTW>
 int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
-    const dim3 grid(w.chunks, w.mchunks), blk(kThreads);
-    size_t lds = (size_t)kWgradStepRows * ((MTW * 16 + 4) + (a.NC + 4)) * sizeof(float);
-    if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
-    if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2>), grid, blk, lds, a);
-    else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4>), grid, blk, lds, a);
+    const dim3 grid(w.chunks, w.mchunks), blk(kThreads * kWgradGroups);
+    const bool vec = (a.ts.C & 3) == 0;   // 16-byte im2col loads
+    if (a.NC == 128) {
+        if (vec) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, true>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
+        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, false>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
+    } else {
+        if (vec) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, true>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
+        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, false>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
+    }
     return STGCN_OK;
 }
 int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {

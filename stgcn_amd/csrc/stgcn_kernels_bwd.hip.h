@@ -369,9 +369,9 @@ struct GconvBwdArgs {
     long slabs;
 };
 
-template <int MAXQ, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
-    constexpr int THREADS = WAVES * 64;
+template <int MAXQ, int MAXW>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)
+__global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
+    const int THREADS = blockDim.x, WAVES = THREADS >> 6;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const long slab = blockIdx.x;
@@ -796,30 +796,44 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
 // ================================================================================================
 // B6: weight gradient of a temporal convolution
 //     dW_eff[k*Cin + i][o] = sum_rows x[row + k*N][i] dZ[row][o]      db_eff[o] = sum_rows dZ[row][o]
-// grid = (row chunks, m chunks); the reduction over rows runs in 16-row steps through LDS with the next
-// step's global loads in flight (register prefetch).  Output: per-chunk partials.
-// wave w owns n-tiles w*NTW .. w*NTW+NTW-1 (NTW = NC/64) of all MTW m-tiles of this m-chunk.
+// grid = (row chunks, m chunks).  The reduction over a chunk's rows runs in SR-row steps through LDS with the next
+// step's global loads in flight (register prefetch).  The problem only offers ~one workgroup per CU (more row chunks
+// would mean more partials), and one wave per SIMD cannot hide the load latency of a step behind its 3 K cycles of
+// MFMAs, so a workgroup carries GROUPS independent wave groups (4 waves each, own LDS tiles, own prefetch): group q
+// reduces steps q, q+GROUPS, ...; the groups' accumulators are summed through LDS in a fixed order at the end.
+// Within a group wave w owns n-tiles w*NTW .. w*NTW+NTW-1 (NTW = NC/64) of all MTW m-tiles of this m-chunk.
+// Output: per-chunk partials.
 // ================================================================================================
-#ifndef STGCN_WGRAD_SR
-#define STGCN_WGRAD_SR 64
+#ifndef STGCN_WGRAD_GROUPS
+#define STGCN_WGRAD_GROUPS 2
 #endif
-constexpr int kWgradStepRows = STGCN_WGRAD_SR;   // rows reduced per barrier interval (build-time tunable)
+constexpr int kWgradGroups = STGCN_WGRAD_GROUPS;
 struct TconvBwdWeightArgs {
     TapSrc ts;           // x viewed through Kt taps (dir = +1): implicit [rows][K = Kt*Cin]
     const float* dZ;     // [rows][NC]
     float* part;         // [chunks][Mpad*NC] ++ [chunks][NC]
     int NC, Mpad, rows_per_chunk, chunks;
 };
+// rows reduced per barrier interval: 64, or 32 where GROUPS tile sets of 64 rows would not fit the LDS
+constexpr int wgrad_step_rows(int MTW, int NTW) {
+    return (size_t)kWgradGroups * 64 * ((MTW * 16 + 4) + (NTW * 64 + 4)) * sizeof(float) <= 156 * 1024 ? 64 : 32;
+}
+constexpr size_t wgrad_lds_bytes(int MTW, int NTW) {
+    return (size_t)kWgradGroups * wgrad_step_rows(MTW, NTW) * ((MTW * 16 + 4) + (NTW * 64 + 4)) * sizeof(float);
+}
 
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
+// VEC: the input channel count is a multiple of 4 (16-byte im2col loads); otherwise scalar loads (narrow first layer).
+template <int MTW, int NTW, bool VEC>
+__global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
     extern __shared__ float stgcn_smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    constexpr int SR = kWgradStepRows;   // rows reduced per barrier interval
+    constexpr int GROUPS = kWgradGroups;
+    constexpr int SR = wgrad_step_rows(MTW, NTW);
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;   // wave group, thread within the group
+    const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     constexpr int MC = MTW * 16, LDC = MC + 4;
-    const int NC = a.NC, LDZ = NC + 4;
-    float* ct = stgcn_smem;              // [SR][LDC]
-    float* zt = stgcn_smem + SR * LDC;   // [SR][LDZ]
+    constexpr int NC = NTW * 64, LDZ = NC + 4;
+    float* ct = stgcn_smem + grp * (SR * LDC + SR * LDZ);   // [SR][LDC]
+    float* zt = ct + SR * LDC;                               // [SR][LDZ]
     // the m-chunks of one row chunk re-read the same dZ rows: keep them adjacent on one XCD (xcd_item)
     const int item = xcd_item((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
     const int chunk = item / (int)gridDim.y, mchunk = item % (int)gridDim.y, m0 = mchunk * MC;
@@ -827,19 +841,19 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
     long crow1 = crow0 + a.rows_per_chunk;
     if (crow1 > a.ts.rows) crow1 = a.ts.rows;
     const int nsteps = (int)((crow1 - crow0 + SR - 1) / SR);
+    const int nit = (nsteps + GROUPS - 1) / GROUPS;   // barrier intervals (the same for every group)
     const int K = a.ts.taps * a.ts.C;
-    const bool vec = (a.ts.C & 3) == 0;
     const long per_b = (long)a.ts.Tdst * a.ts.N;
 
     // staging registers (next step's tiles are fetched while the current step's MFMAs run)
     constexpr int NCR = (SR * (MC / 4) + kThreads - 1) / kThreads;   // float4 of the im2col tile per thread (vector path)
-    constexpr int NCS = (SR * MC + kThreads - 1) / kThreads;         // scalars per thread (narrow-input path, MC == 16)
-    constexpr int NCV = NCR > NCS ? NCR : NCS;
+    constexpr int NCS = (SR * MC + kThreads - 1) / kThreads;         // scalars per thread (narrow-input path)
     constexpr int NZ = SR * NTW * 16 / kThreads;                      // SR * NC / 4 / 256 with NC = 64 * NTW
-    f32x4 creg[NCV], zreg[NZ];
+    f32x4 creg[VEC ? NCR : 1], zreg[NZ];
+    float cs[VEC ? 1 : NCS];
     auto load_regs = [&](int step) {
         const long r0 = crow0 + (long)step * SR;
-        if (vec) {
+        if constexpr (VEC) {
 #pragma unroll
             for (int i = 0; i < NCR; ++i) {
                 const int idx = tid + i * kThreads;
@@ -873,8 +887,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
                         v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
                     }
                 }
-                creg[i] = zero4();
-                creg[i][0] = v;
+                cs[i] = v;
             }
         }
 #pragma unroll
@@ -886,7 +899,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
         }
     };
     auto store_regs = [&]() {
-        if (vec) {
+        if constexpr (VEC) {
 #pragma unroll
             for (int i = 0; i < NCR; ++i) {
                 const int idx = tid + i * kThreads;
@@ -898,7 +911,7 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
             for (int i = 0; i < NCS; ++i) {
                 const int idx = tid + i * kThreads;
                 const int r = idx / MC, q = idx - r * MC;
-                if (r < SR) ct[r * LDC + q] = creg[i][0];
+                if (r < SR) ct[r * LDC + q] = cs[i];
             }
         }
 #pragma unroll
@@ -915,18 +928,23 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = zero4();
     // bias partial: NC columns, tpc = 256 / NC threads per column (NC = 128 -> 2, NC = 256 -> 1)
-    const int tpc = kThreads / NC, bcol = tid % NC, bpart = tid / NC, rpt = SR / tpc;
+    constexpr int tpc = kThreads / NC, rpt = SR / tpc;
+    const int bcol = tid % NC, bpart = tid / NC;
     float bsum = 0.f;
 
     STGCN_PHASE(3, 0);
-    if (nsteps > 0) load_regs(0);
+    if (grp < nsteps) load_regs(grp);
     STGCN_PHASE(3, 1);
-    for (int step = 0; step < nsteps; ++step) {
-        if (step > 0) __syncthreads();   // previous step's tiles consumed
-        store_regs();
+    for (int it = 0; it < nit; ++it) {
+        const int step = it * GROUPS + grp;
+        const bool active = step < nsteps;   // uniform per wave group
+        if (it > 0) __syncthreads();   // previous step's tiles consumed
+        if (active) store_regs();
         __syncthreads();
-        if (step + 1 < nsteps) load_regs(step + 1);
+        if (!active) continue;
+        if (step + GROUPS < nsteps) load_regs(step + GROUPS);
         if (mchunk == 0) {
+#pragma unroll 4
             for (int r = 0; r < rpt; ++r) bsum += zt[(bpart * rpt + r) * LDZ + bcol];
         }
         // A[m = l15][kk = g] = ct[row][m], B[kk = g][o = l15] = zt[row][o] with row = 16*k16 + 4g + s: lanes with
@@ -949,21 +967,46 @@ __global__ __launch_bounds__(256) void tconv_bwd_weight_kernel(TconvBwdWeightArg
         }
     }
     STGCN_PHASE(3, 2);
+    // ---- combine the wave groups (fixed order: group 0 + group 1 + ...) ----------------------------------------
+    if (GROUPS > 1) {
+        float* xb = stgcn_smem;   // [MTW*NTW][256] float4 + [256] floats; fits the tile area for every instantiation
+        for (int q = 1; q < GROUPS; ++q) {
+            __syncthreads();   // tiles (or the previous exchange) consumed
+            if (grp == q) {
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) st4(xb + ((i * NTW + j) * kThreads + tid) * 4, acc[i][j]);
+                xb[MTW * NTW * kThreads * 4 + tid] = bsum;
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[i][j] += ld4(xb + ((i * NTW + j) * kThreads + tid) * 4);
+                bsum += xb[MTW * NTW * kThreads * 4 + tid];
+            }
+        }
+    }
     float* part = a.part + (size_t)chunk * a.Mpad * NC;
+    if (grp == 0) {
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(size_t)(m0 + i * 16 + 4 * g + r) * NC + (wave * NTW + j) * 16 + l15] = acc[i][j][r];
-    if (mchunk == 0) {
+                for (int r = 0; r < 4; ++r) part[(size_t)(m0 + i * 16 + 4 * g + r) * NC + (wave * NTW + j) * 16 + l15] = acc[i][j][r];
+    }
+    if (mchunk == 0) {   // uniform per workgroup
         float* bp = a.part + (size_t)a.chunks * a.Mpad * NC + (size_t)chunk * NC;
-        if (tpc == 1) bp[bcol] = bsum;
-        else {
+        if (tpc == 1) {
+            if (grp == 0) bp[bcol] = bsum;
+        } else {
             __syncthreads();
-            stgcn_smem[tid] = bsum;
+            if (grp == 0) stgcn_smem[tid] = bsum;
             __syncthreads();
-            if (tid < NC) {
+            if (grp == 0 && tid < NC) {
                 float s = 0.f;
                 for (int p = 0; p < tpc; ++p) s += stgcn_smem[p * NC + tid];
                 bp[tid] = s;

@@ -490,9 +490,11 @@ struct GconvFwdArgs {
     long slabs;
 };
 
-template <int MAXQ, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
-    constexpr int THREADS = WAVES * 64;
+// The wave count is a launch parameter (blockDim.x / 64 <= MAXW): one wave per node tile up to 16 tiles (MAXQ = 1, e.g.
+// 13 waves for the 207-node graph: measured faster than 8 waves x 2 tiles), 8 waves x MAXQ tiles beyond.
+template <int MAXQ, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
+    const int THREADS = blockDim.x, WAVES = THREADS >> 6;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const long slab = blockIdx.x;
