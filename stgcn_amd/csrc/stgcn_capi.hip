@@ -138,6 +138,32 @@ uint32_t drop_thresh(float p) {
     if (t < 0.0) t = 0.0;
     return (uint32_t)t;
 }
+// ---- residency: how many workgroups of a kernel the whole device holds at once ----------------------------------
+// The problem sizes of this path give every launch only a few workgroups per CU and all of them start together, so a
+// launch costs (rounds of resident workgroups) x (latency chain of one workgroup): 2070 tiles on 2048 slots run as
+// long as 4096 would.  Launchers therefore pick the tile size / kernel variant whose grid fits ONE round.
+template <typename K>
+int wg_capacity(K kernel, int threads, size_t lds) {
+    struct Entry { const void* k; int threads; size_t lds; int cap; };
+    static Entry cache[64];
+    static int n = 0;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < n; ++i)
+        if (cache[i].k == key && cache[i].threads == threads && cache[i].lds == lds) return cache[i].cap;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess || nb <= 0) nb = 1;
+    const int cap = nb * cus;
+    if (n < 64) cache[n++] = Entry{key, threads, lds, cap};
+    return cap;
+}
+inline int rounds_of(long wgs, int cap) { return (int)((wgs + cap - 1) / cap); }
+
 int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const stgcn_stblock_plan& pl, float* ws,
                        hipStream_t st) {
     const Derived v = derive(d);
@@ -178,30 +204,43 @@ int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st
     return STGCN_OK;
 }
 
-int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
-    // 32-row tiles / 4 waves measured fastest on MI355X for every shape of the model (more, lighter workgroups per CU);
-    // 64-row tiles / 8 waves are kept selectable (STGCN_TCONV_TR=64) for larger problems.
-    static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;   // tuning knob
-    const bool small = force_tr ? force_tr == 32 : true;
-    const bool tiny = force_tr == 16 || (!force_tr && cdiv(a.ts.rows, 32) < 256);     // fewer than one 32-row tile per CU: 16-row tiles
-    const int tr = tiny ? 16 : (small ? 32 : kTileRows);
-    const dim3 grid(cdiv(a.ts.rows, tr));
-    static const size_t lds_pad = getenv("STGCN_LDS_PAD") ? (size_t)atoi(getenv("STGCN_LDS_PAD")) : 0;   // occupancy experiments
-    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float) + lds_pad;
-    if (tiny) {
-        if (a.Cout == 64) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 1, 4>), grid, dim3(256), lds, a);
-        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 1, 4>), grid, dim3(256), lds, a);
-        return STGCN_OK;
+template <int NT>
+int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st) {
+    // candidates: 16 / 32 / 48-row tiles with 4 waves, 64-row tiles with 8 waves.  Smallest tile (most workgroups) whose
+    // grid is resident in one round; otherwise the fewest rounds.  STGCN_TCONV_TR=<rows> forces a tile (tuning knob).
+    static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;
+    const int trs[4] = {16, 32, 48, 64};
+    int best = -1, best_rounds = 1 << 30;
+    for (int i = 0; i < 4; ++i) {
+        const int tr = trs[i];
+        const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
+        int cap;
+        switch (tr) {
+            case 16: cap = wg_capacity(tconv_fwd_kernel<NT, 1, 4>, 256, lds); break;
+            case 32: cap = wg_capacity(tconv_fwd_kernel<NT, 2, 4>, 256, lds); break;
+            case 48: cap = wg_capacity(tconv_fwd_kernel<NT, 3, 4>, 256, lds); break;
+            default: cap = wg_capacity(tconv_fwd_kernel<NT, 4, 8>, 512, lds); break;
+        }
+        const int r = rounds_of(cdiv(a.ts.rows, tr), cap);
+        if (force_tr ? tr == force_tr : r < best_rounds) {
+            best = tr;
+            best_rounds = r;
+            if (force_tr) break;
+        }
     }
-    // 64-row tiles run with 8 waves (2 per SIMD and workgroup), 32-row tiles with 4
-    if (a.Cout == 64) {
-        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 2, 4>), grid, dim3(256), lds, a);
-        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<2, 4, 8>), grid, dim3(512), lds, a);
-    } else {
-        if (small) STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 2, 4>), grid, dim3(256), lds, a);
-        else STGCN_LAUNCH(label, st, (tconv_fwd_kernel<4, 4, 8>), grid, dim3(512), lds, a);
+    if (best < 0) best = 32;
+    const dim3 grid(cdiv(a.ts.rows, best));
+    const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, best) * sizeof(float);
+    switch (best) {
+        case 16: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 1, 4>), grid, dim3(256), lds, a); break;
+        case 32: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 2, 4>), grid, dim3(256), lds, a); break;
+        case 48: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 3, 4>), grid, dim3(256), lds, a); break;
+        default: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 4, 8>), grid, dim3(512), lds, a); break;
     }
     return STGCN_OK;
+}
+int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
+    return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
 }
 
 // graph-conv workgroups: one wave per 16-node tile up to 16 tiles (13 waves for 207 nodes: measured 10% faster than 8 waves
@@ -221,13 +260,20 @@ int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
 }
 
 int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
-    const dim3 grid(cdiv(a.ts.rows, kTileRows)), blk(kThreads);
-    static const size_t lds_pad = getenv("STGCN_LDS_PAD_BWD") ? (size_t)atoi(getenv("STGCN_LDS_PAD_BWD")) : 0;   // occupancy experiments
-    const size_t lds = kTileLdsFloats * sizeof(float) + lds_pad;
-    if (ntt == 1) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<1, 1, 1>), grid, blk, lds, a);
-    else if (ntt == 2) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 2>), grid, blk, lds, a);
-    else if (ntt == 4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 0, 8>), grid, dim3(512), lds, a);
-    else if (ntt == 8) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 2, 0, 8>), grid, dim3(512), lds, a);
+    const long tiles = cdiv(a.ts.rows, kTileRows);
+    const dim3 grid((unsigned)tiles);
+    const size_t lds = kTileLdsFloats * sizeof(float);
+    if (ntt == 1) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<1, 1, 1>), grid, dim3(256), lds, a);
+    else if (ntt == 2) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 2>), grid, dim3(256), lds, a);
+    else if (ntt == 4) {
+        // 8 waves x 2 m-tiles (more waves in flight) unless its register budget leaves part of the grid to a second round
+        // and the 4-wave x 4 m-tile variant does not
+        static const int force_w = getenv("STGCN_BWD_DATA_WAVES") ? atoi(getenv("STGCN_BWD_DATA_WAVES")) : 0;   // tuning knob
+        const int r8 = force_w ? (force_w == 8 ? 0 : 2) : rounds_of(tiles, wg_capacity(tconv_bwd_data_kernel<2, 1, 0, 8>, 512, lds));
+        const int r4 = force_w ? 1 : rounds_of(tiles, wg_capacity(tconv_bwd_data_kernel<4, 1, 0, 4>, 256, lds));
+        if (r8 <= r4) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 1, 0, 8>), grid, dim3(512), lds, a);
+        else STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<4, 1, 0, 4>), grid, dim3(256), lds, a);
+    } else if (ntt == 8) STGCN_LAUNCH(label, st, (tconv_bwd_data_kernel<2, 2, 0, 8>), grid, dim3(512), lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "backward-data with %d input channel tiles (supported: 1, 2, 4, 8)", ntt);
     return STGCN_OK;
 }

@@ -15,12 +15,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- optional per-phase cycle stamps (diagnostic build -DSTGCN_PHASE_TIMING only; compiled out otherwise) -------
 #ifdef STGCN_PHASE_TIMING
+#ifdef STGCN_PHASE_WALL
+#define STGCN_PHASE_CLOCK() wall_clock64()   // 100 MHz, one time base for the whole device: workgroup timelines
+#else
+#define STGCN_PHASE_CLOCK() clock64()        // shader cycles, per-XCD base: phase durations inside a workgroup
+#endif
 __device__ long long stgcn_phase_buf[4096 * 16];
 __device__ int stgcn_phase_kid;
 #define STGCN_PHASE(kid, i)                                                                                     \
     do {                                                                                                        \
         if (stgcn_phase_kid == (kid) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096)                \
-            stgcn_phase_buf[blockIdx.x * 16 + (i)] = clock64();                                                 \
+            stgcn_phase_buf[blockIdx.x * 16 + (i)] = STGCN_PHASE_CLOCK();                                       \
     } while (0)
 #else
 #define STGCN_PHASE(kid, i) ((void)0)

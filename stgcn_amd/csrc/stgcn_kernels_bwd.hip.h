@@ -65,7 +65,8 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
     g.thin = (Kt * c_in <= 16 && c0 == 64 && c1 == 16) ? 1 : 0;
     // grid-stride workgroups of align_gate_bwd (23.5 KB of LDS each: several per CU for latency hiding).  The thin
-    // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there (measured).
+    // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there
+    // (measured; 512 = 2 resident workgroups per CU at 62 KB of LDS -- a 513th would wait for a second round).
     const int al_cap = g.thin ? 512 : 1024;
     g.al_wgs = (int)(tiles1 < al_cap ? tiles1 : al_cap);
     long o = 0;
@@ -238,8 +239,11 @@ struct TconvBwdDataArgs {
 };
 
 // WAVES = 8 (LAYOUT 0 only): the second half of the workgroup owns m-tiles 2..3 of every n-tile column, i.e. WM = 2.
+// Register budgets that keep the grids of the C2 shapes resident in one round: the narrow-output layout (LAYOUT 1) is held
+// to 5 waves per SIMD (<= 96 registers; at 4 its 1035-tile launch would leave 11 workgroups to a second round), the 4-wave
+// variants to 4 (1024 workgroup slots).
 template <int WM, int NT, int LAYOUT, int WAVES = 4>
-__global__ __launch_bounds__(WAVES * 64) void tconv_bwd_data_kernel(TconvBwdDataArgs a) {
+__global__ __launch_bounds__(WAVES * 64, LAYOUT == 1 ? 5 : (WAVES == 4 ? 4 : 1)) void tconv_bwd_data_kernel(TconvBwdDataArgs a) {
     constexpr int THREADS = WAVES * 64;
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);

@@ -43,6 +43,12 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
+// residency queries of the launch heuristics: the emulator runs workgroups one after another, any capacity will do
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return 0; }
+template <typename K>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K, int threads, size_t) { *nb = 2048 / threads; return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 

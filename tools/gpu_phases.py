@@ -66,6 +66,31 @@ def report(kid, which, go):
             line.append(f"p{prev}->p{i}: {np.mean(v[ok] - used[:, prev][ok]):.0f}")
         prev = i
     start_spread = (used[:, cols[0]] - t0)
+    if "STGCN_PHASE_WALL" in os.environ.get("STGCN_EXTRA_FLAGS", ""):
+        st = (used[:, cols[0]] - t0) / 100.0
+        en = (used[:, cols[-1]] - t0) / 100.0
+        q = lambda v: " ".join(f"{np.percentile(v, p):.1f}" for p in (0, 10, 25, 50, 75, 90, 100))
+        print(f"{NAMES[kid]:18s} {which:6s} wgs={len(used):5d} WALL us: start pct[0,10,25,50,75,90,100] = {q(st)} | end = {q(en)} | lifetime = {q(en - st)}")
+        return
+    # per-XCD timelines (every XCD has its own s_memtime base): when do workgroups start / end relative to the XCD's first start
+    idx = np.nonzero((a != 0).any(axis=1))[0]
+    st_rel, en_rel = [], []
+    for x in range(8):
+        rows = a[idx[idx % 8 == x]]
+        if len(rows) == 0:
+            continue
+        first = rows[:, cols[0]]
+        last = rows[:, cols[-1]]
+        ok = (first != 0) & (last != 0)
+        if ok.sum() == 0:
+            continue
+        base = first[ok].min()
+        st_rel.append(first[ok] - base)
+        en_rel.append(last[ok] - base)
+    if st_rel:
+        st_rel = np.concatenate(st_rel); en_rel = np.concatenate(en_rel)
+        q = lambda v: " ".join(f"{np.percentile(v, p):.0f}" for p in (0, 25, 50, 75, 100))
+        print(f"   per-XCD timeline (cycles): start pct[0,25,50,75,100] = {q(st_rel)} | end = {q(en_rel)} | lifetime = {q(en_rel - st_rel)}")
     print(f"{NAMES[kid]:18s} {which:10s} wgs={len(used):5d} span={span} cyc  start mean={start_spread.mean():.0f} max={start_spread.max()}  | " + "  ".join(line))
     print(f"   (the LAST of several launches of this kernel in the step overwrote earlier ones)")
 
