@@ -43,19 +43,19 @@ inline int prof_begin(const char* name, hipStream_t st) {
         if (!g_prof) g_prof = (ProfSlot*)calloc(kProfMax, sizeof(ProfSlot));
         const int grow = g_prof_cap + 256 > kProfMax ? kProfMax : g_prof_cap + 256;
         for (int i = g_prof_cap; i < grow; ++i) {
-            hipEventCreate(&g_prof[i].e0);
-            hipEventCreate(&g_prof[i].e1);
+            (void)hipEventCreate(&g_prof[i].e0);
+            (void)hipEventCreate(&g_prof[i].e1);
         }
         g_prof_cap = grow;
     }
     const int i = g_prof_n++;
     g_prof[i].name = name;
     g_prof[i].tag = g_prof_tag;
-    hipEventRecord(g_prof[i].e0, st);
+    (void)hipEventRecord(g_prof[i].e0, st);
     return i;
 }
 inline void prof_end(int i, hipStream_t st) {
-    if (i >= 0) hipEventRecord(g_prof[i].e1, st);
+    if (i >= 0) (void)hipEventRecord(g_prof[i].e1, st);
 }
 
 // STGCN_LAUNCH_LOG=<file>: one line "label@tag <kernel> <workgroups> <threads>" per launch, so that an external profile
@@ -78,6 +78,33 @@ inline void launch_log(const char* label, const char* kernel, dim3 grid, dim3 bl
         hipError_t e_ = hipGetLastError();                                                        \
         if (e_ != hipSuccess) return fail(STGCN_ERR_LAUNCH, "%s: %s", label, hipGetErrorString(e_)); \
     } while (0)
+
+// ---- side stream ----------------------------------------------------------------------------------------------------
+// The weight-gradient kernels of a backward call depend only on dZ, not on the data-gradient chain that follows it, and
+// both are latency-bound launches of ~1 workgroup per CU, so they could run beside each other.  side_fork(st) returns a
+// stream that starts after everything enqueued on st so far; side_join(st) makes st wait for it (always called before the
+// entry point returns, so callers and hipGraph capture see one stream).  OFF by default: on MI355X the cross-queue
+// dependencies of the 6 fork/join pairs per step cost more than the overlap returns at the C2 size (0.650 vs 0.577 ms per
+// step under hipGraph replay, profiles/r19_r33_experiments.md); STGCN_SIDE_STREAM=1 enables it for larger problems.
+struct SideStream { hipStream_t s; hipEvent_t fork, join; int state; };   // state: 0 not initialised, 1 on, -1 off
+SideStream g_side = {nullptr, nullptr, nullptr, 0};
+hipStream_t side_fork(hipStream_t st) {
+    if (g_side.state == 0) {
+        const char* e = getenv("STGCN_SIDE_STREAM");
+        g_side.state = -1;
+        if (e && atoi(e) == 1 && hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) == hipSuccess)
+            g_side.state = 1;
+    }
+    if (g_side.state < 0) return st;
+    if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork, 0) != hipSuccess) return st;
+    return g_side.s;
+}
+void side_join(hipStream_t st, hipStream_t sd) {
+    if (sd == st) return;
+    if (hipEventRecord(g_side.join, sd) == hipSuccess) (void)hipStreamWaitEvent(st, g_side.join, 0);
+}
 
 #define STGCN_CHECK_LAUNCH(name)                                                                  \
     do {                                                                                          \
@@ -333,9 +360,9 @@ int stgcn_profile_collect(char* buf, size_t cap) {
     Agg agg[96];
     int na = 0;
     for (int i = 0; i < g_prof_n; ++i) {
-        hipEventSynchronize(g_prof[i].e1);
+        (void)hipEventSynchronize(g_prof[i].e1);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
+        (void)hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1);
         int k = 0;
         for (; k < na; ++k)
             if (agg[k].tag == g_prof[i].tag && strcmp(agg[k].name, g_prof[i].name) == 0) break;

@@ -54,6 +54,10 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }   // launches run synchronously
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
