@@ -62,6 +62,12 @@ __device__ __forceinline__ int xcd_item(int b, int n) {
 #endif
 }
 
+// Integer division by a launch-time value that is almost always a power of two (channel counts, float4 columns of a
+// row): an integer divide is ~25 VALU instructions per element on this ISA and the staging / epilogue loops do one per
+// 16-byte load.  sh = pow2_shift(d) once (uniform), then fast_div(x, d, sh) per element (x >= 0).
+__device__ __forceinline__ int pow2_shift(int d) { return (d > 0 && (d & (d - 1)) == 0) ? 31 - __builtin_clz((unsigned)d) : -1; }
+__device__ __forceinline__ int fast_div(int x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
+
 // v_exp_f32 + v_rcp_f32 (1 ulp each): a full-precision IEEE divide costs ~10 instructions per element in the epilogues
 __device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 

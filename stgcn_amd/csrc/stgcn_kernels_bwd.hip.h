@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
         s1 += __shfl_xor(s1, m);
         s2 += __shfl_xor(s2, m);
     }
-    if (valid && (q % c4n) == 0) a.rowstat[slab * a.N + q / c4n] = make_float2(s1, s2);
+    if (valid && (q & (c4n - 1)) == 0) a.rowstat[slab * a.N + fast_div(q, c4n, pow2_shift(c4n))] = make_float2(s1, s2);
 }
 
 // ================================================================================================
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
     __syncthreads();
     if (!valid) return;
     const int c4n = a.C >> 2;
-    const int node = q / c4n, c4 = q - node * c4n;
+    const int node = fast_div(q, c4n, pow2_shift(c4n)), c4 = q - node * c4n;
     const f32x4 ga = ld4(a.gamma + 4 * q);
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     f32x4 dg = zero4(), db = zero4();
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
         if (ph) STGCN_PHASE(6, 2);
         // row-major pass with 16-byte global accesses: gate backward -> dZ, H back into the tile
         for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
-            const int row = idx / c4n, c4 = idx - row * c4n;
+            const int row = fast_div(idx, c4n, pow2_shift(c4n)), c4 = idx - row * c4n;
             const long R = row0 + row;
             f32x4 h = zero4();
             if (R < a.rows) {
@@ -587,9 +587,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
                     u = ld4(a.U + (size_t)R * c0 + 4 * c4);
                     s = ld4(a.S + (size_t)R * c0 + 4 * c4);
                 } else {   // cheap conv (K <= 16): Z = im2col(x) @ W_eff + b_eff recomputed instead of stored
-                    const long per_b = (long)a.ts.Tdst * a.ts.N;
-                    const int b = (int)(R / per_b);
-                    const long rem = R - (long)b * per_b;
+                    const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N), Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                     const float* xr = a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem) * a.ts.C;
                     u = ld4(a.bias + 4 * c4);
                     f32x4 qv = ld4(a.bias + c0 + 4 * c4);
@@ -722,7 +720,7 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         __syncthreads();
         // row-major pass: recompute gate inputs, gate backward, dZ / H tiles
         for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
-            const int row = idx / c4n, c4 = idx - row * c4n;
+            const int row = fast_div(idx, c4n, pow2_shift(c4n)), c4 = idx - row * c4n;
             const long R = row0 + row;
             f32x4 h = zero4(), du = zero4(), dq = zero4();
             if (R < a.rows) {
@@ -847,7 +845,8 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
     const int nsteps = (int)((crow1 - crow0 + SR - 1) / SR);
     const int nit = (nsteps + GROUPS - 1) / GROUPS;   // barrier intervals (the same for every group)
     const int K = a.ts.taps * a.ts.C;
-    const long per_b = (long)a.ts.Tdst * a.ts.N;
+    const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N);   // rows < 2^31 (checked on the host): 32-bit divisions only
+    const int csh = pow2_shift(a.ts.C);
 
     // staging registers (next step's tiles are fetched while the current step's MFMAs run)
     constexpr int NCR = (SR * (MC / 4) + kThreads - 1) / kThreads;   // float4 of the im2col tile per thread (vector path)
@@ -867,9 +866,8 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
                     const long R = r0 + r;
                     const int kidx = m0 + 4 * q;
                     if (R < crow1 && kidx < K) {
-                        const int b = (int)(R / per_b);
-                        const long rem = R - (long)b * per_b;
-                        const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                        const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
+                        const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
                         v = ld4(a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
                     }
                 }
@@ -885,9 +883,8 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
                     const long R = r0 + r;
                     const int kidx = m0 + q;
                     if (R < crow1 && kidx < K) {
-                        const int b = (int)(R / per_b);
-                        const long rem = R - (long)b * per_b;
-                        const int tap = kidx / a.ts.C, ch = kidx - tap * a.ts.C;
+                        const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
+                        const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
                         v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
                     }
                 }

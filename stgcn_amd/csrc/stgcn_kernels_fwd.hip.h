@@ -139,28 +139,28 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
 template <int TR = kTileRows, int THREADS = kThreads>
 __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                   float* At, int lda) {
-    const int K = ts.taps * ts.C;
+    const int K = ts.taps * ts.C, csh = pow2_shift(ts.C);
     if ((ts.C & 3) == 0) {
-        const int q4 = kseg >> 2;
-        const bool full = kseg == kSegMax;   // q4 == 32: shifts instead of integer divisions
+        const int q4 = kseg >> 2, qsh = pow2_shift(q4);
         for (int idx = threadIdx.x; idx < TR * q4; idx += THREADS) {
-            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
+            const int r = fast_div(idx, q4, qsh), q = idx - r * q4;
             const int kidx = k0 + 4 * q;
             f32x4 v = zero4();
             if (kidx < K) {
-                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
                 if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
             st4(At + r * lda + 4 * q, v);
         }
     } else {   // narrow inputs (C = 1 for the first block): scalar gather
+        const int ksh = pow2_shift(kseg);
         for (int idx = threadIdx.x; idx < TR * kseg; idx += THREADS) {
-            const int r = idx / kseg, q = idx - r * kseg;
+            const int r = fast_div(idx, kseg, ksh), q = idx - r * kseg;
             const int kidx = k0 + q;
             float v = 0.f;
             if (kidx < K) {
-                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
                 if (tt >= 0 && tt < ts.Tsrc) v = ts.src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
             }
@@ -204,17 +204,16 @@ template <int TR, int THREADS>
 __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                       TileRegs<TR, THREADS>& regs) {
     constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
-    const int K = ts.taps * ts.C, q4 = kseg >> 2;
-    const bool full = kseg == kSegMax;
+    const int K = ts.taps * ts.C, q4 = kseg >> 2, qsh = pow2_shift(q4), csh = pow2_shift(ts.C);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * THREADS;
         f32x4 v = zero4();
         if (idx < TR * q4) {
-            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
+            const int r = fast_div(idx, q4, qsh), q = idx - r * q4;
             const int kidx = k0 + 4 * q;
             if (kidx < K) {
-                const int tap = kidx / ts.C, ch = kidx - tap * ts.C;
+                const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
                 if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
@@ -225,13 +224,12 @@ __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const in
 template <int TR, int THREADS>
 __device__ __forceinline__ void tile_commit_segment(int kseg, const TileRegs<TR, THREADS>& regs, float* At, int lda) {
     constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
-    const int q4 = kseg >> 2;
-    const bool full = kseg == kSegMax;
+    const int q4 = kseg >> 2, qsh = pow2_shift(q4);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * THREADS;
         if (idx < TR * q4) {
-            const int r = full ? (idx >> 5) : idx / q4, q = full ? (idx & 31) : idx - r * q4;
+            const int r = fast_div(idx, q4, qsh), q = idx - r * q4;
             st4(At + r * lda + 4 * q, regs.v[i]);
         }
     }
@@ -402,9 +400,9 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
             for (int r = 0; r < 4; ++r) Zt[((mt0 + i) * 16 + 4 * g + r) * ldz + col] = acc[i][j][r];
     }
     __syncthreads();
-    const int c4n = Cout >> 2;
+    const int c4n = Cout >> 2, c4sh = pow2_shift(c4n);
     for (int idx = threadIdx.x; idx < TR * c4n; idx += THREADS) {
-        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int row = fast_div(idx, c4n, c4sh), c4 = idx - row * c4n;
         const long R = row0 + row;
         const f32x4 p = ld4(Zt + row * ldz + 4 * c4), q = ld4(Zt + row * ldz + Cout + 4 * c4);
         const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + Cout + 4 * c4);

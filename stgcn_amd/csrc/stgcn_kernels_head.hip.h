@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     }
     __syncthreads();
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-    const int c4n = c1 >> 2;   // 32
+    const int c4n = c1 >> 2, c4sh = pow2_shift(c4n);   // 32
     const float b2 = a.b2 ? a.b2[0] : 0.f;
     for (int idx = threadIdx.x; idx < TR * c4n; idx += kThreads) {
-        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int row = fast_div(idx, c4n, c4sh), c4 = idx - row * c4n;
         const long R = row0 + row;
         f32x4 h = ld4(Zt + row * ldz + 4 * c4);
         const f32x4 w2 = ld4(a.w2 + 4 * c4);

@@ -42,12 +42,25 @@ def main(fetch_db, write_db, launch_log):
             continue
         label, kernel, wgs, threads = parts
         labels.setdefault(label, (norm(kernel), int(wgs) * int(threads), int(wgs)))
+    def lookup(table, kname, grid):
+        """exact (symbol, grid) match, else the unique kernel with the same base name and grid (the launch log shows
+        template arguments as written in the source, e.g. <MTW, 2, true>, rocprof shows them instantiated)"""
+        hit = table.get((kname, grid))
+        if hit is not None:
+            return hit, kname
+        base = kname.split("<")[0]
+        cands = [(k, v) for k, v in table.items() if k[1] == grid and k[0].split("<")[0] == base]
+        if len(cands) == 1:
+            return cands[0][1], cands[0][0][0]
+        return None, kname
+
     res = {}
     for label, (kname, grid, wgs) in sorted(labels.items()):
-        f = fetch.get((kname, grid))
-        w = write.get((kname, grid))
+        f, kname_f = lookup(fetch, kname, grid)
+        w, _ = lookup(write, kname, grid)
         if f is None or w is None:
             continue
+        kname = kname_f
         res[label] = {
             "kernel": kname, "workgroups": wgs, "launches_sampled": f[1],
             "FETCH_SIZE_raw_KiB": round(f[0], 1), "WRITE_SIZE_raw_KiB": round(w[0], 1),
