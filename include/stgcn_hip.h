@@ -52,6 +52,7 @@ typedef struct stgcn_stblock_desc {
     float ln_eps;             /* 1e-12 in the reference (layers.py:246)                              */
     int32_t need_dx;          /* backward: also produce the input gradient                           */
     int32_t reserved;         /* free-form tag (e.g. block index); only used to label the built-in kernel timer   */
+    int32_t prepacked;        /* 1: stgcn_prepack already rewrote this call's weights into ws (forward skips its pack launch) */
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -155,6 +156,7 @@ typedef struct stgcn_outblock_desc {
     float ln_eps;
     int32_t need_dx;
     int32_t reserved;
+    int32_t prepacked;        /* as in stgcn_stblock_desc */
 } stgcn_outblock_desc;
 
 /* state_dict keys under "output.": tc_w tmp_conv1.causal_conv.weight (2*c0, c_in, Ko, 1), tc_b .bias,
@@ -187,6 +189,18 @@ int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock
 int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                             const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
                             void* stream);
+
+/* ---- Whole-model weight pack: the per-call pack launches of all ST blocks and of the head in ONE launch at the start of a
+ *      training / inference step (the parameters only change in optimizer.step(), main.py:169).  Every forward whose desc
+ *      has prepacked = 1 then skips its own pack; `ws` must be the buffers later handed to those forward / backward calls.
+ *      head_desc may be NULL (no fused head).  Packs the backward-data operands regardless of need_dx.                  */
+typedef struct stgcn_prepack_block {
+    const stgcn_stblock_desc* desc;
+    const stgcn_stblock_params* params;
+    float* ws;
+} stgcn_prepack_block;
+int stgcn_prepack(int32_t n_blocks, const stgcn_prepack_block* blocks, const stgcn_outblock_desc* head_desc,
+                  const stgcn_outblock_params* head_params, float* head_ws, void* stream);
 
 /* ---- Optimizer step: torch.optim.AdamW(lr, weight_decay) as main.py:148 configures it (betas (0.9, 0.999), eps 1e-8,
  *      amsgrad False), applied by optimizer.step() at main.py:169.  `tensors` is a HOST array of `count` entries (device

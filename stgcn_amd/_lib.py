@@ -25,7 +25,8 @@ class StblockDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32),
                 ("c0", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32), ("Kt", C.c_int32), ("Ks", C.c_int32),
                 ("act", C.c_int32), ("graph_conv", C.c_int32), ("training", C.c_int32),
-                ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32)]
+                ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32),
+                ("prepacked", C.c_int32)]
 
 
 PARAM_FIELDS = ["tc1_w", "tc1_b", "tc1_aw", "tc1_ab", "al_w", "al_b", "gc_w", "gc_b",
@@ -53,7 +54,7 @@ class StblockPlan(C.Structure):
 class OutblockDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("c_end", C.c_int32), ("Ko", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float),
-                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32)]
+                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32), ("prepacked", C.c_int32)]
 
 
 HEAD_PARAM_FIELDS = ["tc_w", "tc_b", "tc_aw", "tc_ab", "ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
@@ -61,6 +62,10 @@ HEAD_PARAM_FIELDS = ["tc_w", "tc_b", "tc_aw", "tc_ab", "ln_w", "ln_b", "fc1_w", 
 
 class OutblockParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in HEAD_PARAM_FIELDS]
+
+
+class PrepackBlock(C.Structure):      # stgcn_prepack_block
+    _fields_ = [("desc", C.POINTER(StblockDesc)), ("params", C.POINTER(StblockParams)), ("ws", C.c_void_p)]
 
 
 class OutblockGrads(C.Structure):
@@ -114,6 +119,9 @@ class _Lib:
         d.stgcn_adamw_step.argtypes = [C.POINTER(AdamwTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
         d.stgcn_adamw_step.restype = C.c_int
+        d.stgcn_prepack.argtypes = [C.c_int32, C.POINTER(PrepackBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p,
+                                    C.c_void_p]
+        d.stgcn_prepack.restype = C.c_int
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int
         d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]
@@ -154,4 +162,4 @@ def lib() -> _Lib:
 
 EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
-                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step"]
+                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack"]

@@ -191,36 +191,53 @@ int wg_capacity(K kernel, int threads, size_t lds) {
 }
 inline int rounds_of(long wgs, int cap) { return (int)((wgs + cap - 1) / cap); }
 
-int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const stgcn_stblock_plan& pl, float* ws,
-                       hipStream_t st) {
-    const Derived v = derive(d);
+// pack jobs: appended to one PackArgs so that several modules can share a launch (stgcn_prepack)
+struct PackList {
     PackArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    int nj = 0;
-    auto add = [&](int kind, int n, float* dst, const float* w, const float* b, const float* aw, const float* ab, int Cin, int Cout,
-                   int Kt, int KCH) {
+    int nj;
+    PackList() : nj(0) { memset(&pa, 0, sizeof(pa)); }
+    bool add(int kind, int n, float* dst, const float* w, const float* b, const float* aw, const float* ab, int Cin, int Cout, int Kt,
+             int KCH) {
+        if (nj >= kMaxPackJobs) return false;
         PackJob& j = pa.job[nj];
         j.kind = kind; j.n = n; j.dst = dst; j.w = w; j.b = b; j.aw = aw; j.ab = ab;
         j.Cin = Cin; j.Cout = Cout; j.Kt = Kt; j.KCH = KCH; j.gated = 1;
         pa.start[nj + 1] = pa.start[nj] + cdiv(n, kThreads);
         ++nj;
-    };
-    add(PK_TCONV_FWD, v.NC1 * v.KP1, ws + pl.ws_W1p, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, v.KP1 / 16);
-    if (d->need_dx)
-        add(PK_TCONV_BWD, d->Kt * v.NC1 * v.CP_in, ws + pl.ws_W1d, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt,
-            d->Kt * v.NC1 / 16);
-    add(PK_TCONV_BIAS, v.NC1, ws + pl.ws_b1, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
-    add(PK_ALIGN_FWD, d->c0 * d->c1, ws + pl.ws_Wap, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, d->c0 / 16);
-    add(PK_ALIGN_BWD, v.CP1 * d->c0, ws + pl.ws_WaT, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, v.CP1 / 16);
-    add(PK_ALIGN_BIAS, d->c1, ws + pl.ws_ba, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, 0);
-    add(PK_TCONV_FWD, v.NC2 * v.KP2, ws + pl.ws_W2p, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, v.KP2 / 16);
-    add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
-        d->Kt * v.NC2 / 16);
-    add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
-    if (pl.recompute_tc1) add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
-    pa.njobs = nj;
-    STGCN_LAUNCH("pack", st, pack_kernel, dim3(pa.start[nj]), dim3(kThreads), 0, pa);
+        return true;
+    }
+};
+bool pack_fill_block(PackList& L, const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const stgcn_stblock_plan& pl, float* ws,
+                     bool all) {
+    const Derived v = derive(d);
+    bool ok = true;
+    ok &= L.add(PK_TCONV_FWD, v.NC1 * v.KP1, ws + pl.ws_W1p, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, v.KP1 / 16);
+    if (d->need_dx || all)
+        ok &= L.add(PK_TCONV_BWD, d->Kt * v.NC1 * v.CP_in, ws + pl.ws_W1d, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt,
+                    d->Kt * v.NC1 / 16);
+    ok &= L.add(PK_TCONV_BIAS, v.NC1, ws + pl.ws_b1, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
+    ok &= L.add(PK_ALIGN_FWD, d->c0 * d->c1, ws + pl.ws_Wap, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, d->c0 / 16);
+    ok &= L.add(PK_ALIGN_BWD, v.CP1 * d->c0, ws + pl.ws_WaT, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, v.CP1 / 16);
+    ok &= L.add(PK_ALIGN_BIAS, d->c1, ws + pl.ws_ba, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, 0);
+    ok &= L.add(PK_TCONV_FWD, v.NC2 * v.KP2, ws + pl.ws_W2p, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, v.KP2 / 16);
+    ok &= L.add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
+                d->Kt * v.NC2 / 16);
+    ok &= L.add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
+    if (pl.recompute_tc1)
+        ok &= L.add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
+    return ok;
+}
+int launch_pack_list(const char* label, PackList& L, hipStream_t st) {
+    if (L.nj == 0) return STGCN_OK;
+    L.pa.njobs = L.nj;
+    STGCN_LAUNCH(label, st, pack_kernel, dim3(L.pa.start[L.nj]), dim3(kThreads), 0, L.pa);
     return STGCN_OK;
+}
+int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const stgcn_stblock_plan& pl, float* ws,
+                       hipStream_t st) {
+    PackList L;
+    if (!pack_fill_block(L, d, P, pl, ws, false)) return fail(STGCN_ERR_INVALID, "pack job table overflow");
+    return launch_pack_list("pack", L, st);
 }
 
 int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st) {
@@ -460,7 +477,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     hipStream_t st = (hipStream_t)stream;
     g_prof_tag = d->reserved;
 
-    rc = launch_pack(d, P, pl, ws, st);
+    rc = d->prepacked ? STGCN_OK : launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
 
     // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------

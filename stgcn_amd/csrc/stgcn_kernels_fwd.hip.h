@@ -28,7 +28,7 @@ struct PackJob {
     const float* ab;  // temporal-layer Align conv bias (Cout) or null
     int Cin, Cout, Kt, KCH, gated;
 };
-constexpr int kMaxPackJobs = 12;
+constexpr int kMaxPackJobs = 36;   // 2-3 ST blocks x 10 jobs + the head (stgcn_prepack)
 struct PackArgs {
     PackJob job[kMaxPackJobs];
     int start[kMaxPackJobs + 1];   // prefix sums of workgroup counts

@@ -8,6 +8,8 @@ graph_conv_type, gso, enable_bias, droprate, n_his.
 """
 from __future__ import annotations
 
+import os
+
 import torch.nn as nn
 
 from . import layers
@@ -37,14 +39,37 @@ class _STGCNBase(nn.Module):
     def _make_dropout(self, p):
         self.dropout = nn.Dropout(p=p)
 
+    def _prepack(self, x):
+        """All weight packs of the step in one launch (the per-module pack launches are skipped for this forward)."""
+        from . import ops, _lib
+        from .layers import STConvBlock, OutputBlock
+        if x.dim() != 4 or not (x.is_cuda or _lib.lib().is_emulator) or os.environ.get("STGCN_PREPACK", "1") == "0":
+            return []            # (the modules raise the proper error themselves / tuning knob: per-module pack launches)
+        blocks, T = [], x.shape[2]
+        for blk in self.st_blocks:
+            if not isinstance(blk, STConvBlock):
+                return []
+            blocks.append((blk.cfg, T, blk._params(), blk._ws))
+            T -= 2 * (blk.cfg.Kt - 1)
+        head = None
+        if self.Ko > 1 and isinstance(self.output, OutputBlock) and ops.head_supported(self.output.cfg):
+            head = (self.output.cfg, T, self.output._params(), self.output._ws)
+        ops.prepack_modules(blocks, head, x.shape[0], x.device)
+        return [b[3] for b in blocks] + ([head[3]] if head is not None else [])
+
     def forward(self, x):
-        x = self.st_blocks(x)
-        if self.Ko > 1:
-            x = self.output(x)
-        elif self.Ko == 0:
-            x = self.fc1(x.permute(0, 2, 3, 1))
-            x = self.relu(x)
-            x = self.fc2(x).permute(0, 3, 1, 2)
+        marked = self._prepack(x)
+        try:
+            x = self.st_blocks(x)
+            if self.Ko > 1:
+                x = self.output(x)
+            elif self.Ko == 0:
+                x = self.fc1(x.permute(0, 2, 3, 1))
+                x = self.relu(x)
+                x = self.fc2(x).permute(0, 3, 1, 2)
+        finally:
+            for wsc in marked:      # a module that did not run (exception) must pack by itself next time
+                wsc.prepacked = False
         return x
 
 

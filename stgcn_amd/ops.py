@@ -51,7 +51,7 @@ def _check_device(t: torch.Tensor, what: str):
         raise RuntimeError(f"{what}: stgcn_amd runs on MI355X only (tensor is on {t.device}); there is no CPU fallback")
 
 
-def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool) -> StblockDesc:
+def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False) -> StblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")  # layers.py:117-118
     if cfg.graph_conv_type not in _lib.GRAPH_CONV:
@@ -67,6 +67,7 @@ def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool) -
     d.ln_eps = float(cfg.ln_eps)
     d.need_dx = 1 if need_dx else 0
     d.reserved = int(cfg.tag)
+    d.prepacked = 1 if prepacked else 0
     return d
 
 
@@ -117,6 +118,11 @@ class WorkspaceCache:
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
+        self.prepacked = False      # one-shot: set by prepack_modules, consumed by the next forward of the owning module
+
+    def take_prepacked(self) -> bool:
+        p, self.prepacked = self.prepacked, False
+        return p
 
     def get(self, n_floats: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < n_floats or self.buf.device != device:
@@ -140,7 +146,7 @@ class _STBlockFn(torch.autograd.Function):
         L = _lib.lib()
         B, T, N, c_in = x_cl.shape
         need_dx = bool(x_cl.requires_grad)
-        desc = make_desc(cfg, B, T, training, need_dx)
+        desc = make_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked())
         plan = query_plan(desc)
         dev = x_cl.device
         ps = [None if p is None else p.detach() for p in params]
@@ -212,6 +218,41 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     return y_cl.permute(0, 3, 1, 2)
 
 
+def prepack_modules(blocks, head, B: int, device) -> None:
+    """One pack launch for a whole model step (stgcn_prepack): ``blocks`` is a list of (cfg, T_in, params, wsc) of the ST
+    blocks in order, ``head`` is (cfg, T_in, params, wsc) or None.  Marks every workspace so that the module's next forward
+    skips its own pack launch.  Parameters only change in optimizer.step(), so this runs once per forward of the model."""
+    L = _lib.lib()
+    arr = (_lib.PrepackBlock * max(len(blocks), 1))()
+    keep = []
+    for i, (cfg, T, params, wsc) in enumerate(blocks):
+        desc = make_desc(cfg, B, T, True, True)
+        plan = query_plan(desc)
+        ps = [None if p is None else p.detach() for p in params]
+        pst = _param_struct(StblockParams, ps)
+        ws = wsc.get(plan.ws_floats, device)
+        keep += [desc, pst, ps, ws]
+        arr[i].desc = C.pointer(desc)
+        arr[i].params = C.pointer(pst)
+        arr[i].ws = ws.data_ptr()
+    hd = hp = hws = None
+    if head is not None:
+        cfg, T, params, wsc = head
+        hdesc = make_head_desc(cfg, B, T, True, True)
+        hplan = query_head_plan(hdesc)
+        hps = [None if p is None else p.detach() for p in params]
+        hpst = _head_struct(OutblockParams, hps)
+        hws_t = wsc.get(hplan.ws_floats, device)
+        keep += [hdesc, hpst, hps, hws_t]
+        hd, hp, hws = C.byref(hdesc), C.byref(hpst), hws_t.data_ptr()
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else None
+    L.check(L.dll.stgcn_prepack(len(blocks), arr, hd, hp, hws, stream), "stgcn_prepack")
+    for _, _, _, wsc in blocks:
+        wsc.prepacked = True
+    if head is not None:
+        head[3].prepacked = True
+
+
 # ------------------------------------------------------------------------------------------------ output head
 @dataclass(frozen=True)
 class HeadConfig:
@@ -231,7 +272,7 @@ def head_supported(cfg: HeadConfig) -> bool:
             and (cfg.c_in % 4 == 0 or cfg.Ko * cfg.c_in <= 16))
 
 
-def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool) -> OutblockDesc:
+def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False) -> OutblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")
     d = OutblockDesc()
@@ -242,6 +283,7 @@ def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: boo
     d.training = 1 if training else 0
     d.droprate, d.ln_eps = float(cfg.droprate), float(cfg.ln_eps)
     d.need_dx = 1 if need_dx else 0
+    d.prepacked = 1 if prepacked else 0
     return d
 
 
@@ -274,7 +316,7 @@ class _OutBlockFn(torch.autograd.Function):
         L = _lib.lib()
         B, T, N, c_in = x_cl.shape
         need_dx = bool(x_cl.requires_grad)
-        desc = make_head_desc(cfg, B, T, training, need_dx)
+        desc = make_head_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked())
         plan = query_head_plan(desc)
         dev = x_cl.device
         ps = [None if p is None else p.detach() for p in params]

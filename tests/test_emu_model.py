@@ -60,3 +60,28 @@ def test_model_matches_reference_golden(name):
         if ("grad." + k) in fx:
             r = fx["grad." + k]
             assert maxabs(prm.grad.numpy(), r) <= 1e-3 * max(1e-30, float(np.abs(r).max())) + 1e-7, k
+
+
+def test_prepack_equals_per_module_pack(monkeypatch):
+    """stgcn_prepack (one pack launch per model forward) must leave exactly what the per-module pack launches write:
+    outputs and gradients are bitwise identical with and without it, and the one-shot flags never outlive a forward."""
+    from stgcn_amd.layers import DropoutStream
+    fx, model, x, y = _build("tiny_cheb_f32")
+    model.train()
+
+    def run():
+        DropoutStream.manual_seed(77)          # same dropout masks in both runs
+        for p in model.parameters():
+            p.grad = None
+        out = model(x)
+        loss = torch.nn.functional.mse_loss(out.reshape(len(x), -1), y)
+        loss.backward()
+        return out.detach().clone(), [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+
+    o1, g1 = run()
+    assert all(not b._ws.prepacked for b in model.st_blocks) and not model.output._ws.prepacked
+    monkeypatch.setattr(type(model), "_prepack", lambda self, x: [])
+    o2, g2 = run()
+    assert torch.equal(o1, o2)
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
