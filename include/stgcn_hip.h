@@ -119,9 +119,12 @@ const char* stgcn_last_error(void); /* thread-local message of the last failing 
 
 int stgcn_stblock_plan_query(const stgcn_stblock_desc* desc, stgcn_stblock_plan* plan);
 
-/* gso: dense (N, N) row-major.  gso_pad / gso_t_pad: NP*NP floats each, NP = roundup16(N): the operator and its
- * transpose, zero padded and stored in MFMA fragment order (layout: stgcn_kernels_fwd.hip.h, gso_pad_kernel).    */
-int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream);
+/* gso: dense (N, N) row-major.  terms = operator terms of the block's graph conv including the identity (ChebGraphConv:
+ * Ks, layers.py:147-161; GraphConv: 2).  gso_pad / gso_t_pad: (terms-1)*NP*NP floats each (at least 1), NP = roundup16(N):
+ * the Chebyshev polynomials T_1(gso) .. T_{terms-1}(gso) (T_1 = gso, T_k = 2 gso T_{k-1} - T_{k-2}: the recursion the
+ * reference applies to the activations, applied once to the constant operator) and their transposes, zero padded and
+ * stored in MFMA fragment order (layout: stgcn_kernels_fwd.hip.h, gso_frag_kernel).  scratch: 3*NP*NP floats.        */
+int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad, float* gso_t_pad, float* scratch, void* stream);
 
 /* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
  * offset is the high 64 counter bits).  offset_dev (nullable) points to a DEVICE uint64 added to `offset` when

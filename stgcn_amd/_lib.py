@@ -102,7 +102,7 @@ class _Lib:
         d.stgcn_backend.restype = C.c_char_p
         d.stgcn_last_error.restype = C.c_char_p
         d.stgcn_stblock_plan_query.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockPlan)]
-        d.stgcn_gso_prepare.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.stgcn_gso_prepare.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,

@@ -287,18 +287,44 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
     return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
 }
 
-// graph-conv workgroups: one wave per 16-node tile up to 16 tiles (13 waves for 207 nodes: measured 10% faster than 8 waves
-// x 2 tiles), 8 waves x up to 4 tiles beyond
-inline int gc_waves(int HT) { return HT > 16 ? 8 : (HT < 4 ? 4 : HT); }
+// graph-conv launch geometry: a (b, t) slab is split over `parts` workgroups (part p owns node tiles p, p + parts, ..) of
+// `waves` waves with up to `maxq` tiles per wave.  The path offers only B*T slabs (192-320 at C2) for 256 CUs and one
+// slab's 13 node tiles do not divide over 4 SIMDs, so the forward runs 4 waves x ~1 tile per workgroup (parts = tiles/4:
+// every workgroup puts one tile on each SIMD, ~5 workgroups per CU: 27.5 -> 22.6 us at C2 block 0); the backward, whose
+// parts would each re-stage X_k / dY and re-form all G_k, stays at one workgroup per slab (2 parts: 29 -> 35 us).
+// STGCN_GC_PARTS=<f>,<b> overrides (tuning knob).
+struct GcGeom { int parts, waves, maxq; };
+inline GcGeom gc_geom(int HT, int want_parts) {
+    GcGeom g;
+    g.parts = want_parts < 1 ? 1 : (want_parts > HT ? HT : want_parts);
+    const int per = (HT + g.parts - 1) / g.parts;          // tiles of the largest part
+    g.waves = per > 16 ? 8 : (per < 4 ? 4 : per);
+    g.maxq = (per + g.waves - 1) / g.waves;
+    return g;
+}
+inline void gc_parts_override(int& fwd, int& bwd) {
+    static int f = 0, b = 0, init = 0;
+    if (!init) {
+        init = 1;
+        const char* e = getenv("STGCN_GC_PARTS");
+        if (e) sscanf(e, "%d,%d", &f, &b);
+    }
+    if (f > 0) fwd = f;
+    if (b > 0) bwd = b;
+}
 
-int launch_gconv_fwd(const GconvFwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, waves = gc_waves(HT), maxq = (HT + waves - 1) / waves;
-    const size_t lds = (size_t)3 * 16 * (a.NP + 4) * sizeof(float);
-    const dim3 grid((unsigned)a.slabs), blk(waves * 64);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, 16>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, 8>), grid, blk, lds, a);
-    else if (maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, 8>), grid, blk, lds, a);
-    else if (maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, 8>), grid, blk, lds, a);
+int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
+    const int HT = a.NP / 16;
+    int pf = (HT + 3) / 4, pb = 1;
+    gc_parts_override(pf, pb);
+    const GcGeom g = gc_geom(HT, pf);
+    a.parts = g.parts;
+    const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
+    const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
+    if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, 16>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, 8>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, 8>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, 8>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
@@ -322,15 +348,19 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
     return STGCN_OK;
 }
 
-int launch_gconv_bwd(const GconvBwdArgs& a, hipStream_t st) {
-    const int HT = a.NP / 16, waves = gc_waves(HT), maxq = (HT + waves - 1) / waves;
+int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
+    const int HT = a.NP / 16;
+    int pf = 0, pb = 1;
+    gc_parts_override(pf, pb);
+    const GcGeom g = gc_geom(HT, pb);
+    a.parts = g.parts;
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
-    const dim3 grid((unsigned)a.slabs), blk(waves * 64);
-    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, 16>), grid, blk, lds, a);
-    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, 8>), grid, blk, lds, a);
-    else if (maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, 8>), grid, blk, lds, a);
-    else if (maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, 8>), grid, blk, lds, a);
+    const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
+    if (g.maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, 16>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, 8>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, 8>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, 8>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
@@ -446,11 +476,28 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     return STGCN_OK;
 }
 
-int stgcn_gso_prepare(const float* gso, int32_t N, float* gso_pad, float* gso_t_pad, void* stream) {
-    if (!gso || !gso_pad || !gso_t_pad || N < 1) return fail(STGCN_ERR_INVALID, "stgcn_gso_prepare: bad arguments");
+int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad, float* gso_t_pad, float* scratch, void* stream) {
+    if (!gso || !gso_pad || !gso_t_pad || !scratch || N < 1 || terms < 1 || terms > 9)
+        return fail(STGCN_ERR_INVALID, "stgcn_gso_prepare: bad arguments (N >= 1, 1 <= terms <= 9)");
+    hipStream_t st = (hipStream_t)stream;
     const int NP = (int)rup(N, 16);
-    STGCN_LAUNCH("gso_pad", (hipStream_t)stream, gso_pad_kernel, dim3(cdiv((int64_t)NP * NP, kThreads)), dim3(kThreads), 0, gso, (int)N,
-                 NP, gso_pad, gso_t_pad);
+    const size_t M = (size_t)NP * NP;
+    const dim3 grid(cdiv((int64_t)M, kThreads)), blk(kThreads);
+    float* D[3] = {scratch, scratch + M, scratch + 2 * M};   // D[0] = L (kept), D[1] / D[2]: T_{k-1} / T_{k-2} ring
+    STGCN_LAUNCH("gso_dense", st, gso_dense_kernel, grid, blk, 0, gso, (int)N, NP, D[0]);
+    const float* tm1 = D[0];      // T_1
+    const float* tm2 = nullptr;   // T_0 = I
+    for (int k = 1; k < terms; ++k) {
+        const float* tk = tm1;
+        if (k >= 2) {
+            float* out = (tm1 == D[1]) ? D[2] : D[1];
+            STGCN_LAUNCH("cheb_next", st, cheb_next_kernel, grid, blk, 0, (const float*)D[0], tm1, tm2, (int)N, NP, out);
+            tm2 = tm1;
+            tm1 = out;
+            tk = out;
+        }
+        STGCN_LAUNCH("gso_frag", st, gso_frag_kernel, grid, blk, 0, tk, NP, gso_pad + (size_t)(k - 1) * M, gso_t_pad + (size_t)(k - 1) * M);
+    }
     return STGCN_OK;
 }
 

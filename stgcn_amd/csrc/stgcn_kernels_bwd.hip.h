@@ -357,28 +357,29 @@ __global__ __launch_bounds__(WAVES * 64, LAYOUT == 1 ? 5 : (WAVES == 4 ? 4 : 1))
 // ================================================================================================
 // B3: graph-conv backward on one (b, t) slab, dY = masked upstream gradient:
 //     dW_k = X_k^T dY, db = 1^T dY                       (partials per slab)
-//     G_k = dY W_k^T ; for k = Ks-1..2: G_{k-1} += 2 L^T G_k ; G_{k-2} -= G_k
-//     dA = G_0 + L^T G_1 + dY                            (the + dY is the residual of layers.py:229)
-// Same fragment scheme as gconv_fwd_kernel with the transposed operator LTp.
+//     G_k = dY W_k^T ;  dA = G_0 + sum_{k>=1} T_k(L)^T G_k + dY      (the + dY is the residual of layers.py:229)
+// Same fragment scheme as gconv_fwd_kernel with the transposed polynomials LTp (independent terms, no recursion).
 // ================================================================================================
 struct GconvBwdArgs {
     const float* dY;     // [slabs][N][16]
     const float* X0;     // [slabs][N][16]   (A)
     const float* Xk;     // [terms-1][slabs][N][16]
-    const float* LTp;    // fragment-packed transposed operator
+    const float* LTp;    // fragment-packed T_1^T .. T_{terms-1}^T (stgcn_gso_prepare), NP*NP floats each
     const float* W;
     float* dA;           // [slabs][N][16]
     float* part;         // [slabs][(terms+1)*256]
     int N, NP, Ks, kipf;
+    int parts;           // workgroups per slab (see GconvFwdArgs); every part stages the slab and forms all G_k
     long slabs;
 };
 
 template <int MAXQ, int MAXW>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)
 __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
-    const int THREADS = blockDim.x, WAVES = THREADS >> 6;
     extern __shared__ float stgcn_smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long slab = blockIdx.x;
+    const int THREADS = blockDim.x, NW = THREADS >> 6, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int P = a.parts, prt = (int)(blockIdx.x % (unsigned)P);
+    const long slab = blockIdx.x / (unsigned)P;
+    const int wave = prt + P * w, WAVES = P * NW;   // owned node tiles: wave + WAVES * q
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, LDY = 20, Ks = a.Ks;
     float* const GT0 = stgcn_smem;                 // GT(k) = GT0 + k*16*LDX, transposed [c][node]
     float* const dYs = stgcn_smem + Ks * 16 * LDX; // [NP][LDY] row major
@@ -416,95 +417,85 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
     }
     __syncthreads();   // X_k no longer needed: GT buffers become G_k
 
-    // ---- G_k = dY W_k^T on the owned node tiles -----------------------------------------------------
+    // ---- G_k = dY W_k^T on ALL node tiles (they are the K dimension of the products below; with parts > 1 every part of
+    //      the slab forms them: 4 MFMAs per tile and term) ---------------------------------------------------------
     for (int k = 0; k < Ks; ++k) {
         f32x4 wf = zero4();   // B[kk = j][col = i] = W_k[i = l15][j = 4g + s]
         if (!(a.kipf && k == 0)) wf = ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g);
+        for (int ht = w; ht < HT; ht += NW) {
+            const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
+            f32x4 d = zero4();
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            if (ht < HT) {
-                const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
-                f32x4 d = zero4();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) d = mfma4(af[s], wf[s], d);
-                st4(GT0 + (k * 16 + l15) * LDX + ht * 16 + 4 * g, d);      // D[h = 4g + r][i = l15]
-            }
+            for (int s = 0; s < 4; ++s) d = mfma4(af[s], wf[s], d);
+            st4(GT0 + (k * 16 + l15) * LDX + ht * 16 + 4 * g, d);      // D[h = 4g + r][i = l15]
         }
     }
 
-    // ---- reverse Chebyshev recursion --------------------------------------------------------------------
-    for (int k = Ks - 1; k >= 1; --k) {
-        __syncthreads();   // G_k complete
-        const float* Gk = GT0 + k * 16 * LDX;
-        f32x4 acc[MAXQ];
+    __syncthreads();   // every G_k complete
+
+    // ---- dA = G_0 + sum_{k >= 1} T_k^T G_k + dY on the owned node tiles: the terms are independent products with the
+    //      precomputed polynomials (two terms per pass over the k chunks, separate accumulators) ---------------------
+    const size_t MSZ = (size_t)NP * NP;
+    f32x4 acc1[MAXQ], acc2[MAXQ];
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
-        f32x4 bn1[MAXQ], bn2[MAXQ];   // operator fragments two chunks ahead
+    for (int q = 0; q < MAXQ; ++q) {
+        acc1[q] = zero4();
+        acc2[q] = zero4();
+    }
+    for (int k0 = 1; k0 < Ks; k0 += 2) {
+        const bool two = k0 + 1 < Ks;
+        const float* T1 = a.LTp + (size_t)(k0 - 1) * MSZ;
+        const float* T2 = T1 + MSZ;
+        const float* G1 = GT0 + k0 * 16 * LDX;
+        const float* G2 = G1 + 16 * LDX;
+        f32x4 p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // operator fragments one (p) and two (n) chunks ahead
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
-            const float* lrow = a.LTp + ((size_t)ht * KCH * 64 + lane) * 4;   // fragment-packed transposed operator
-            bn1[q] = ht < HT ? ld4(lrow) : zero4();
-            bn2[q] = (ht < HT && KCH > 1) ? ld4(lrow + 256) : zero4();
+            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
+            const bool in = ht < HT;
+            p1[q] = in ? ld4(T1 + o) : zero4();
+            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
+            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
+            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
         }
         for (int kc = 0; kc < KCH; ++kc) {
-            const f32x4 af = ld4(Gk + l15 * LDX + kc * 16 + 4 * g);
-            f32x4 bf[MAXQ];
+            const f32x4 af1 = ld4(G1 + l15 * LDX + kc * 16 + 4 * g);
+            const f32x4 af2 = two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4();
+            f32x4 b1[MAXQ], b2[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
-                bf[q] = bn1[q];
-                bn1[q] = bn2[q];
+                b1[q] = p1[q]; b2[q] = p2[q];
+                p1[q] = n1[q]; p2[q] = n2[q];
                 const int ht = wave + WAVES * q;
-                if (kc + 2 < KCH && ht < HT) bn2[q] = ld4(a.LTp + ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4);
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + WAVES * q;
-                if (ht < HT) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[q][s], acc[q]);
+                if (kc + 2 < KCH && ht < HT) {
+                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
+                    n1[q] = ld4(T1 + o);
+                    if (two) n2[q] = ld4(T2 + o);
                 }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            if (ht < HT) {
-                const int h = ht * 16 + l15;
-                if (k >= 2) {
-                    float* Gm1 = GT0 + (k - 1) * 16 * LDX;
-                    float* Gm2 = GT0 + (k - 2) * 16 * LDX;
+            for (int q = 0; q < MAXQ; ++q) {
+                if (wave + WAVES * q < HT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Gm1[(4 * g + r) * LDX + h] += 2.0f * acc[q][r];
-                        Gm2[(4 * g + r) * LDX + h] -= Gk[(4 * g + r) * LDX + h];
-                    }
-                } else {   // k == 1: dA = G_0 + L^T G_1 + dY
-                    if (h < N) {
-                        const f32x4 y = ld4(dYs + h * LDY + 4 * g);
-                        f32x4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + acc[q][r] + y[r];
-                        st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
+                    for (int s = 0; s < 4; ++s) {
+                        acc1[q] = mfma4(af1[s], b1[q][s], acc1[q]);
+                        if (two) acc2[q] = mfma4(af2[s], b2[q][s], acc2[q]);
                     }
                 }
             }
         }
     }
-    if (Ks == 1) {   // no operator term: dA = G_0 + dY
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            const int h = ht * 16 + l15;
-            if (ht < HT && h < N) {
-                const f32x4 y = ld4(dYs + h * LDY + 4 * g);
-                f32x4 o;
+    for (int q = 0; q < MAXQ; ++q) {
+        const int ht = wave + WAVES * q;
+        const int h = ht * 16 + l15;
+        if (ht < HT && h < N) {
+            const f32x4 y = ld4(dYs + h * LDY + 4 * g);
+            f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + y[r];
-                st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
-            }
+            for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + (acc1[q][r] + acc2[q][r]) + y[r];
+            st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
         }
     }
 }

@@ -86,21 +86,40 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     j.dst[e] = v;
 }
 
-// The graph shift operator is constant, so it is rewritten ONCE into MFMA B-operand fragment order, zero padded to
-// NP = roundup(N, 16):   Lf[((ht*KCH + kc)*64 + lane)*4 + s] = L[ht*16 + (lane&15)][kc*16 + 4*(lane>>4) + s]
-// (and the same for L^T, used by backward).  One (node tile ht, k chunk kc) fragment is then a contiguous 1 KiB
-// wave load (8 full cache lines) instead of 16 row segments of 64 B (half of 16 lines): the operator is streamed
-// through L1 by every workgroup, so this halves the dominant L2 -> L1 traffic of the graph-conv kernels.
-__global__ __launch_bounds__(256) void gso_pad_kernel(const float* L, int N, int NP, float* Lf, float* LTf) {
+// The graph shift operator is constant, so the Chebyshev polynomials T_k(L) (T_0 = I, T_1 = L, T_k = 2 L T_{k-1} - T_{k-2},
+// layers.py:153-161 applied to the operator instead of the activations) are formed ONCE per model and rewritten into MFMA
+// B-operand fragment order, zero padded to NP = roundup(N, 16):
+//     Tf[k-1][((ht*KCH + kc)*64 + lane)*4 + s] = T_k[ht*16 + (lane&15)][kc*16 + 4*(lane>>4) + s]        k = 1 .. terms-1
+// (and the same for T_k^T, used by backward).  Every term of the graph conv is then an independent X0 x T_k^T product: no
+// recursion through LDS, no barrier between terms, one pass over the staged X0 for all terms.  One (node tile, k chunk)
+// fragment is a contiguous 1 KiB wave load (8 full cache lines).
+// dense, zero padded copy: D[h][i] = L[h][i]
+__global__ __launch_bounds__(256) void gso_dense_kernel(const float* L, int N, int NP, float* D) {
+    const int e = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    if (e >= NP * NP) return;
+    const int h = e / NP, i = e - h * NP;
+    D[e] = (h < N && i < N) ? L[(size_t)h * N + i] : 0.f;
+}
+// out = 2 * L * Tm1 - Tm2 (dense NP x NP; Tm2 == nullptr stands for the identity on the first N rows); fp64 accumulation
+__global__ __launch_bounds__(256) void cheb_next_kernel(const float* L, const float* Tm1, const float* Tm2, int N, int NP, float* out) {
+    const int e = (int)blockIdx.x * kThreads + (int)threadIdx.x;
+    if (e >= NP * NP) return;
+    const int h = e / NP, i = e - h * NP;
+    double acc = 0.0;
+    for (int m = 0; m < NP; ++m) acc += (double)L[(size_t)h * NP + m] * (double)Tm1[(size_t)m * NP + i];
+    const double prev = Tm2 ? (double)Tm2[e] : ((h == i && h < N) ? 1.0 : 0.0);
+    out[e] = (float)(2.0 * acc - prev);
+}
+// dense padded D -> fragment order of D and of D^T
+__global__ __launch_bounds__(256) void gso_frag_kernel(const float* D, int NP, float* Tf, float* TTf) {
     const int e = (int)blockIdx.x * kThreads + (int)threadIdx.x;
     if (e >= NP * NP) return;
     const int KCH = NP >> 4;
     const int s = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
     const int kc = rest % KCH, ht = rest / KCH;
     const int h = ht * 16 + (lane & 15), i = kc * 16 + 4 * (lane >> 4) + s;
-    const bool in = h < N && i < N;
-    Lf[e] = in ? L[(size_t)h * N + i] : 0.f;
-    LTf[e] = in ? L[(size_t)i * N + h] : 0.f;
+    Tf[e] = D[(size_t)h * NP + i];
+    TTf[e] = D[(size_t)i * NP + h];
 }
 
 // ================================================================================================
@@ -466,41 +485,42 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 
 // ================================================================================================
 // F2: graph convolution on one (b, t) slab  X0 = A[slab] (N x 16)
-//     X1 = L X0 ; Xk = 2 L X_{k-1} - X_{k-2}          (layers.py:147-161, Kipf: X1 = L X0, layers.py:198)
+//     X_k = T_k(L) X0, k = 1 .. terms-1                (layers.py:147-161; Kipf: X1 = L X0, layers.py:198)
 //     Y  = sum_k Xk Wk + bias                          (layers.py:165-168 / :199-202)
 //     G  = relu(Y + X0)                                (layers.py:229, 253)
-// One workgroup per slab.  X_k live transposed in LDS (XT[c][node]) so that they are the MFMA A operand
-// (rows = 16 channels, k = nodes); L fragments come straight from L2 (padded operator, 16-B loads);
-// D = X_k^T tile[c][h] leaves each lane with 4 consecutive channels of one node, which is at once the
-// store layout and the A operand of the 16x16 weight contraction.
-// Wave w of WAVES owns node tiles h-tile = w, w+WAVES, ... (MAXQ of them).  8 waves = 2 per SIMD, so one
-// wave's operator-fragment loads (L2 latency) hide behind the other's MFMAs; the fragments of chunk kc+1
-// are also requested before the MFMAs of chunk kc.
+// One workgroup per slab.  X0 lives transposed in LDS (XT[c][node]) so that it is the MFMA A operand (rows = 16
+// channels, k = nodes); the fragments of the precomputed polynomials T_k come straight from L2 (16-B loads, requested
+// two chunks ahead); all terms share ONE pass over X0: per k-chunk one LDS read feeds the MFMAs of two terms.
+// D = X_k^T tile[c][h] leaves each lane with 4 consecutive channels of one node, which is at once the store layout
+// and the A operand of the 16x16 weight contraction.  No barrier after the staging of X0.
+// The wave count is a launch parameter (blockDim.x / 64 <= MAXW): one wave per node tile up to 16 tiles (MAXQ = 1, e.g.
+// 13 waves for the 207-node graph: measured faster than 8 waves x 2 tiles), 8 waves x MAXQ tiles beyond.
 // ================================================================================================
 struct GconvFwdArgs {
     const float* A;      // [slabs][N][16]
-    const float* Lp;     // fragment-packed operator (gso_pad_kernel), NP*NP floats
+    const float* Lp;     // fragment-packed T_1 .. T_{Ks-1} (stgcn_gso_prepare), NP*NP floats each
     const float* W;      // cheb: [Ks][16][16] ; kipf: [16][16]
     const float* bias;   // [16] or null
     float* Xk;           // [Ks-1][slabs][N][16]   (X1..X_{Ks-1}, saved for backward; nullable)
     float* G;            // [slabs][N][16]
     int N, NP, Ks, kipf; // Ks = number of terms (kipf: 2)
+    int parts;           // workgroups per slab: part p owns node tiles p, p + parts, ... (grid = slabs * parts)
     long slabs;
 };
 
-// The wave count is a launch parameter (blockDim.x / 64 <= MAXW): one wave per node tile up to 16 tiles (MAXQ = 1, e.g.
-// 13 waves for the 207-node graph: measured faster than 8 waves x 2 tiles), 8 waves x MAXQ tiles beyond.
 template <int MAXQ, int MAXW>
 __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
-    const int THREADS = blockDim.x, WAVES = THREADS >> 6;
     extern __shared__ float stgcn_smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long slab = blockIdx.x;
+    const int THREADS = blockDim.x, tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int P = a.parts, part = (int)(blockIdx.x % (unsigned)P);
+    const long slab = blockIdx.x / (unsigned)P;
+    // node tile of (wave w, slot q) = part + P * (w + nwaves * q) = wave + WAVES * q with the two names below
+    const int wave = part + P * (tid >> 6), WAVES = P * (THREADS >> 6);
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
-    float* const XT0 = stgcn_smem;   // three rotating transposed buffers XT(k) = XT0 + (k % 3) * 16 * LDX
+    const size_t MSZ = (size_t)NP * NP;
+    float* const XT0 = stgcn_smem;   // X0 transposed: [16][LDX]
 
     STGCN_PHASE(4, 0);
-    // stage X0 transposed
     const float* Asl = a.A + (size_t)slab * N * 16;
     for (int idx = tid; idx < NP * 4; idx += THREADS) {
         const int n = idx >> 2, c4 = idx & 3;
@@ -519,92 +539,88 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
         res[q] = ht < HT ? ld4(XT0 + l15 * LDX + ht * 16 + 4 * g) : zero4();
     }
-
-    for (int k = 0; k < a.Ks; ++k) {
-        // weight fragment B[kk = c][col = j] = W_k[c = 4g + s][j = l15]
+    // weight fragment B[kk = c][col = j] = W_k[c = 4g + s][j = l15]
+    auto wfrag = [&](int k) {
         f32x4 wf = zero4();
         if (!(a.kipf && k == 0)) {
             const float* Wk = a.W + (a.kipf ? 0 : (size_t)k * 256);
 #pragma unroll
             for (int s = 0; s < 4; ++s) wf[s] = Wk[(4 * g + s) * 16 + l15];
         }
-        if (k == 0) {
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + WAVES * q;
-                if (ht < HT) {
-                    const int h = ht * 16 + l15;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) yacc[q] = mfma4(XT0[(4 * g + s) * LDX + h], wf[s], yacc[q]);
-                }
-            }
-            continue;
-        }
-        if (k >= 2) __syncthreads();   // X_{k-1} complete in LDS
-        STGCN_PHASE(4, 2 * k);
-        const float* Xprev = XT0 + ((k - 1) % 3) * 16 * LDX;
-        f32x4 acc[MAXQ];
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) acc[q] = zero4();
-        // operator fragments are requested two chunks ahead (L2 latency >> one chunk of MFMAs)
-        f32x4 bn1[MAXQ], bn2[MAXQ];
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            const float* lrow = a.Lp + ((size_t)ht * KCH * 64 + lane) * 4;   // fragment-packed operator
-#if STGCN_ABL == 1
-            (void)lrow; bn1[q] = zero4(); bn2[q] = zero4();
-#else
-            bn1[q] = ht < HT ? ld4(lrow) : zero4();
-            bn2[q] = (ht < HT && KCH > 1) ? ld4(lrow + 256) : zero4();
-#endif
-        }
-        for (int kc = 0; kc < KCH; ++kc) {
-            const f32x4 af = ld4(Xprev + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
-            f32x4 bf[MAXQ];
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                bf[q] = bn1[q];                                             // B[node][h = l15]
-                bn1[q] = bn2[q];
-                const int ht = wave + WAVES * q;
-#if STGCN_ABL != 1
-                if (kc + 2 < KCH && ht < HT) bn2[q] = ld4(a.Lp + ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4);
-#endif
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int ht = wave + WAVES * q;
-                if (ht < HT) {
-#if STGCN_ABL == 2
-                    asm volatile("" ::"v"(af[0]), "v"(bf[q][0]), "v"(bf[q][3]));
-                    acc[q][0] += af[1];
-#else
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc[q] = mfma4(af[s], bf[q][s], acc[q]);
-#endif
-                }
-            }
-        }
-        STGCN_PHASE(4, 2 * k + 1);
-        float* Xcur = XT0 + (k % 3) * 16 * LDX;
-        const float* Xpp = XT0 + ((k + 1) % 3) * 16 * LDX;   // == (k-2) % 3
+        return wf;
+    };
+    {   // term 0: X0 W0
+        const f32x4 wf = wfrag(0);
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const int h = ht * 16 + l15;
-                f32x4 x = acc[q];   // X_k[h][c = 4g + r]
-                if (k >= 2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = 2.0f * x[r] - Xpp[(4 * g + r) * LDX + h];
+                for (int s = 0; s < 4; ++s) yacc[q] = mfma4(XT0[(4 * g + s) * LDX + h], wf[s], yacc[q]);
+            }
+        }
+    }
+    // terms k0, k0+1 together: acc1 = X0^T-tile products with T_k0, acc2 with T_{k0+1}
+    for (int k0 = 1; k0 < a.Ks; k0 += 2) {
+        const bool two = k0 + 1 < a.Ks;
+        const float* T1 = a.Lp + (size_t)(k0 - 1) * MSZ;
+        const float* T2 = T1 + MSZ;
+        const f32x4 wf1 = wfrag(k0), wf2 = two ? wfrag(k0 + 1) : zero4();
+        STGCN_PHASE(4, 2 * k0);
+        f32x4 acc1[MAXQ], acc2[MAXQ], p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // fragments one (p) and two (n) chunks ahead
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            acc1[q] = zero4();
+            acc2[q] = zero4();
+            const int ht = wave + WAVES * q;
+            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
+            const bool in = ht < HT;
+            p1[q] = in ? ld4(T1 + o) : zero4();
+            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
+            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
+            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
+        }
+        for (int kc = 0; kc < KCH; ++kc) {
+            const f32x4 af = ld4(XT0 + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
+            f32x4 b1[MAXQ], b2[MAXQ];
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                b1[q] = p1[q]; b2[q] = p2[q];
+                p1[q] = n1[q]; p2[q] = n2[q];
+                const int ht = wave + WAVES * q;
+                if (kc + 2 < KCH && ht < HT) {
+                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
+                    n1[q] = ld4(T1 + o);
+                    if (two) n2[q] = ld4(T2 + o);
                 }
-                if (k + 1 < a.Ks) {
+            }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Xcur[(4 * g + r) * LDX + h] = x[r];
+            for (int q = 0; q < MAXQ; ++q) {
+                if (wave + WAVES * q < HT) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc1[q] = mfma4(af[s], b1[q][s], acc1[q]);
+                        if (two) acc2[q] = mfma4(af[s], b2[q][s], acc2[q]);
+                    }
                 }
-                if (a.Xk && h < N) st4(a.Xk + (((size_t)(k - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, x);
+            }
+        }
+        STGCN_PHASE(4, 2 * k0 + 1);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) yacc[q] = mfma4(x[s], wf[s], yacc[q]);
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            if (ht < HT) {
+                const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
+                if (a.Xk && h < N) {
+                    st4(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
+                    if (two) st4(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    yacc[q] = mfma4(acc1[q][s], wf1[s], yacc[q]);
+                    if (two) yacc[q] = mfma4(acc2[q][s], wf2[s], yacc[q]);
+                }
             }
         }
     }

@@ -239,7 +239,7 @@ class STConvBlock(nn.Module):
         gso = self.gso
         key = (gso.data_ptr(), gso._version, str(device))
         if self._gso_cache is None or self._gso_cache[0] != key:
-            gp, gt = ops.gso_prepare(gso.to(device))
+            gp, gt = ops.gso_prepare(gso.to(device), ops.graph_terms(self.cfg))
             self._gso_cache = (key, gp, gt)
         return self._gso_cache[1], self._gso_cache[2]
 

@@ -85,18 +85,29 @@ def query_plan(desc: StblockDesc) -> StblockPlan:
     return p
 
 
-def gso_prepare(gso: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Pad (and transpose) the dense (N, N) graph shift operator once (main.py:101-103 upload)."""
+def gso_prepare(gso: torch.Tensor, terms: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Once per model (main.py:101-103 upload): the Chebyshev polynomials T_1 .. T_{terms-1} of the dense (N, N) graph
+    shift operator and their transposes, zero padded and in MFMA fragment order.  ``terms`` = operator terms of the graph
+    conv including the identity: Ks for ChebGraphConv, 2 for GraphConv (``graph_terms``)."""
     L = _lib.lib()
     gso = gso.detach().to(torch.float32).contiguous()
     _check_device(gso, "gso")
     N = gso.shape[0]
     assert gso.shape == (N, N)
     NP = (N + 15) // 16 * 16
-    gp = torch.empty(NP, NP, dtype=torch.float32, device=gso.device)
-    gt = torch.empty(NP, NP, dtype=torch.float32, device=gso.device)
-    L.check(L.dll.stgcn_gso_prepare(gso.data_ptr(), N, gp.data_ptr(), gt.data_ptr(), _stream_of(gso)), "stgcn_gso_prepare")
+    nm = max(int(terms) - 1, 1)
+    gp = torch.zeros(nm, NP, NP, dtype=torch.float32, device=gso.device)
+    gt = torch.zeros(nm, NP, NP, dtype=torch.float32, device=gso.device)
+    scratch = torch.empty(3, NP, NP, dtype=torch.float32, device=gso.device)
+    L.check(L.dll.stgcn_gso_prepare(gso.data_ptr(), N, int(terms), gp.data_ptr(), gt.data_ptr(), scratch.data_ptr(), _stream_of(gso)),
+            "stgcn_gso_prepare")
+    if gso.is_cuda:
+        torch.cuda.current_stream(gso.device).synchronize()     # scratch is freed on return
     return gp, gt
+
+
+def graph_terms(cfg: "BlockConfig") -> int:
+    return int(cfg.Ks) if cfg.graph_conv_type == "cheb_graph_conv" else 2
 
 
 def _optr(t: Optional[torch.Tensor]):

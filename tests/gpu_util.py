@@ -26,7 +26,7 @@ def run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None
     dy_np = rs.standard_normal((B, channels[2], T2, N)).astype(np.float32)
     bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=tuple(channels), act_func=act, graph_conv_type=gct,
                            droprate=pdrop)
-    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev))
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev), ops.graph_terms(bcfg))
     params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", gct)]
     x = torch.from_numpy(x_np).to(dev).requires_grad_(c_in > 1)
     wsc = ops.WorkspaceCache()

@@ -33,7 +33,7 @@ def test_block_backward(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
 
     bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=tuple(channels), act_func=act,
                            graph_conv_type=gct, droprate=pdrop)
-    gp, gt = ops.gso_prepare(torch.from_numpy(gso))
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso), ops.graph_terms(bcfg))
     params = [None if t is None else t.clone().requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", gct)]
     x = torch.from_numpy(x_np).requires_grad_(c_in > 1)
     wsc = ops.WorkspaceCache()

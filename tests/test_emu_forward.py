@@ -34,16 +34,27 @@ def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
                            graph_conv_type=gct, droprate=0.5)
     desc = ops.make_desc(bcfg, B, T, training=True, need_dx=c_in > 1)
     plan = ops.query_plan(desc)
-    gp, gt = ops.gso_prepare(torch.from_numpy(gso))
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso), ops.graph_terms(bcfg))
     NP = plan.NP
     KCH = NP // 16
 
     def unpack(f):      # fragment order -> dense (NP, NP): f[((ht*KCH + kc)*64 + lane)*4 + s] = M[ht*16 + lane%16][kc*16 + 4*(lane//16) + s]
         f = f.numpy().reshape(NP // 16, KCH, 4, 16, 4)          # ht, kc, lane//16, lane%16, s
         return f.transpose(0, 3, 1, 2, 4).reshape(NP, NP)
-    dp, dt = unpack(gp), unpack(gt)
-    assert np.array_equal(dp[:N, :N], gso) and np.array_equal(dt[:N, :N], gso.T)
-    assert dp[N:].sum() == 0 and dp[:, N:].sum() == 0 and dt[N:].sum() == 0 and dt[:, N:].sum() == 0
+    # T_1 = gso exactly; T_k = 2 gso T_{k-1} - T_{k-2} (fp64 accumulation in the prepare kernel), transposes alongside
+    terms = ops.graph_terms(bcfg)
+    assert gp.shape[0] == max(terms - 1, 1)
+    tm2, tm1 = np.eye(N), gso.astype(np.float64)
+    for k in range(1, terms):
+        if k >= 2:
+            tm2, tm1 = tm1, 2.0 * gso.astype(np.float64) @ tm1 - tm2
+        dp, dt = unpack(gp[k - 1]), unpack(gt[k - 1])
+        if k == 1:
+            assert np.array_equal(dp[:N, :N], gso) and np.array_equal(dt[:N, :N], gso.T)
+        else:
+            scale = max(1.0, np.abs(tm1).max())
+            assert np.abs(dp[:N, :N] - tm1).max() <= 2e-6 * scale and np.abs(dt[:N, :N] - tm1.T).max() <= 2e-6 * scale
+        assert dp[N:].sum() == 0 and dp[:, N:].sum() == 0 and dt[N:].sum() == 0 and dt[:, N:].sum() == 0
 
     params = params_in_field_order(p, "st_blocks.0.", gct)
     pst = ops._param_struct(_lib.StblockParams, params)

@@ -30,7 +30,7 @@ def run_block(c_in, T):
     gso = real_gso("metr_la.cheb_sym_norm_lap")
     bcfg = ops.BlockConfig(Kt=3, Ks=3, n_vertex=207, c_in=c_in, channels=(64, 16, 64), act_func="glu", graph_conv_type="cheb_graph_conv",
                            droprate=0.5)
-    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev))
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev), ops.graph_terms(bcfg))
     params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", "cheb_graph_conv")]
     x = torch.randn(32, c_in, T, 207, device=dev).requires_grad_(c_in > 1)
     wsc = ops.WorkspaceCache()
