@@ -24,7 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
-N_HIS, KT, KS, B_LOCAL = 12, 3, 3, 32
+N_HIS, KT, KS, B_LOCAL = 12, 3, 3, int(os.environ.get("STGCN_BENCH_B", "32"))   # (env: batch-size sweeps of tools/, not the headline)
 BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
 
 
@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--chains", type=int, default=int(os.environ.get("STGCN_CHAINS", "1")),
+                    help="micro-batch chains of the minibatch run concurrently on separate HIP streams (train.chained_fwd_bwd)")
+    ap.add_argument("--chain-graphs", action="store_true", help="one hipGraph per chain, replayed on its own stream")
     args = ap.parse_args()
 
     from stgcn_amd import DropoutStream, _lib, models
@@ -179,7 +182,11 @@ def main():
     graph_err = None
     if use_graph:
         try:
-            graphed = GraphedTrainStep(model, opt, *batch(0), world=world)
+            if args.chain_graphs and world == 1:
+                from stgcn_amd.train import ChainGraphsTrainStep
+                graphed = ChainGraphsTrainStep(model, opt, *batch(0), chains=args.chains)
+            else:
+                graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains)
 
             def run_step(xb, yb):
                 return graphed(xb, yb)
@@ -230,7 +237,8 @@ def main():
                                   "dropout 0.5, AdamW lr 1e-3 wd 1e-3; full step zero_grad+fwd+MSE+bwd+opt",
                       "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
                       "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
-                      "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err}}
+                      "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err,
+                      "chains": args.chains if use_graph else 1}}
 
     if rank == 0 and not args.no_profile:
         # per-kernel durations with hipEvents on the launch stream, over the same K steps (second pass)

@@ -36,6 +36,7 @@ class DropoutStream:
     _sites: int = 0
     counter = None            # device int64[1] in graph mode
     SITE_STRIDE = 1 << 20     # room for a million dropout sites per step
+    CHAIN_STRIDE = 1 << 12    # ... of which each concurrent micro-batch chain (ops.chain_scope) gets 4096
 
     @classmethod
     def manual_seed(cls, seed: int):
@@ -256,7 +257,7 @@ class STConvBlock(nn.Module):
         training = self.training and self.cfg.droprate > 0.0
         counter = DropoutStream.counter if training else None
         if counter is not None:
-            offset = self._site                       # static per block; the device counter supplies the step
+            offset = self._site + DropoutStream.CHAIN_STRIDE * ops.current_chain()   # static per block and chain; the device counter supplies the step
         else:
             offset = DropoutStream.next_offset() if training else 0
         return ops.st_conv_block(x, gp, gt, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)
@@ -299,7 +300,7 @@ class OutputBlock(nn.Module):
         training = self.training and self.cfg.droprate > 0.0
         counter = DropoutStream.counter if training else None
         if counter is not None:
-            offset = self._site
+            offset = self._site + DropoutStream.CHAIN_STRIDE * ops.current_chain()
         else:
             offset = DropoutStream.next_offset() if training else 0
         return ops.output_block(x, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)

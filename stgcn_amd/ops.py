@@ -123,22 +123,54 @@ def dropout_mask(n: int, droprate: float, seed: int, offset: int, device, offset
     return out
 
 
+_chain = 0
+
+
+def current_chain() -> int:
+    """Index of the micro-batch chain the calling code runs for (``train.chained_fwd_bwd``); 0 outside of it."""
+    return _chain
+
+
+class chain_scope:
+    """Everything launched inside belongs to micro-batch chain ``c``: modules use that chain's workspace (chains run
+    concurrently on different HIP streams and must not share backward temporaries) and its dropout sub-stream."""
+
+    def __init__(self, c: int):
+        self.c = int(c)
+
+    def __enter__(self):
+        global _chain
+        self.prev, _chain = _chain, self.c
+        return self
+
+    def __exit__(self, *exc):
+        global _chain
+        _chain = self.prev
+        return False
+
+
 class WorkspaceCache:
     """Per-module scratch (`ws` of the C ABI): packed weights written by forward and re-read by the
-    backward of the same step, plus backward temporaries.  Re-allocated only when the plan grows."""
+    backward of the same step, plus backward temporaries.  Re-allocated only when the plan grows.
+    One buffer per micro-batch chain (``chain_scope``); ``buf`` is chain 0's."""
 
     def __init__(self):
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs: Dict[int, torch.Tensor] = {}
         self.prepacked = False      # one-shot: set by prepack_modules, consumed by the next forward of the owning module
+
+    @property
+    def buf(self) -> Optional[torch.Tensor]:
+        return self.bufs.get(0)
 
     def take_prepacked(self) -> bool:
         p, self.prepacked = self.prepacked, False
         return p
 
     def get(self, n_floats: int, device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < n_floats or self.buf.device != device:
-            self.buf = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
-        return self.buf
+        b = self.bufs.get(_chain)
+        if b is None or b.numel() < n_floats or b.device != device:
+            b = self.bufs[_chain] = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
+        return b
 
 
 def _param_struct(cls, tensors):

@@ -98,6 +98,51 @@ def train_step(model, optimizer, x, y, allreduce: Optional[FlatGradAllReduce] = 
     return loss.detach()
 
 
+def chained_fwd_bwd(model, x, y, chains: int, streams=None):
+    """zero_grad'ed forward + MSE + backward of one minibatch as ``chains`` independent micro-batch chains.
+
+    Every kernel of this path is a 10-40 us launch whose workgroups walk load -> MFMA -> store together, so a single
+    in-order chain leaves the memory system idle while the MFMA pipes run and vice versa.  The windows of a minibatch are
+    independent (LayerNorm is per (b, t) slab), so the minibatch is cut into ``chains`` slices whose
+    complete forward + backward run CONCURRENTLY on separate HIP streams (one fork at the start, one join at the end;
+    per-chain workspaces through ``ops.chain_scope``); their parameter gradients are summed in a fixed order after the
+    join, which equals the gradient of the mean loss over the whole minibatch.  ``streams[c]`` (c >= 1) are the side
+    streams; ``None`` runs the chains back to back on the current stream (CPU emulator / tests).
+    Sets ``p.grad`` and returns the detached mean loss."""
+    from contextlib import nullcontext
+    from . import ops
+    params = [p for p in model.parameters() if p.requires_grad]
+    B = len(x)
+    assert chains >= 1 and B % chains == 0, f"batch {B} does not split into {chains} chains"
+    Bc = B // chains
+    use_streams = streams is not None and x.is_cuda and chains > 1
+    main = torch.cuda.current_stream(x.device) if use_streams else None
+    losses, grads = [], []
+    for c in range(chains):
+        s = streams[c] if (use_streams and c > 0) else None
+        if s is not None:
+            s.wait_stream(main)                       # fork: inputs / parameters are ready on the main stream
+        with (torch.cuda.stream(s) if s is not None else nullcontext()), ops.chain_scope(c):
+            xc, yc = x[c * Bc:(c + 1) * Bc], y[c * Bc:(c + 1) * Bc]
+            pred = model(xc).reshape(Bc, -1)
+            loss = torch.nn.functional.mse_loss(pred, yc) * (1.0 / chains)
+            grads.append(torch.autograd.grad(loss, params, allow_unused=True))
+            losses.append(loss.detach())
+    if use_streams:
+        for c in range(1, chains):
+            main.wait_stream(streams[c])              # join
+    live = [i for i, g in enumerate(grads[0]) if g is not None]
+    acc = [grads[0][i] for i in live]
+    for c in range(1, chains):
+        torch._foreach_add_(acc, [grads[c][i] for i in live])
+    for i, g in zip(live, acc):
+        params[i].grad = g
+    total = losses[0]
+    for l in losses[1:]:
+        total = total + l
+    return total
+
+
 class GraphedTrainStep:
     """The loop body of main.py:165-169 captured once into hipGraph(s) and replayed.
 
@@ -111,11 +156,14 @@ class GraphedTrainStep:
     buffer (fwd+bwd+flatten | all-reduce | unflatten+AdamW).
     """
 
-    def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3):
+    def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3,
+                 chains: int = 1):
         from .layers import DropoutStream
         assert x_example.is_cuda, "hipGraph capture needs the MI355X path"
         self.model, self.opt, self.world = model, optimizer, world
         dev = x_example.device
+        self.chains = int(chains)                 # micro-batch chains on concurrent streams (chained_fwd_bwd)
+        self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.chains - 1)]
         self.x = torch.empty_like(x_example)
         self.y = torch.empty_like(y_example)
         self.x.copy_(x_example)
@@ -156,6 +204,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
 
     def _fwd_bwd(self):
+        if self.chains > 1:
+            return chained_fwd_bwd(self.model, self.x, self.y, self.chains, self.streams)
         y_pred = self.model(self.x).reshape(len(self.x), -1)
         loss = torch.nn.functional.mse_loss(y_pred, self.y)
         loss.backward()
@@ -181,4 +231,80 @@ class GraphedTrainStep:
         if self.g2 is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.g2.replay()
+        return self.loss
+
+
+class ChainGraphsTrainStep:
+    """The training step as ``chains`` micro-batch chains, each captured into its OWN single-stream hipGraph and replayed on
+    its own HIP stream (so the chains' kernels can be resident on the GPU together), followed by a tail graph on the main
+    stream (fixed-order gradient sum, AdamW, dropout-counter bump).  Single GPU only.  A hipGraph with parallel branches
+    (``GraphedTrainStep(chains=k)``) measured slower than one chain on ROCm 7.2 (branches are not overlapped); independent
+    graphs on independent streams leave the overlap to the hardware queues."""
+
+    def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, chains: int = 2, warmup: int = 3):
+        from . import ops
+        from .layers import DropoutStream
+        assert x_example.is_cuda and chains >= 1 and len(x_example) % chains == 0
+        self.model, self.opt, self.chains = model, optimizer, int(chains)
+        dev = x_example.device
+        self.x, self.y = x_example.clone(), y_example.clone()
+        if DropoutStream.counter is None or DropoutStream.counter.device != dev:
+            DropoutStream.use_device_counter(dev)
+        self.counter = DropoutStream.counter
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.chains)]
+        Bc = len(self.x) // self.chains
+
+        def chain_body(c):
+            with ops.chain_scope(c):
+                xc, yc = self.x[c * Bc:(c + 1) * Bc], self.y[c * Bc:(c + 1) * Bc]
+                loss = torch.nn.functional.mse_loss(self.model(xc).reshape(Bc, -1), yc) * (1.0 / self.chains)
+                return loss.detach(), torch.autograd.grad(loss, self.params, allow_unused=True)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = [chain_body(c) for c in range(self.chains)]
+                self._tail(outs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graphs, outs = [], []
+        for c in range(self.chains):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs.append(chain_body(c))
+            self.graphs.append(g)
+        self.tail = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.tail):
+            self.loss = self._tail(outs)
+        self(x_example, y_example)
+        torch.cuda.synchronize(dev)
+
+    def _tail(self, outs):
+        from .layers import DropoutStream
+        live = [i for i, g in enumerate(outs[0][1]) if g is not None]
+        acc = [outs[0][1][i] for i in live]
+        for c in range(1, self.chains):
+            torch._foreach_add_(acc, [outs[c][1][i] for i in live])
+        for i, g in zip(live, acc):
+            self.params[i].grad = g
+        self.opt.step()
+        DropoutStream.advance()
+        total = outs[0][0]
+        for l, _ in outs[1:]:
+            total = total + l
+        return total
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        main = torch.cuda.current_stream(self.x.device)
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        for s, g in zip(self.streams, self.graphs):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                g.replay()
+        for s in self.streams:
+            main.wait_stream(s)
+        self.tail.replay()
         return self.loss

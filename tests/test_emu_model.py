@@ -85,3 +85,25 @@ def test_prepack_equals_per_module_pack(monkeypatch):
     assert torch.equal(o1, o2)
     for a, b in zip(g1, g2):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
+def test_chained_microbatches_equal_whole_batch():
+    """train.chained_fwd_bwd: the minibatch cut into independent micro-batch chains (own workspaces, gradients summed after
+    the join) gives the loss and the gradients of the whole minibatch (fixtures have droprate 0 -> deterministic)."""
+    from stgcn_amd.train import chained_fwd_bwd
+    fx, model, x, y = _build("tiny_cheb_f32")
+    model.train()
+    B = len(x) // 2 * 2
+    x, y = x[:B], y[:B]
+    model.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.mse_loss(model(x).reshape(B, -1), y)
+    loss.backward()
+    ref = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    loss2 = chained_fwd_bwd(model, x, y, 2)
+    assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))
+    assert all(len(b._ws.bufs) == 2 for b in model.st_blocks)          # one workspace per chain
+    for r, p in zip(ref, model.parameters()):
+        assert (r is None) == (p.grad is None)
+        if r is not None:
+            assert maxabs(p.grad.numpy(), r.numpy()) <= 1e-5 * max(1e-30, float(r.abs().max())) + 1e-8

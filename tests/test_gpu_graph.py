@@ -95,3 +95,29 @@ def test_graphed_training_reduces_loss():
         last = gs(x, y)
     DropoutStream.disable_device_counter()
     assert float(last.item()) < 0.6 * first
+
+
+def test_chained_graph_step_equals_single_chain():
+    """The minibatch as 2 / 4 concurrent micro-batch chains (train.chained_fwd_bwd, one stream each, captured into the same
+    hipGraph) trains to the same parameters as the single chain (droprate 0: no mask dependence)."""
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer
+    g = torch.Generator().manual_seed(2)
+    xs = torch.randn(5, 8, 1, 12, 207, generator=g).to(DEV)
+    ys = torch.randn(5, 8, 207, generator=g).to(DEV)
+    finals = []
+    for chains in (1, 2, 4):
+        DropoutStream.use_device_counter(torch.device(DEV))
+        DropoutStream.manual_seed(3)
+        m = _make(0.0)
+        o = make_optimizer(m, capturable=True)
+        gs = GraphedTrainStep(m, o, xs[0], ys[0], warmup=2, chains=chains)
+        losses = [float(gs(xs[i], ys[i]).item()) for i in range(1, 5)]
+        torch.cuda.synchronize()
+        finals.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+        DropoutStream.disable_device_counter()
+    for losses, sd in finals[1:]:
+        assert np.allclose(losses, finals[0][0], rtol=1e-5, atol=0), (losses, finals[0][0])
+        for k, v in sd.items():
+            d = float((v - finals[0][1][k]).abs().max())
+            assert d <= 2e-5, (k, d)       # AdamW normalises gradients: tiny summation-order differences stay tiny
