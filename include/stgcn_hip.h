@@ -53,6 +53,7 @@ typedef struct stgcn_stblock_desc {
     int32_t need_dx;          /* backward: also produce the input gradient                           */
     int32_t reserved;         /* free-form tag (e.g. block index); only used to label the built-in kernel timer   */
     int32_t prepacked;        /* 1: stgcn_prepack already rewrote this call's weights into ws (forward skips its pack launch) */
+    int32_t defer_reduce;     /* backward: 1 = leave the per-workgroup gradient partials in ws; stgcn_grad_flush reduces them     */
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -160,6 +161,7 @@ typedef struct stgcn_outblock_desc {
     int32_t need_dx;
     int32_t reserved;
     int32_t prepacked;        /* as in stgcn_stblock_desc */
+    int32_t defer_reduce;     /* as in stgcn_stblock_desc */
 } stgcn_outblock_desc;
 
 /* state_dict keys under "output.": tc_w tmp_conv1.causal_conv.weight (2*c0, c_in, Ko, 1), tc_b .bias,
@@ -196,14 +198,22 @@ int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outbloc
 /* ---- Whole-model weight pack: the per-call pack launches of all ST blocks and of the head in ONE launch at the start of a
  *      training / inference step (the parameters only change in optimizer.step(), main.py:169).  Every forward whose desc
  *      has prepacked = 1 then skips its own pack; `ws` must be the buffers later handed to those forward / backward calls.
- *      head_desc may be NULL (no fused head).  Packs the backward-data operands regardless of need_dx.                  */
+ *      head_desc may be NULL (no fused head).  Packs the backward-data operands regardless of need_dx.
+ *      counters (nullable, <= 4): device-side int64 step counters advanced by this first launch of the step,
+ *      *ptr = (*ptr + inc) % mod (mod 0: no wrap) -- the dropout stream position, the optimizer's step count (main.py:169) and the
+ *      like ride on the pack launch instead of costing one tiny launch each inside a captured step.                    */
 typedef struct stgcn_prepack_block {
     const stgcn_stblock_desc* desc;
     const stgcn_stblock_params* params;
     float* ws;
 } stgcn_prepack_block;
+typedef struct stgcn_step_counter {
+    int64_t* ptr;
+    int64_t inc, mod;
+} stgcn_step_counter;
 int stgcn_prepack(int32_t n_blocks, const stgcn_prepack_block* blocks, const stgcn_outblock_desc* head_desc,
-                  const stgcn_outblock_params* head_params, float* head_ws, void* stream);
+                  const stgcn_outblock_params* head_params, float* head_ws, int32_t n_counters, const stgcn_step_counter* counters,
+                  void* stream);
 
 /* ---- Optimizer step: torch.optim.AdamW(lr, weight_decay) as main.py:148 configures it (betas (0.9, 0.999), eps 1e-8,
  *      amsgrad False), applied by optimizer.step() at main.py:169.  `tensors` is a HOST array of `count` entries (device
@@ -219,6 +229,31 @@ typedef struct stgcn_adamw_tensor {
 } stgcn_adamw_tensor;
 int stgcn_adamw_step(const stgcn_adamw_tensor* tensors, int32_t count, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int64_t step, const int64_t* step_dev, const float* lr_dev, void* stream);
+
+/* ---- Whole-model gradient flush: the final reductions of every backward call of a step whose desc had defer_reduce = 1
+ *      (same desc / grads / ws as those calls) in ONE launch, optionally with optimizer.step() (main.py:169) applied to each
+ *      gradient element as it is produced (opt/opt_count/hyper as for stgcn_adamw_step; every opt entry's `grad` must be one
+ *      of the gradient buffers of this flush; opt == NULL: reduce only, e.g. before a data-parallel all-reduce).          */
+typedef struct stgcn_flush_block {
+    const stgcn_stblock_desc* desc;
+    const stgcn_stblock_grads* grads;
+    float* ws;
+} stgcn_flush_block;
+typedef struct stgcn_adamw_hyper {
+    float lr, beta1, beta2, eps, weight_decay;
+    int64_t step;
+    const int64_t* step_dev;
+    const float* lr_dev;
+} stgcn_adamw_hyper;
+int stgcn_grad_flush(int32_t n_blocks, const stgcn_flush_block* blocks, const stgcn_outblock_desc* head_desc,
+                     const stgcn_outblock_grads* head_grads, float* head_ws, const stgcn_adamw_tensor* opt, int32_t opt_count,
+                     const stgcn_adamw_hyper* hyper, void* stream);
+
+/* ---- Loss: nn.MSELoss() as main.py:136 builds it (mean over all n = B*N elements) together with the gradient that
+ *      l.backward() (main.py:168) feeds into the model output, in one launch:
+ *          loss[0] = mean((pred - target)^2) ;  dpred[i] = 2 (pred[i] - target[i]) * grad_scale / n
+ *      grad_scale = 1 for the reference's loop (1/k for a minibatch processed as k micro-batches).                        */
+int stgcn_mse_loss_grad(const float* pred, const float* target, int64_t n, float grad_scale, float* loss, float* dpred, void* stream);
 
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the

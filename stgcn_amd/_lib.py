@@ -26,7 +26,7 @@ class StblockDesc(C.Structure):
                 ("c0", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32), ("Kt", C.c_int32), ("Ks", C.c_int32),
                 ("act", C.c_int32), ("graph_conv", C.c_int32), ("training", C.c_int32),
                 ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32),
-                ("prepacked", C.c_int32)]
+                ("prepacked", C.c_int32), ("defer_reduce", C.c_int32)]
 
 
 PARAM_FIELDS = ["tc1_w", "tc1_b", "tc1_aw", "tc1_ab", "al_w", "al_b", "gc_w", "gc_b",
@@ -54,7 +54,8 @@ class StblockPlan(C.Structure):
 class OutblockDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("c_end", C.c_int32), ("Ko", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float),
-                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32), ("prepacked", C.c_int32)]
+                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32), ("prepacked", C.c_int32),
+                ("defer_reduce", C.c_int32)]
 
 
 HEAD_PARAM_FIELDS = ["tc_w", "tc_b", "tc_aw", "tc_ab", "ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
@@ -83,6 +84,19 @@ class OutblockPlan(C.Structure):
 
 class AdamwTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64)]
+
+
+class StepCounter(C.Structure):       # stgcn_step_counter
+    _fields_ = [("ptr", C.c_void_p), ("inc", C.c_int64), ("mod", C.c_int64)]
+
+
+class FlushBlock(C.Structure):        # stgcn_flush_block
+    _fields_ = [("desc", C.POINTER(StblockDesc)), ("grads", C.POINTER(StblockGrads)), ("ws", C.c_void_p)]
+
+
+class AdamwHyper(C.Structure):        # stgcn_adamw_hyper
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("step", C.c_int64), ("step_dev", C.c_void_p), ("lr_dev", C.c_void_p)]
 
 
 class StgcnError(RuntimeError):
@@ -120,8 +134,13 @@ class _Lib:
                                        C.c_void_p, C.c_void_p, C.c_void_p]
         d.stgcn_adamw_step.restype = C.c_int
         d.stgcn_prepack.argtypes = [C.c_int32, C.POINTER(PrepackBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p,
-                                    C.c_void_p]
+                                    C.c_int32, C.POINTER(StepCounter), C.c_void_p]
         d.stgcn_prepack.restype = C.c_int
+        d.stgcn_grad_flush.argtypes = [C.c_int32, C.POINTER(FlushBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockGrads), C.c_void_p,
+                                       C.POINTER(AdamwTensor), C.c_int32, C.POINTER(AdamwHyper), C.c_void_p]
+        d.stgcn_grad_flush.restype = C.c_int
+        d.stgcn_mse_loss_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.stgcn_mse_loss_grad.restype = C.c_int
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int
         d.stgcn_profile_collect.argtypes = [C.c_char_p, C.c_size_t]
@@ -162,4 +181,5 @@ def lib() -> _Lib:
 
 EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn_stblock_plan_query", "stgcn_gso_prepare",
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
-                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack"]
+                    "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack",
+                    "stgcn_mse_loss_grad", "stgcn_grad_flush"]

@@ -283,8 +283,81 @@ int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st
     }
     return STGCN_OK;
 }
+// v2 kernels (batched loads, weights in registers): tile rows 16*TM with 4 waves; KC = chunks per weight round
+template <int NT, int KC>
+int launch_tconv_fwd2_kc(const char* label, const TconvFwdArgs& a, hipStream_t st) {
+    static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;
+    constexpr int MAXTM = NT == 2 ? 4 : 2;
+    const int KP = a.KCH * 16, NC = 4 * a.Cout / 2;
+    int best = -1, best_rounds = 1 << 30;
+    for (int tm = 1; tm <= MAXTM; ++tm) {
+        const size_t lds = (size_t)tconv2_lds_floats(KP, NC, 16 * tm) * sizeof(float);
+        int cap;
+        switch (tm) {
+            case 1: cap = wg_capacity(tconv_fwd2_kernel<NT, 1, KC>, 256, lds); break;
+            case 2: cap = wg_capacity(tconv_fwd2_kernel<NT, 2, KC>, 256, lds); break;
+            case 3: cap = wg_capacity(tconv_fwd2_kernel<NT, (MAXTM >= 3 ? 3 : 1), KC>, 256, lds); break;
+            default: cap = wg_capacity(tconv_fwd2_kernel<NT, (MAXTM >= 4 ? 4 : 1), KC>, 256, lds); break;
+        }
+        const int r = rounds_of(cdiv(a.ts.rows, 16 * tm), cap);
+        if (force_tr ? 16 * tm == force_tr : r < best_rounds) {
+            best = tm;
+            best_rounds = r;
+            if (force_tr) break;
+        }
+    }
+    if (best < 0) best = 2;
+    const dim3 grid(cdiv(a.ts.rows, 16 * best));
+    const size_t lds = (size_t)tconv2_lds_floats(KP, NC, 16 * best) * sizeof(float);
+    switch (best) {
+        case 1: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, 1, KC>), grid, dim3(256), lds, a); break;
+        case 2: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, 2, KC>), grid, dim3(256), lds, a); break;
+        case 3: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, (MAXTM >= 3 ? 3 : 1), KC>), grid, dim3(256), lds, a); break;
+        default: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, (MAXTM >= 4 ? 4 : 1), KC>), grid, dim3(256), lds, a); break;
+    }
+    return STGCN_OK;
+}
+// v3 kernels (time-complete tiles: one workgroup = 16 nodes x all time steps of one window, weights of the whole K in registers)
+template <int WAVES, int NT, int KCW>
+int launch_tconv_fwd3(const char* label, const TconvFwdArgs& a, hipStream_t st) {
+    constexpr int MG = 2;
+    const int node_tiles = (a.ts.N + 15) / 16;
+    const long B = a.ts.rows / ((long)a.ts.Tdst * a.ts.N);
+    const size_t lds = tconv3_lds_bytes(a.ts.Tsrc, a.ts.C, 16 * WAVES * NT, MG);
+    STGCN_LAUNCH(label, st, (tconv_fwd3_kernel<WAVES, NT, KCW, MG>), dim3((unsigned)(B * node_tiles)), dim3(WAVES * 64), lds, a, node_tiles);
+    return STGCN_OK;
+}
+// v4: 32-row x 256-column tiles with streamed, double-buffered weight rounds (the output head; see tconv_fwd4_kernel)
+inline bool tconv4_ok(const TconvFwdArgs& a) {
+    static const int off = getenv("STGCN_TCONV4") ? atoi(getenv("STGCN_TCONV4")) == 0 : 0;   // A/B knob
+    return !off && a.Cout == 128 && (a.ts.C & 3) == 0 && a.KCH * 16 == a.ts.taps * a.ts.C && !a.Wap && !a.H &&
+           (size_t)tconv2_lds_floats(a.KCH * 16, 256, 32) * sizeof(float) <= 64 * 1024;
+}
+template <bool PLAIN>
+int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {
+    constexpr int TM = 2, KC = 4;
+    const size_t lds = (size_t)tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TM) * sizeof(float);
+    STGCN_LAUNCH(label, st, (tconv_fwd4_kernel<TM, KC, PLAIN>), dim3(cdiv(aa.f.ts.rows, 16 * TM)), dim3(512), lds, aa);
+    return STGCN_OK;
+}
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
-    return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
+    if (tconv4_ok(a)) {
+        Tconv4Args aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.f = a;
+        return launch_tconv_fwd4<false>(label, aa, st);
+    }
+    static const int ver = getenv("STGCN_TCONV_V") ? atoi(getenv("STGCN_TCONV_V")) : 1;   // 1: row tiles, per-chunk loads (fastest at C2); 2: row tiles, batched loads; 3: time-complete tiles
+    if (ver == 3 && (a.ts.C & 15) == 0 && a.KCH * 16 == a.ts.taps * a.ts.C && a.c1 == 16 * (a.Wap ? 1 : a.c1 / 16) &&
+        tconv3_lds_bytes(a.ts.Tsrc, a.ts.C, 2 * a.Cout, 2) <= 64 * 1024) {
+        if (a.Cout == 64 && a.KCH <= 3) return launch_tconv_fwd3<4, 2, 3>(label, a, st);
+        if (a.Cout == 64 && a.KCH <= 12) return launch_tconv_fwd3<4, 2, 12>(label, a, st);
+        if (a.Cout == 128 && a.KCH <= 4) return launch_tconv_fwd3<8, 2, 4>(label, a, st);
+        if (a.Cout == 128 && a.KCH <= 16) return launch_tconv_fwd3<8, 2, 16>(label, a, st);
+    }
+    if (ver == 1) return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
+    if (a.Cout == 64) return a.KCH <= 4 ? launch_tconv_fwd2_kc<2, 4>(label, a, st) : launch_tconv_fwd2_kc<2, 12>(label, a, st);
+    return a.KCH <= 4 ? launch_tconv_fwd2_kc<4, 4>(label, a, st) : launch_tconv_fwd2_kc<4, 8>(label, a, st);
 }
 
 // graph-conv launch geometry: a (b, t) slab is split over `parts` workgroups (part p owns node tiles p, p + parts, ..) of
@@ -317,6 +390,33 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     const int HT = a.NP / 16;
     int pf = (HT + 3) / 4, pb = 1;
     gc_parts_override(pf, pb);
+    {   // operator-stationary variant: the wave's operator fragments in registers, several slabs per workgroup
+        static const int per_cu = getenv("STGCN_GC_REG") ? atoi(getenv("STGCN_GC_REG")) : 0;   // opt-in (measured equal / slower at C2 and at bs 128): workgroups per CU
+        const int off = per_cu <= 0;
+        const int nterm = a.Ks - 1, KCH = a.NP / 16;
+        if (!off && (nterm == 1 || nterm == 2) && KCH <= 21 && a.NP * 4 <= 1024) {
+            const int parts = (HT + 3) / 4;
+            a.parts = parts;
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            }
+            // about one workgroup per CU: groups = CUs / parts slab ranges
+            int groups = per_cu * cus / parts;
+            if (groups < 1) groups = 1;
+            if (groups > a.slabs) groups = (int)a.slabs;
+            const int spw = (int)((a.slabs + groups - 1) / groups);
+            groups = (int)((a.slabs + spw - 1) / spw);
+            const size_t lds = (size_t)2 * 16 * (a.NP + 4) * sizeof(float);
+            const dim3 grid((unsigned)(groups * parts)), blk(256);
+            if (KCH <= 13 && nterm == 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_reg_kernel<13, 2>), grid, blk, lds, a, spw);
+            else if (KCH <= 13) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_reg_kernel<13, 1>), grid, blk, lds, a, spw);
+            else if (nterm == 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_reg_kernel<21, 2>), grid, blk, lds, a, spw);
+            else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_reg_kernel<21, 1>), grid, blk, lds, a, spw);
+            return STGCN_OK;
+        }
+    }
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
@@ -386,6 +486,67 @@ int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const Wgra
         case 3: return launch_bwd_weight_n<3>(label, a, w, st);
         default: return launch_bwd_weight_n<4>(label, a, w, st);
     }
+}
+
+// ---- final deterministic reduction: job lists shared by the backward entry points and stgcn_grad_flush ----------------
+struct ReduceList {
+    ReduceArgs ra;
+    int nj;
+    bool overflow;
+    ReduceList() : nj(0), overflow(false) { memset(&ra, 0, sizeof(ra)); }
+    // job = (dst, src, partial count/stride, enumeration sizes n0 n1 n2 (n2 contiguous in src), src strides, dst strides)
+    void add(float* dst, const float* src, int Pn, long pstride, int n0, int n1, int n2, long s0, long s1, long s2, long t0, long t1,
+             long t2) {
+        if (!dst) return;
+        if (nj >= kMaxReduceJobs) { overflow = true; return; }
+        ReduceJob& j = ra.job[nj];
+        j.src = src; j.dst = dst; j.P = Pn; j.pstride = pstride; j.n0 = n0; j.n1 = n1; j.n2 = n2;
+        j.s0 = (int)s0; j.s1 = (int)s1; j.s2 = (int)s2; j.t0 = (int)t0; j.t1 = (int)t1; j.t2 = (int)t2;
+        ra.start[nj + 1] = ra.start[nj] + reduce_job_setup(j);
+        ++nj;
+    }
+    void add_flat(float* dst, const float* src, int Pn, long pstride, int n) { add(dst, src, Pn, pstride, 1, 1, n, 0, 0, 1, 0, 0, 1); }
+};
+int launch_reduce_list(const char* label, ReduceList& L, hipStream_t st) {
+    if (L.overflow) return fail(STGCN_ERR_INVALID, "%s: more than %d reduction jobs in one launch", label, kMaxReduceJobs);
+    if (L.nj == 0) return STGCN_OK;
+    L.ra.njobs = L.nj;
+    STGCN_LAUNCH(label, st, reduce_kernel, dim3(L.ra.start[L.nj]), dim3(kThreads), kThreads * 4 * sizeof(float), L.ra);
+    return STGCN_OK;
+}
+void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived& v, const BwdGeom& bg, const float* part,
+                       const stgcn_stblock_grads* G) {
+    auto add_tconv = [&](const WgradGeom& w, int Cin, int Cout, float* gw, float* gb, float* gaw, float* gab) {
+        const float* wp = part + w.off;
+        const float* bp = wp + (long)w.chunks * w.Mpad * w.NC;
+        const long ps = (long)w.Mpad * w.NC;
+        // enumerate (k, i, o): src dW_eff[k*Cin + i][o] -> dst conv_w[o][i][k]
+        L.add(gw, wp, w.chunks, ps, d->Kt, Cin, w.NC, (long)Cin * w.NC, w.NC, 1, 1, d->Kt, (long)Cin * d->Kt);
+        L.add_flat(gb, bp, w.chunks, w.NC, w.NC);
+        if (Cin > Cout) {   // the residual branch is a live 1x1 conv: it shares tap Kt-1 of the P half
+            L.add(gaw, wp + (long)(d->Kt - 1) * Cin * w.NC, w.chunks, ps, 1, Cin, Cout, 0, w.NC, 1, 0, 1, Cin);   // aw[o][i] <- row i, col o
+            L.add_flat(gab, bp, w.chunks, w.NC, Cout);
+        }
+    };
+    if (bg.thin) {   // dW_eff (16 padded rows) and db_eff sit behind dWa | dba in the per-workgroup partials
+        const float* wp = part + bg.off_al + (long)d->c0 * 16 + 16;
+        L.add(G->tc1_w, wp, bg.al_wgs, bg.al_stride, d->Kt, d->c_in, v.NC1, (long)d->c_in * v.NC1, v.NC1, 1, 1, d->Kt, (long)d->c_in * d->Kt);
+        L.add_flat(G->tc1_b, wp + 16 * v.NC1, bg.al_wgs, bg.al_stride, v.NC1);
+    } else {
+        add_tconv(bg.w1, d->c_in, d->c0, G->tc1_w, G->tc1_b, G->tc1_aw, G->tc1_ab);
+    }
+    add_tconv(bg.w2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw, G->tc2_ab);
+    if (d->c0 > d->c1) {
+        // enumerate (i, j): src dWa[i][j] -> dst al_w[j][i]
+        L.add(G->al_w, part + bg.off_al, bg.al_wgs, bg.al_stride, 1, d->c0, d->c1, 0, d->c1, 1, 0, 1, d->c0);
+        L.add_flat(G->al_b, part + bg.off_al + (long)d->c0 * d->c1, bg.al_wgs, bg.al_stride, d->c1);
+    }
+    if (d->graph_conv == STGCN_GC_KIPF) L.add_flat(G->gc_w, part + bg.off_gc + 256, (int)v.slabs1, bg.gc_stride, 256);
+    else L.add_flat(G->gc_w, part + bg.off_gc, (int)v.slabs1, bg.gc_stride, v.terms * 256);
+    L.add_flat(G->gc_b, part + bg.off_gc + (long)v.terms * 256, (int)v.slabs1, bg.gc_stride, 16);
+    const int n = d->N * d->c2;
+    L.add_flat(G->ln_w, part + bg.off_ln_g, bg.ln_sg, n, n);
+    L.add_flat(G->ln_b, part + bg.off_ln_b, bg.ln_sg, n, n);
 }
 }  // namespace
 

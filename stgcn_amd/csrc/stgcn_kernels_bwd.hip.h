@@ -1019,19 +1019,27 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
 struct ReduceJob {
     const float* src;
     float* dst;
+    float* p;     // optional fused AdamW (stgcn_grad_flush): parameter, exp_avg, exp_avg_sq laid out like dst; null = reduce only
+    float* m;
+    float* v;
+    long pstride;
     int P;
     int vec;      // 1: n2, pstride, s0, s1 are multiples of 4 and src is 16-byte aligned
     int slices;   // 8 or 32
-    long pstride;
     int n0, n1, n2;
-    long s0, s1, s2;
-    long t0, t1, t2;
+    int s0, s1, s2;
+    int t0, t1, t2;
 };
-constexpr int kMaxReduceJobs = 16;
+constexpr int kMaxReduceJobs = 32;   // 2 ST blocks x 10-12 + the head's 8-10 in one launch (kernel arguments <= 4 KiB)
 struct ReduceArgs {
     ReduceJob job[kMaxReduceJobs];
     int start[kMaxReduceJobs + 1];
     int njobs;
+    // fused AdamW (only read for jobs with p != null): same arithmetic as adamw_kernel
+    float lr, b1, b2, eps, wd, lb1, lb2;
+    long step;
+    const long* step_dev;
+    const float* lr_dev;
 };
 // host: classify the job and return its workgroup count
 inline int reduce_job_setup(ReduceJob& j) {
@@ -1056,8 +1064,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     long doff = 0;
     if (e < n) {
         const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
-        const float* s = j.src + d0 * j.s0 + d1 * j.s1 + d2 * j.s2;
-        doff = d0 * j.t0 + d1 * j.t1 + d2 * j.t2;
+        const float* s = j.src + (long)d0 * j.s0 + (long)d1 * j.s1 + (long)d2 * j.s2;
+        doff = (long)d0 * j.t0 + (long)d1 * j.t1 + (long)d2 * j.t2;
         int p = sl;
         if (j.vec) {
             f32x4 a0 = zero4(), a1 = zero4(), a2 = zero4(), a3 = zero4();   // 4 x 16 B in flight per thread
@@ -1086,10 +1094,23 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     if (sl == 0 && e < n) {
         f32x4 t = zero4();
         for (int k = 0; k < kReduceSlices; ++k) t += ld4(stgcn_smem + (k * kReduceElems + el) * 4);
-        j.dst[doff] = t[0];
-        if (j.vec) {
-#pragma unroll
-            for (int i = 1; i < 4; ++i) j.dst[doff + i * j.t2] = t[i];
+        const int nw = j.vec ? 4 : 1;
+        for (int i = 0; i < nw; ++i) j.dst[doff + (long)i * j.t2] = t[i];
+        if (j.p) {   // AdamW on the freshly reduced gradient (torch.optim.AdamW, see adamw_kernel)
+            const float ts = (float)(a.step_dev ? *a.step_dev : a.step);
+            const float lr = a.lr_dev ? *a.lr_dev : a.lr;
+            const float bc1 = -expm1f(ts * a.lb1);
+            const float rs2 = rsqrtf(-expm1f(ts * a.lb2));
+            const float decay = 1.0f - lr * a.wd, step_size = lr / bc1;
+            for (int i = 0; i < nw; ++i) {
+                const long o = doff + (long)i * j.t2;
+                const float g = t[i];
+                const float m = a.b1 * j.m[o] + (1.0f - a.b1) * g;
+                const float v = a.b2 * j.v[o] + (1.0f - a.b2) * g * g;
+                j.m[o] = m;
+                j.v[o] = v;
+                j.p[o] = j.p[o] * decay - step_size * (m / (sqrtf(v) * rs2 + a.eps));
+            }
         }
     }
 }

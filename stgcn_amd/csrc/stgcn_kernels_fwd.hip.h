@@ -16,7 +16,8 @@ namespace stgcn {
 // ================================================================================================
 enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5,
                 PK_LIN_FWD = 6, PK_LIN_BWD = 7,
-                PK_TCONV_DENSE = 8, PK_ALIGN_DENSE = 9 };   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
+                PK_TCONV_DENSE = 8, PK_ALIGN_DENSE = 9,
+                PK_TCONV_BWDT = 10 };   // one-step transposed conv as a dense GEMM: K = NC (o), cols = tap*Cin + i   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
 
 struct PackJob {
     int kind;
@@ -29,10 +30,15 @@ struct PackJob {
     int Cin, Cout, Kt, KCH, gated;
 };
 constexpr int kMaxPackJobs = 36;   // 2-3 ST blocks x 10 jobs + the head (stgcn_prepack)
+constexpr int kMaxStepCounters = 4;
 struct PackArgs {
     PackJob job[kMaxPackJobs];
     int start[kMaxPackJobs + 1];   // prefix sums of workgroup counts
     int njobs;
+    // device-side step counters advanced by the first launch of a training step (stgcn_prepack): *ptr = (*ptr + inc) [% mod]
+    int ncounters;
+    long* cptr[kMaxStepCounters];
+    long cinc[kMaxStepCounters], cmod[kMaxStepCounters];
 };
 
 // W_eff[tap*Cin + i][o]: causal-conv weight with the residual branch Align(x)[:, :, Kt-1:] folded in
@@ -47,6 +53,11 @@ __device__ __forceinline__ float tconv_weff(const PackJob& j, int tap, int i, in
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < a.ncounters; ++k) {
+            const long v = *a.cptr[k] + a.cinc[k];
+            *a.cptr[k] = a.cmod[k] > 0 ? v % a.cmod[k] : v;
+        }
     int jb = 0;
     while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
     const PackJob& j = a.job[jb];
@@ -73,6 +84,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
             if (kidx < j.Kt * j.Cin) v = tconv_weff(j, kidx / j.Cin, kidx % j.Cin, col);
         } else if (j.kind == PK_TCONV_BWD) {   // K = Kt*NC, cols = Cin (padded to 16)
             if (col < j.Cin) v = tconv_weff(j, kidx / NC, col, kidx % NC);
+        } else if (j.kind == PK_TCONV_BWDT) {  // K = NC (o), cols = Kt*Cin: B[o][tap*Cin + i] = W_eff[tap*Cin + i][o]
+            if (kidx < NC && col < j.Kt * j.Cin) v = tconv_weff(j, col / j.Cin, col % j.Cin, kidx);
         } else if (j.kind == PK_ALIGN_FWD) {   // A = H @ Wa : K = c0 (=Cin), cols = c1 (=Cout)
             if (kidx < j.Cin && col < j.Cout) v = (j.Cin > j.Cout) ? j.w[(size_t)col * j.Cin + kidx] : (kidx == col ? 1.f : 0.f);
         } else if (j.kind == PK_ALIGN_BWD) {   // dH = dA @ Wa^T : K = c1, cols = c0
@@ -484,6 +497,554 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 }
 
 // ================================================================================================
+// F1 (v2): the same gated temporal convolution with a SHORT dependent-latency chain per workgroup.
+// The C2 launches of this path are 10-40 us long with a handful of workgroups per CU, so a workgroup's run time is the
+// sum of its dependent memory round trips, not its FLOPs (profiles/r40_batch_sweep.log: half of the step time is
+// independent of the batch size).  v1 staged a tile with a load -> wait -> LDS-store loop (one HBM round trip per 16 B
+// and thread) and fetched the weight fragments of every K chunk inside the MFMA loop (one L2 round trip per chunk).
+// Here every global load a phase needs is ISSUED before the first wait:
+//   1. weight fragments of a whole round of KC chunks (the entire K for the ST blocks) + bias -> registers,
+//   2. the whole im2col tile [TR x K] (all taps) -> registers -> LDS in batches of SB 16-byte loads per thread; row
+//      coordinates are computed in registers (no LDS row table, no barrier before the loads),
+//   3. MFMA loop fed from registers (B) and LDS (A) only,
+//   4. the align weights are requested before the accumulators go through LDS, the epilogue loop is unrolled.
+// Template: NT n-tiles per wave (NC = 64*NT, Cout = 32*NT), TM m-tiles (rows = 16*TM, shared by the 4 waves),
+// KC chunks of 16 K-columns per weight round.
+// ================================================================================================
+// (b, t, n) of a flat output row of a tap source, two 32-bit divisions (once per thread)
+struct RowCoord { int b, t, n; };
+__device__ __forceinline__ RowCoord row_coord(const TapSrc& ts, long R) {
+    const unsigned per_b = (unsigned)(ts.Tdst * ts.N), Ru = (unsigned)R;
+    RowCoord c;
+    c.b = (int)(Ru / per_b);
+    const unsigned rem = Ru - (unsigned)c.b * per_b;
+    c.t = (int)(rem / (unsigned)ts.N);
+    c.n = (int)(rem - (unsigned)c.t * (unsigned)ts.N);
+    return c;
+}
+// coordinates of row R0 + r from those of R0 (r < 64: a few compare / subtract steps instead of divisions)
+__device__ __forceinline__ RowCoord row_advance(const TapSrc& ts, RowCoord c, int r) {
+    c.n += r;
+    while (c.n >= ts.N) { c.n -= ts.N; ++c.t; }
+    while (c.t >= ts.Tdst) { c.t -= ts.Tdst; ++c.b; }
+    return c;
+}
+
+// Whole tile of a forward (dir = +1) tap source -> At[TR][lda], columns [0, KP): batches of SB loads per thread in flight.
+template <int TR, int SB, int THREADS = kThreads>
+__device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int KP, float* At, int lda) {
+    const int tid = threadIdx.x, K = ts.taps * ts.C;
+    const RowCoord c0 = row_coord(ts, row0 < ts.rows ? row0 : 0);
+    if ((ts.C & 3) == 0) {
+        const int c4n = ts.C >> 2, c4sh = pow2_shift(c4n), per_tap = TR * c4n, total = ts.taps * per_tap;
+        for (int base = 0; base < total; base += THREADS * SB) {
+            f32x4 v[SB];
+            int dst[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int idx = base + i * THREADS + tid;
+                v[i] = zero4();
+                dst[i] = -1;
+                if (idx < total) {
+                    int tap = 0, rem = idx;
+                    while (rem >= per_tap) { rem -= per_tap; ++tap; }
+                    const int r = fast_div(rem, c4n, c4sh), c4 = rem - r * c4n;
+                    dst[i] = r * lda + tap * ts.C + 4 * c4;
+                    if (row0 + r < ts.rows) {
+                        const RowCoord c = row_advance(ts, c0, r);
+                        v[i] = ld4(ts.src + ((size_t)(c.b * ts.Tsrc + c.t + tap) * ts.N + c.n) * ts.C + 4 * c4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i)
+                if (dst[i] >= 0) st4(At + dst[i], v[i]);
+        }
+        if (K < KP) {   // zero the K padding (K not a multiple of 16)
+            const int padw = KP - K;
+            for (int idx = tid; idx < TR * padw; idx += THREADS) {
+                const int r = idx / padw, q = idx - r * padw;
+                At[r * lda + K + q] = 0.f;
+            }
+        }
+    } else {   // narrow inputs (C = 1 for the first block): scalar gather of the K valid columns, zeros elsewhere
+        const int total = TR * KP;
+        for (int base = 0; base < total; base += THREADS * SB) {
+            float v[SB];
+            int dst[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int idx = base + i * THREADS + tid;
+                v[i] = 0.f;
+                dst[i] = -1;
+                if (idx < total) {
+                    const int r = idx / KP, q = idx - r * KP;
+                    dst[i] = r * lda + q;
+                    if (q < K && row0 + r < ts.rows) {
+                        const int tap = q / ts.C, ch = q - tap * ts.C;
+                        const RowCoord c = row_advance(ts, c0, r);
+                        v[i] = ts.src[((size_t)(c.b * ts.Tsrc + c.t + tap) * ts.N + c.n) * ts.C + ch];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i)
+                if (dst[i] >= 0) At[dst[i]] = v[i];
+        }
+    }
+}
+
+inline int tconv2_lds_floats(int kp, int nc, int rows) { return rows * ((kp > nc ? kp : nc) + 4); }
+
+template <int NT, int TM, int KC>
+__global__ __launch_bounds__(256) void tconv_fwd2_kernel(TconvFwdArgs a) {
+    constexpr int TR = TM * 16, THREADS = 256, COUT = 32 * NT, NC = 2 * COUT, C4N = COUT / 4, LDZ = NC + 4;
+    constexpr int NIT = TR * C4N / THREADS;   // epilogue iterations (TM * NT / 2)
+    static_assert(TR * C4N % THREADS == 0, "tile rows x channel quads must be a multiple of the workgroup size");
+    extern __shared__ float stgcn_smem[];
+    float* At = stgcn_smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
+    const int KCH = a.KCH, KP = KCH * 16, lda = KP + 4;
+    const bool do_align = a.Wap != nullptr;
+
+    STGCN_PHASE(1, 0);
+    // ---- 1. weights of the first round + bias: requested before anything else -----------------------------------
+    f32x4 wb[KC][NT];
+    auto load_round = [&](int kc0) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wb[kc][j] = (kc0 + kc < KCH) ? ld4(a.Wp + ((size_t)((wave + 4 * j) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
+    };
+    load_round(0);
+    const int c4 = tid & (C4N - 1);   // the channel quad of this thread in every epilogue iteration (256 % C4N == 0)
+    const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + COUT + 4 * c4);
+
+    STGCN_PHASE(1, 1);
+    // ---- 2. whole tile -> LDS ------------------------------------------------------------------------------------
+    stage_tile_fwd<TR, 8>(a.ts, row0, KP, At, lda);
+    STGCN_PHASE(1, 2);
+    __syncthreads();
+    STGCN_PHASE(1, 3);
+
+    // ---- 3. MFMA rounds ------------------------------------------------------------------------------------------
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+    const float* arow = At + l15 * lda + 4 * g;
+    for (int kc0 = 0; kc0 < KCH; kc0 += KC) {
+        if (kc0 > 0) load_round(kc0);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc0 + kc < KCH) {
+                f32x4 av[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = ld4(arow + i * 16 * lda + (kc0 + kc) * 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i][s], wb[kc][j][s], acc[i][j]);
+            }
+        }
+    }
+    STGCN_PHASE(1, 4);
+    // align weights (K = COUT: 2*NT chunks, one n-tile since c1 = 16): in flight while the accumulators go through LDS
+    f32x4 wa[2 * NT];
+    float bal = 0.f;
+    if (do_align && wave < TM) {
+#pragma unroll
+        for (int kc = 0; kc < 2 * NT; ++kc) wa[kc] = ld4(a.Wap + ((size_t)kc * 64 + lane) * 4);
+        bal = a.ba[l15];
+    }
+
+    // ---- 4. epilogue: accumulators -> LDS tile Zt[TR][NC + 4] -> row-major float4 pass (coalesced U/S/H stores) ----
+    float* Zt = At;
+    __syncthreads();   // every wave is done reading At
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * LDZ + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    STGCN_PHASE(1, 5);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = (tid + it * THREADS) / C4N;
+        const long R = row0 + row;
+        const f32x4 p = ld4(Zt + row * LDZ + 4 * c4), q = ld4(Zt + row * LDZ + COUT + 4 * c4);
+        f32x4 u, sg, h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i] = p[i] + bp[i];
+            sg[i] = sigmoid_f(q[i] + bq[i]);
+            h[i] = gate_fwd(u[i], sg[i], a.act);
+        }
+        if (R < a.ts.rows) {
+            const size_t o = (size_t)R * COUT + 4 * c4;
+            if (a.U) st4(a.U + o, u);
+            if (a.S) st4(a.S + o, sg);
+            if (a.H) st4(a.H + o, h);
+        }
+        if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
+            float sr = (h[0] + h[1]) + (h[2] + h[3]);
+#pragma unroll
+            for (int m = C4N >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
+            const float mr = sr / (float)COUT;
+            float d2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
+#pragma unroll
+            for (int m = C4N >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
+            if (c4 == 0 && R < a.ts.rows) a.rowstat[R] = make_float2(mr, d2);
+        }
+        if (do_align) st4(Zt + row * LDZ + 4 * c4, h);   // H tile in place of the P half
+    }
+    STGCN_PHASE(1, 6);
+    if (!do_align) return;
+    __syncthreads();
+    // ---- align epilogue: A[TR x 16] = H[TR x COUT] @ Wa + ba ; wave w (< TM) owns rows 16w..16w+15 ----------------
+    if (wave >= TM) return;
+    f32x4 c0 = zero4(), c1v = zero4();
+#pragma unroll
+    for (int kc = 0; kc < 2 * NT; ++kc) {
+        const f32x4 av = ld4(Zt + (wave * 16 + l15) * LDZ + kc * 16 + 4 * g);
+        c0 = mfma4(av[0], wa[kc][0], c0);
+        c1v = mfma4(av[1], wa[kc][1], c1v);
+        c0 = mfma4(av[2], wa[kc][2], c0);
+        c1v = mfma4(av[3], wa[kc][3], c1v);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long R = row0 + wave * 16 + 4 * g + r;
+        if (R < a.ts.rows) a.A[(size_t)R * a.c1 + l15] = c0[r] + c1v[r] + bal;
+    }
+    STGCN_PHASE(1, 7);
+}
+
+// ================================================================================================
+// F1 (v3, "time-complete tiles"): one workgroup owns 16 consecutive nodes of one window b for ALL time steps.
+// The input tile X[b, 0..Tsrc-1, n0..n0+15, :] (Tsrc*16 rows of C floats) is read from HBM exactly once into LDS; the
+// Kt taps of the temporal conv are row shifts INSIDE that tile (A operand of output step t, tap k = LDS rows
+// (t + k)*16 .. +16): no im2col copy, no re-reads of neighbouring time steps through L2, identical work per
+// workgroup (row tiles that straddle slabs made v1's workgroups differ 3x in backward).  Every wave keeps the
+// weight fragments of its n-tiles for the WHOLE K in registers (loaded once per workgroup: B * ceil(N/16) = 416
+// workgroups at C2 instead of 1242 tiles re-fetching 96 KB each) and walks the output steps in groups of MG m-tiles;
+// each group's accumulators go through a small LDS tile for the bias / sigmoid / GLU row pass with coalesced 16-byte
+// U, S stores, the LayerNorm row partials and the optional Align(c0 -> c1) GEMM, exactly like v1.
+// Template: WAVES (4 or 8), NT n-tiles per wave (NC = 16 * WAVES * NT), KCW = K/16 chunks held in registers, MG m-tiles
+// per group.  Requires C % 16 == 0 (the 1-channel first layer stays on v1).
+// ================================================================================================
+inline size_t tconv3_lds_bytes(int Tsrc, int C, int NC, int MG) { return ((size_t)Tsrc * 16 * (C + 4) + (size_t)MG * 16 * (NC + 4)) * sizeof(float); }
+
+#ifndef STGCN_V3_STAGGER
+#define STGCN_V3_STAGGER 0
+#endif
+template <int WAVES, int NT, int KCW, int MG>
+__global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, int node_tiles) {
+    constexpr int THREADS = WAVES * 64, NC = 16 * WAVES * NT, COUT = NC / 2, C4N = COUT / 4, LDZ = NC + 4;
+    constexpr int NIT = MG * 16 * C4N / THREADS;   // row-pass iterations per group
+    static_assert(MG * 16 * C4N % THREADS == 0 && THREADS % C4N == 0, "row pass must tile the workgroup");
+    extern __shared__ float stgcn_smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const TapSrc& ts = a.ts;
+    const int C = ts.C, ldx = C + 4, Tsrc = ts.Tsrc, Tdst = ts.Tdst, N = ts.N, cpt = C >> 4;   // cpt: K chunks per tap
+    const int item = xcd_item(blockIdx.x, gridDim.x);
+    const int b = item / node_tiles, n0 = (item - b * node_tiles) * 16;
+    float* Xt = stgcn_smem;                       // [Tsrc*16][ldx]
+    float* Zt = Xt + Tsrc * 16 * ldx;             // [MG*16][LDZ]
+    const int KCH = a.KCH;
+    const bool do_align = a.Wap != nullptr;
+
+    STGCN_PHASE(a.Wap ? 1 : 7, 0);
+    // ---- 1. weights of the whole K, bias, align weights -> registers (requested first) ---------------------------
+    f32x4 wb[KCW][NT];
+#pragma unroll
+    for (int q = 0; q < KCW; ++q)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            wb[q][j] = q < KCH ? ld4(a.Wp + ((size_t)((wave + WAVES * j) * KCH + q) * 64 + lane) * 4) : zero4();
+    const int c4 = tid & (C4N - 1);
+    const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + COUT + 4 * c4);
+    f32x4 wa[COUT / 16];
+    float bal = 0.f;
+    if (do_align && wave < MG) {
+#pragma unroll
+        for (int kc = 0; kc < COUT / 16; ++kc) wa[kc] = ld4(a.Wap + ((size_t)kc * 64 + lane) * 4);
+        bal = a.ba[l15];
+    }
+
+    STGCN_PHASE(a.Wap ? 1 : 7, 1);
+    // ---- 2. the input tile: all time steps of 16 nodes, once -----------------------------------------------------
+    {
+        const int c4n = C >> 2, c4sh = pow2_shift(c4n), total = Tsrc * 16 * c4n;
+        const float* xb = ts.src + (size_t)b * Tsrc * N * C;
+        for (int base = 0; base < total; base += THREADS * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * THREADS + tid;
+                v[i] = zero4();
+                if (idx < total) {
+                    const int row = fast_div(idx, c4n, c4sh), q4 = idx - row * c4n, t = row >> 4, nn = row & 15;
+                    if (n0 + nn < N) v[i] = ld4(xb + ((size_t)t * N + n0 + nn) * C + 4 * q4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + i * THREADS + tid;
+                if (idx < total) {
+                    const int row = fast_div(idx, c4n, c4sh), q4 = idx - row * c4n;
+                    st4(Xt + row * ldx + 4 * q4, v[i]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    STGCN_PHASE(a.Wap ? 1 : 7, 2);
+#if STGCN_V3_STAGGER > 0
+    // workgroups beyond the first 256 are the second residents of their CU: half a group period behind the first, so that
+    // one workgroup's row pass runs beside the other's MFMAs (experiment knob, units of 2048 cycles)
+    if (blockIdx.x >= 256)
+        for (int i = 0; i < STGCN_V3_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+
+    // ---- 3. output steps in groups of MG ----------------------------------------------------------------------------
+    for (int mg = 0; mg < Tdst; mg += MG) {
+        f32x4 acc[MG][NT];
+#pragma unroll
+        for (int i = 0; i < MG; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+#pragma unroll
+        for (int q = 0; q < KCW; ++q) {
+            if (q < KCH) {
+                const int tap = q / cpt, kc = q - tap * cpt;
+                f32x4 av[MG];
+#pragma unroll
+                for (int i = 0; i < MG; ++i) {
+                    int t = mg + i;
+                    if (t >= Tdst) t = Tdst - 1;   // padding m-tile of the last group: computed, never stored
+                    av[i] = ld4(Xt + ((t + tap) * 16 + l15) * ldx + kc * 16 + 4 * g);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MG; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i][s], wb[q][j][s], acc[i][j]);
+            }
+        }
+        if (mg == 0) STGCN_PHASE(a.Wap ? 1 : 7, 3);
+        if (mg > 0) __syncthreads();   // the previous group's readers of Zt are done
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = (wave + WAVES * j) * 16 + l15;
+#pragma unroll
+            for (int i = 0; i < MG; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * LDZ + col] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (mg == 0) STGCN_PHASE(a.Wap ? 1 : 7, 4);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (tid + it * THREADS) / C4N, t = mg + (row >> 4), nn = row & 15;
+            const bool valid = t < Tdst && n0 + nn < N;
+            const size_t R = ((size_t)b * Tdst + t) * N + n0 + nn;
+            const f32x4 p = ld4(Zt + row * LDZ + 4 * c4), q = ld4(Zt + row * LDZ + COUT + 4 * c4);
+            f32x4 u, sg, h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = p[i] + bp[i];
+                sg[i] = sigmoid_f(q[i] + bq[i]);
+                h[i] = gate_fwd(u[i], sg[i], a.act);
+            }
+            if (valid) {
+                const size_t o = R * COUT + 4 * c4;
+                if (a.U) st4(a.U + o, u);
+                if (a.S) st4(a.S + o, sg);
+                if (a.H) st4(a.H + o, h);
+            }
+            if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
+                float sr = (h[0] + h[1]) + (h[2] + h[3]);
+#pragma unroll
+                for (int m = C4N >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
+                const float mr = sr / (float)COUT;
+                float d2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
+#pragma unroll
+                for (int m = C4N >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
+                if (c4 == 0 && valid) a.rowstat[R] = make_float2(mr, d2);
+            }
+            if (do_align) st4(Zt + row * LDZ + 4 * c4, h);   // H tile in place of the P half
+        }
+        if (mg == 0) STGCN_PHASE(a.Wap ? 1 : 7, 5);
+        if (do_align) {
+            __syncthreads();
+            if (wave < MG && mg + wave < Tdst) {   // wave w: A[16 x 16] = H[m-tile w] @ Wa + ba
+                f32x4 c0 = zero4(), c1v = zero4();
+#pragma unroll
+                for (int kc = 0; kc < COUT / 16; ++kc) {
+                    const f32x4 av = ld4(Zt + (wave * 16 + l15) * LDZ + kc * 16 + 4 * g);
+                    c0 = mfma4(av[0], wa[kc][0], c0);
+                    c1v = mfma4(av[1], wa[kc][1], c1v);
+                    c0 = mfma4(av[2], wa[kc][2], c0);
+                    c1v = mfma4(av[3], wa[kc][3], c1v);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = 4 * g + r;
+                    if (n0 + nn < N) a.A[(((size_t)b * Tdst + mg + wave) * N + n0 + nn) * a.c1 + l15] = c0[r] + c1v[r] + bal;
+                }
+            }
+        }
+        if (mg == 0) STGCN_PHASE(a.Wap ? 1 : 7, 6);
+    }
+    STGCN_PHASE(a.Wap ? 1 : 7, 7);
+}
+
+// ================================================================================================
+// F1 (v4, wide outputs / few rows: the output head): row tile of 16*TM rows x NC = 256 columns, 8 waves (wave w owns
+// n-tiles w and w + 8), the whole im2col tile in LDS, and the weight fragments STREAMED in rounds of KC chunks through two
+// register buffers: the loads of round r+1 are in flight while the MFMAs of round r run.  With 16 x 256 outputs per tile a
+// workgroup moves 256 KB of weights through its CU's vector-memory path (~25 B/clk measured) for 8 K MFMA cycles: the head
+// conv is bound by that stream and by the L2 round trip per K chunk of v1 (profiles/r19_r33_experiments.md v44), so the
+// tile is 32 rows (half the weight bytes per row) and no MFMA ever waits for a load that was not requested a round ahead.
+// PLAIN = false: gated epilogue (bias, sigmoid, GLU, U / S stores, LayerNorm row partials) = the head's forward conv.
+// PLAIN = true : out[(b*outT + col / outC) * N + n][col % outC] = acc : the head's transposed conv, which for T1 = 1 is
+//                ONE dense GEMM dZ[B*N x NC] @ B[NC x Ko*Cin] (weights packed by PK_TCONV_BWDT) instead of Ko masked taps.
+// ================================================================================================
+struct Tconv4Args {
+    TconvFwdArgs f;     // ts, Wp, bias, KCH, Cout (NC = 2*Cout), act, U, S, rowstat (gated) -- H, align fields unused
+    float* out;         // PLAIN: destination tensor (B, outT, N, outC)
+    int outT, outC;
+};
+
+template <int TM, int KC, bool PLAIN>
+__global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
+    constexpr int WAVES = 8, NT = 2, THREADS = 512, TR = TM * 16, NC = 256, COUT = 128, LDZ = NC + 4;
+    const TconvFwdArgs& a = aa.f;
+    extern __shared__ float stgcn_smem[];
+    float* At = stgcn_smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
+    const int KCH = a.KCH, KP = KCH * 16, lda = KP + 4;
+
+    f32x4 wA[KC][NT], wB[KC][NT];
+    auto load_round = [&](f32x4 (&w)[KC][NT], int kc0) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                w[kc][j] = (kc0 + kc < KCH) ? ld4(a.Wp + ((size_t)((wave + WAVES * j) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
+    };
+    load_round(wA, 0);
+    stage_tile_fwd<TR, 4, THREADS>(a.ts, row0, KP, At, lda);
+    __syncthreads();
+
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
+    const float* arow = At + l15 * lda + 4 * g;
+    auto mma_round = [&](const f32x4 (&w)[KC][NT], int kc0) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc0 + kc < KCH) {
+                f32x4 av[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = ld4(arow + i * 16 * lda + (kc0 + kc) * 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i][s], w[kc][j][s], acc[i][j]);
+            }
+        }
+    };
+    for (int kc0 = 0; kc0 < KCH; kc0 += 2 * KC) {
+        if (kc0 + KC < KCH) load_round(wB, kc0 + KC);
+        mma_round(wA, kc0);
+        if (kc0 + 2 * KC < KCH) load_round(wA, kc0 + 2 * KC);
+        if (kc0 + KC < KCH) mma_round(wB, kc0 + KC);
+    }
+
+    // ---- epilogue through LDS: Zt[TR][NC + 4] -> row-major 16-byte stores ------------------------------------------
+    float* Zt = At;
+    __syncthreads();   // every wave is done reading At
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = (wave + WAVES * j) * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * LDZ + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    if constexpr (PLAIN) {
+        constexpr int Q4 = NC / 4, NIT = TR * Q4 / THREADS;   // float4 columns of the full row
+        const int q = tid & (Q4 - 1);
+        const int tap = (4 * q) / aa.outC, ci = 4 * q - tap * aa.outC;
+        const RowCoord c0 = row_coord(a.ts, row0 < a.ts.rows ? row0 : 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (tid + it * THREADS) / Q4;
+            if (row0 + row < a.ts.rows) {
+                const RowCoord c = row_advance(a.ts, c0, row);     // (b, t = 0, n) of the dZ row
+                st4(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, ld4(Zt + row * LDZ + 4 * q));
+            }
+        }
+    } else {
+        constexpr int C4N = COUT / 4, NIT = TR * C4N / THREADS;
+        const int c4 = tid & (C4N - 1);
+        const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + COUT + 4 * c4);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = (tid + it * THREADS) / C4N;
+            const long R = row0 + row;
+            const f32x4 p = ld4(Zt + row * LDZ + 4 * c4), q = ld4(Zt + row * LDZ + COUT + 4 * c4);
+            f32x4 u, sg, h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = p[i] + bp[i];
+                sg[i] = sigmoid_f(q[i] + bq[i]);
+                h[i] = gate_fwd(u[i], sg[i], a.act);
+            }
+            if (R < a.ts.rows) {
+                const size_t o = (size_t)R * COUT + 4 * c4;
+                if (a.U) st4(a.U + o, u);
+                if (a.S) st4(a.S + o, sg);
+                if (a.H) st4(a.H + o, h);
+            }
+            if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
+                float sr = (h[0] + h[1]) + (h[2] + h[3]);
+#pragma unroll
+                for (int m = C4N >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
+                const float mr = sr / (float)COUT;
+                float d2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
+#pragma unroll
+                for (int m = C4N >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
+                if (c4 == 0 && R < a.ts.rows) a.rowstat[R] = make_float2(mr, d2);
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // F2: graph convolution on one (b, t) slab  X0 = A[slab] (N x 16)
 //     X_k = T_k(L) X0, k = 1 .. terms-1                (layers.py:147-161; Kipf: X1 = L X0, layers.py:198)
 //     Y  = sum_k Xk Wk + bias                          (layers.py:165-168 / :199-202)
@@ -638,6 +1199,117 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         }
     }
     STGCN_PHASE(4, 15);
+}
+
+// ================================================================================================
+// F2 (operator-stationary variant): the fragments of T_1 .. T_{Ks-1} a wave needs for ITS node tile (KCH chunks per term,
+// 1 KiB each: 26 KiB for the 207-node graph, Ks = 3) are loaded into registers ONCE and the workgroup then walks `spw`
+// slabs: per MFMA of the slab-per-workgroup kernel a wave pulls 256 B of operator through its CU's vector-memory path
+// (~25 B/clk measured, i.e. the four SIMDs together are fed at 78 % of what their MFMAs consume, and every slab re-reads
+// the whole 340 KB operator from L2: 110 MB per launch at C2).  Here the operator crosses the L1 once per workgroup
+// (256 workgroups x 104 KiB), the per-slab traffic is the 13 KiB X0 slab (prefetched into registers one slab ahead,
+// double-buffered in LDS) and the MFMAs are fed from registers (B) and LDS (A).
+// grid = parts * groups; workgroup (part, grp) owns node tiles part + parts * wave and slabs grp*spw .. +spw.
+// Template: KCM >= KCH chunks per term held in registers, NTERM = Ks - 1 (1 or 2) operator terms.
+// ================================================================================================
+template <int KCM, int NTERM>
+__global__ __launch_bounds__(256) void gconv_fwd_reg_kernel(GconvFwdArgs a, int spw) {
+    extern __shared__ float stgcn_smem[];
+    constexpr int THREADS = 256;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int P = a.parts, part = (int)(blockIdx.x % (unsigned)P);
+    const long grp = blockIdx.x / (unsigned)P;
+    const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
+    const size_t MSZ = (size_t)NP * NP;
+    const int ht = part + P * (tid >> 6);   // this wave's node tile
+    const bool own = ht < HT;
+    const long s0 = grp * spw;
+    long s1 = s0 + spw;
+    if (s1 > a.slabs) s1 = a.slabs;
+
+    // ---- operator fragments of this wave's tile -> registers, weight fragments, bias -------------------------------
+    f32x4 Tr[NTERM][KCM];
+#pragma unroll
+    for (int k = 0; k < NTERM; ++k)
+#pragma unroll
+        for (int kc = 0; kc < KCM; ++kc)
+            Tr[k][kc] = (own && kc < KCH) ? ld4(a.Lp + (size_t)k * MSZ + ((size_t)(ht * KCH + kc) * 64 + lane) * 4) : zero4();
+    f32x4 wf[NTERM + 1];   // B[kk = c][col = j] = W_k[c = 4g + s][j = l15]
+#pragma unroll
+    for (int k = 0; k <= NTERM; ++k) {
+        wf[k] = zero4();
+        if (!(a.kipf && k == 0)) {
+            const float* Wk = a.W + (a.kipf ? 0 : (size_t)k * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wf[k][s] = Wk[(4 * g + s) * 16 + l15];
+        }
+    }
+    const float bb = a.bias ? a.bias[l15] : 0.f;
+
+    // ---- X0 slabs: registers (one slab ahead) -> LDS (two buffers), transposed [c][node] -------------------------------
+    constexpr int NV = 4;   // float4 per thread per slab (NP * 4 <= 1024, i.e. N <= 256)
+    f32x4 xv[NV];
+    auto fetch = [&](long slab) {
+        const float* Asl = a.A + (size_t)slab * N * 16;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS, n = idx >> 2, c4 = idx & 3;
+            xv[i] = (idx < NP * 4 && n < N) ? ld4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+        }
+    };
+    auto commit = [&](float* XT) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS, n = idx >> 2, c4 = idx & 3;
+            if (idx < NP * 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) XT[(c4 * 4 + j) * LDX + n] = xv[i][j];
+            }
+        }
+    };
+    if (s0 < s1) {
+        fetch(s0);
+        commit(stgcn_smem);
+    }
+    for (long slab = s0; slab < s1; ++slab) {
+        float* const XT0 = stgcn_smem + ((slab - s0) & 1) * 16 * LDX;
+        float* const XTn = stgcn_smem + (((slab - s0) & 1) ^ 1) * 16 * LDX;
+        if (slab + 1 < s1) fetch(slab + 1);
+        __syncthreads();   // XT0 complete; every wave is past its reads of XTn (previous slab)
+        if (own) {
+            const int h = ht * 16 + l15;
+            // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
+            const f32x4 res = ld4(XT0 + l15 * LDX + ht * 16 + 4 * g);
+            f32x4 yacc = zero4();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) yacc = mfma4(XT0[(4 * g + s) * LDX + h], wf[0][s], yacc);   // term 0: X0 W0
+            f32x4 acc[NTERM];
+#pragma unroll
+            for (int k = 0; k < NTERM; ++k) acc[k] = zero4();
+#pragma unroll
+            for (int kc = 0; kc < KCM; ++kc) {
+                if (kc < KCH) {
+                    const f32x4 af = ld4(XT0 + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int k = 0; k < NTERM; ++k) acc[k] = mfma4(af[s], Tr[k][kc][s], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NTERM; ++k) {   // acc[k][r] = X_{k+1}[h][c = 4g + r]
+                if (a.Xk && h < N) st4(a.Xk + (((size_t)k * a.slabs + slab) * N + h) * 16 + 4 * g, acc[k]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) yacc = mfma4(acc[k][s], wf[k + 1][s], yacc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = ht * 16 + 4 * g + r;
+                if (hh < N) a.G[((size_t)slab * N + hh) * 16 + l15] = fmaxf(yacc[r] + bb + res[r], 0.f);
+            }
+        }
+        if (slab + 1 < s1) commit(XTn);
+    }
 }
 
 // ================================================================================================

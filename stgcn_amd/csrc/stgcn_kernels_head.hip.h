@@ -231,4 +231,33 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
     }
 }
 
+// ================================================================================================
+// nn.MSELoss() (main.py:136, mean over all B*N elements) and its gradient in ONE launch:
+//     loss = mean((pred - y)^2) ;  dpred = 2 (pred - y) * grad_scale / n
+// The reference's loss + l.backward() head is 5 ATen launches (mse, mean, ones_like fill, mse_backward, scale) for 6624
+// elements; every launch of this path costs 5-8 us whatever its size.  One workgroup of 1024 threads, fixed summation
+// order (bitwise reproducible).
+// ================================================================================================
+__global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* pred, const float* y, long n, float gscale, float* loss,
+                                                              float* dpred) {
+    extern __shared__ float stgcn_smem[];   // [16] wave sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float k = 2.0f * gscale / (float)n;
+    float acc = 0.f;
+    for (long e = tid; e < n; e += 1024) {
+        const float d = pred[e] - y[e];
+        acc += d * d;
+        dpred[e] = k * d;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) stgcn_smem[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += stgcn_smem[w];
+        loss[0] = s / (float)n;
+    }
+}
+
 }  // namespace stgcn

@@ -54,7 +54,9 @@ class _STGCNBase(nn.Module):
         head = None
         if self.Ko > 1 and isinstance(self.output, OutputBlock) and ops.head_supported(self.output.cfg):
             head = (self.output.cfg, T, self.output._params(), self.output._ws)
-        ops.prepack_modules(blocks, head, x.shape[0], x.device)
+        # step counters a trainer asked to advance with the first launch of each TRAINING forward (train.GraphedTrainStep)
+        counters = getattr(self, "_step_counters", None) if self.training else None
+        ops.prepack_modules(blocks, head, x.shape[0], x.device, counters)
         return [b[3] for b in blocks] + ([head[3]] if head is not None else [])
 
     def forward(self, x):

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (HEAD_PARAM_FIELDS, PARAM_FIELDS, OutblockDesc, OutblockGrads, OutblockParams, OutblockPlan, StblockDesc,
+from ._lib import (HEAD_PARAM_FIELDS, PARAM_FIELDS, AdamwHyper, AdamwTensor, FlushBlock, OutblockDesc, OutblockGrads, OutblockParams, OutblockPlan, StblockDesc,
                    StblockGrads, StblockParams, StblockPlan)
 
 
@@ -51,7 +51,7 @@ def _check_device(t: torch.Tensor, what: str):
         raise RuntimeError(f"{what}: stgcn_amd runs on MI355X only (tensor is on {t.device}); there is no CPU fallback")
 
 
-def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False) -> StblockDesc:
+def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False) -> StblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")  # layers.py:117-118
     if cfg.graph_conv_type not in _lib.GRAPH_CONV:
@@ -68,6 +68,7 @@ def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, p
     d.need_dx = 1 if need_dx else 0
     d.reserved = int(cfg.tag)
     d.prepacked = 1 if prepacked else 0
+    d.defer_reduce = 1 if defer else 0
     return d
 
 
@@ -121,6 +122,70 @@ def dropout_mask(n: int, droprate: float, seed: int, offset: int, device, offset
     L.check(L.dll.stgcn_dropout_mask(out.data_ptr(), n, float(droprate), seed, offset, _optr(offset_dev), _stream_of(out)),
             "stgcn_dropout_mask")
     return out
+
+
+def mse_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``nn.MSELoss()(pred, target)`` (main.py:136/167) and d loss / d pred in one launch (stgcn_mse_loss_grad), outside
+    autograd: the trainer calls ``pred.backward(dpred)`` instead of ``loss.backward()`` (main.py:168), which removes the
+    five small ATen launches of the loss head.  Returns (loss[1], dpred like pred)."""
+    L = _lib.lib()
+    p = pred.detach()
+    _check_device(p, "pred")
+    if p.shape != target.shape or not p.is_contiguous() or not target.is_contiguous() or target.dtype != torch.float32:
+        raise ValueError(f"mse_loss_and_grad: contiguous float32 tensors of one shape expected, got {tuple(p.shape)} / {tuple(target.shape)}")
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    dpred = torch.empty_like(p)
+    L.check(L.dll.stgcn_mse_loss_grad(p.data_ptr(), target.data_ptr(), p.numel(), float(grad_scale), loss.data_ptr(), dpred.data_ptr(),
+                                      _stream_of(p)), "stgcn_mse_loss_grad")
+    return loss, dpred
+
+
+class GradSink:
+    """Whole-model gradient flush (``stgcn_grad_flush``).  While a sink is active (``grad_sink_scope``) the fused operators'
+    backward calls leave their per-workgroup gradient partials in the module workspaces, write NO parameter gradients and
+    return none to autograd; ``flush()`` then reduces the partials of every module of the step in ONE launch straight into
+    the sink's persistent gradient buffers (``grads[param]``, e.g. views of one flat data-parallel all-reduce buffer, which
+    the trainer also installs as ``param.grad``), optionally applying AdamW to each element as it is produced.  Three
+    reduce launches + the optimizer launch of a step become one."""
+
+    def __init__(self, grads: Dict[torch.nn.Parameter, torch.Tensor]):
+        self.by_ptr = {p.data_ptr(): g for p, g in grads.items()}
+        self.blocks = []          # (desc, grads struct, ws tensor, keep-alive)
+        self.head = None
+
+    def grad_for(self, p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if p is None else self.by_ptr.get(p.data_ptr())
+
+    def flush(self, opt_table=None, hyper: Optional[AdamwHyper] = None, stream: Optional[int] = None) -> None:
+        L = _lib.lib()
+        arr = (FlushBlock * max(len(self.blocks), 1))()
+        for i, (desc, gst, ws, _) in enumerate(self.blocks):
+            arr[i].desc, arr[i].grads, arr[i].ws = C.pointer(desc), C.pointer(gst), ws.data_ptr()
+        hd = hg = hws = None
+        if self.head is not None:
+            hd, hg, hws = C.byref(self.head[0]), C.byref(self.head[1]), self.head[2].data_ptr()
+        n_opt = 0 if opt_table is None else len(opt_table)
+        L.check(L.dll.stgcn_grad_flush(len(self.blocks), arr, hd, hg, hws, opt_table, n_opt, None if hyper is None else C.byref(hyper), stream),
+                "stgcn_grad_flush")
+        self.blocks, self.head = [], None
+
+
+_sink: Optional[GradSink] = None
+
+
+class grad_sink_scope:
+    def __init__(self, sink: Optional[GradSink]):
+        self.sink = sink
+
+    def __enter__(self):
+        global _sink
+        self.prev, _sink = _sink, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _sink
+        _sink = self.prev
+        return False
 
 
 _chain = 0
@@ -219,7 +284,8 @@ class _STBlockFn(torch.autograd.Function):
         params = [next(it) if pr else None for pr in ctx.param_present]
         cfg = ctx.cfg
         B, T, N, c_in = x_cl.shape
-        desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx)
+        sink = _sink
+        desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None)
         plan = query_plan(desc)
         dy = dy.contiguous()
         dev = x_cl.device
@@ -230,6 +296,10 @@ class _STBlockFn(torch.autograd.Function):
         for name, p, need in zip(PARAM_FIELDS, params, ctx.param_needs_grad):
             if p is None or not need or not used.get(name, True):
                 grads.append(None)
+            elif sink is not None:
+                grads.append(sink.grad_for(p))      # persistent buffer, filled by sink.flush()
+                if grads[-1] is None:
+                    raise RuntimeError(f"gradient sink has no buffer for parameter {name}")
             else:
                 grads.append(torch.empty_like(p))
         dx = torch.empty_like(x_cl) if ctx.need_dx else None
@@ -241,6 +311,9 @@ class _STBlockFn(torch.autograd.Function):
                                              None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _optr(ctx.offset_dev),
                                              _stream_of(x_cl)),
                 "stgcn_stblock_backward")
+        if sink is not None:
+            sink.blocks.append((desc, gst, ws, (grads, params)))
+            grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, None, None, *grads)
 
 
@@ -261,7 +334,7 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     return y_cl.permute(0, 3, 1, 2)
 
 
-def prepack_modules(blocks, head, B: int, device) -> None:
+def prepack_modules(blocks, head, B: int, device, counters=None) -> None:
     """One pack launch for a whole model step (stgcn_prepack): ``blocks`` is a list of (cfg, T_in, params, wsc) of the ST
     blocks in order, ``head`` is (cfg, T_in, params, wsc) or None.  Marks every workspace so that the module's next forward
     skips its own pack launch.  Parameters only change in optimizer.step(), so this runs once per forward of the model."""
@@ -289,7 +362,13 @@ def prepack_modules(blocks, head, B: int, device) -> None:
         keep += [hdesc, hpst, hps, hws_t]
         hd, hp, hws = C.byref(hdesc), C.byref(hpst), hws_t.data_ptr()
     stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else None
-    L.check(L.dll.stgcn_prepack(len(blocks), arr, hd, hp, hws, stream), "stgcn_prepack")
+    carr = None
+    if counters:
+        carr = (_lib.StepCounter * len(counters))()
+        for i, (t, inc, mod) in enumerate(counters):
+            assert t.dtype == torch.int64 and t.numel() == 1
+            carr[i].ptr, carr[i].inc, carr[i].mod = t.data_ptr(), int(inc), int(mod)
+    L.check(L.dll.stgcn_prepack(len(blocks), arr, hd, hp, hws, 0 if carr is None else len(counters), carr, stream), "stgcn_prepack")
     for _, _, _, wsc in blocks:
         wsc.prepacked = True
     if head is not None:
@@ -315,7 +394,7 @@ def head_supported(cfg: HeadConfig) -> bool:
             and (cfg.c_in % 4 == 0 or cfg.Ko * cfg.c_in <= 16))
 
 
-def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False) -> OutblockDesc:
+def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False) -> OutblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")
     d = OutblockDesc()
@@ -327,6 +406,7 @@ def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: boo
     d.droprate, d.ln_eps = float(cfg.droprate), float(cfg.ln_eps)
     d.need_dx = 1 if need_dx else 0
     d.prepacked = 1 if prepacked else 0
+    d.defer_reduce = 1 if defer else 0
     return d
 
 
@@ -383,18 +463,29 @@ class _OutBlockFn(torch.autograd.Function):
         params = [next(it) if pr else None for pr in ctx.param_present]
         cfg = ctx.cfg
         B, T, N, c_in = x_cl.shape
-        desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx)
+        sink = _sink
+        desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None)
         dout = dout.contiguous()
         used = {"tc_aw": c_in > cfg.channels[0], "tc_ab": c_in > cfg.channels[0]}
         grads = []
         for name, p, need in zip(HEAD_PARAM_FIELDS, params, ctx.param_needs_grad):
-            grads.append(torch.empty_like(p) if (p is not None and need and used.get(name, True)) else None)
+            if not (p is not None and need and used.get(name, True)):
+                grads.append(None)
+            elif sink is not None:
+                grads.append(sink.grad_for(p))
+                if grads[-1] is None:
+                    raise RuntimeError(f"gradient sink has no buffer for head parameter {name}")
+            else:
+                grads.append(torch.empty_like(p))
         dx = torch.empty_like(x_cl) if ctx.need_dx else None
         pst = _head_struct(OutblockParams, [None if p is None else p.detach() for p in params])
         gst = _head_struct(OutblockGrads, grads)
         L.check(L.dll.stgcn_outblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
                                               ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(), _stream_of(x_cl)),
                 "stgcn_outblock_backward")
+        if sink is not None:
+            sink.head = (desc, gst, ctx.ws, (grads, params))
+            grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, *grads)
 
 

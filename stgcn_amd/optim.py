@@ -31,6 +31,51 @@ class AdamW(torch.optim.Optimizer):
                 self._dev[gi][1].fill_(float(group["lr"]))
 
     @torch.no_grad()
+    def device_step_counter(self, device) -> torch.Tensor:
+        """The device-side step count of group 0 (capturable mode), created on first use.  A trainer that advances it
+        itself (e.g. on the weight-pack launch at the start of the step, ``stgcn_prepack`` counters) passes
+        ``bump_step=False`` to ``flush_with``."""
+        group = self.param_groups[0]
+        if 0 not in self._dev:
+            self._dev[0] = (torch.zeros(1, dtype=torch.int64, device=device), torch.full((1,), float(group["lr"]), device=device))
+        return self._dev[0][0]
+
+    def flush_with(self, sink, grads, bump_step: bool = True):
+        """``sink.flush()`` + ``step()`` in ONE launch (stgcn_grad_flush with the optimizer table): every gradient element is
+        reduced from the backward partials and consumed by AdamW on the spot.  ``grads``: {parameter: gradient buffer} of the
+        sink (all live parameters of the single param group); same arithmetic and state as ``step()``."""
+        from . import ops
+        assert len(self.param_groups) == 1, "flush_with handles one parameter group"
+        group = self.param_groups[0]
+        live = [p for p in group["params"] if p in grads]
+        assert len(live) == len(grads), "gradient sink holds parameters this optimizer does not own"
+        dev = live[0].device
+        table = (_lib.AdamwTensor * len(live))()
+        for i, p in enumerate(live):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("stgcn_amd.optim.AdamW handles contiguous float32 parameters only")
+            st = self.state[p]
+            if not st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            table[i].param, table[i].grad = p.data_ptr(), grads[p].data_ptr()
+            table[i].exp_avg, table[i].exp_avg_sq, table[i].numel = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+        hyper = _lib.AdamwHyper()
+        b1, b2 = group["betas"]
+        hyper.lr, hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay = float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"])
+        if self.capturable and dev.type == "cuda":
+            self.device_step_counter(dev)
+            step_t, lr_t = self._dev[0]
+            if bump_step:
+                step_t.add_(1)
+            hyper.step, hyper.step_dev, hyper.lr_dev = 0, step_t.data_ptr(), lr_t.data_ptr()
+        else:
+            group["_step"] = group.get("_step", 0) + 1
+            hyper.step, hyper.step_dev, hyper.lr_dev = group["_step"], None, None
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        sink.flush(table, hyper, stream)
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

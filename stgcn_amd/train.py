@@ -85,13 +85,66 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-3, weight_decay: float
     raise ValueError(f"ERROR: The {name} optimizer is undefined.")   # main.py:154
 
 
+def fwd_loss_bwd(model, x, y):
+    """forward -> MSELoss -> backward (main.py:166-168) with the loss and its gradient from ONE launch
+    (``ops.mse_loss_and_grad``): ``pred.backward(dpred)`` equals ``MSELoss()(pred, y).backward()``.  Returns the loss (shape [])."""
+    from . import ops
+    y_pred = model(x).reshape(len(x), -1)
+    loss, dpred = ops.mse_loss_and_grad(y_pred, y)
+    y_pred.backward(dpred)
+    return loss[0]
+
+
+class GradArena:
+    """One flat fp32 buffer holding the gradient of every live parameter (those the model actually uses: the reference
+    leaves ``.grad`` None for the 10 idle align convs) in ``model.parameters()`` order, with one view
+    per parameter installed as ``param.grad``.  It is at once the destination of ``ops.GradSink.flush`` (no per-step
+    gradient allocations, no autograd accumulation) and the data-parallel all-reduce buffer (no flatten / unflatten
+    copies around the collective)."""
+
+    def __init__(self, live_params: List[torch.nn.Parameter]):
+        from . import ops
+        self.params = list(live_params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.grads = {}
+        off = 0
+        for p in self.params:
+            self.grads[p] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.sink = ops.GradSink(self.grads)
+
+    def install(self):
+        for p, g in self.grads.items():
+            p.grad = g
+
+
+def fused_train_step(model, optimizer, x, y, arena: GradArena, world: int = 1, all_reduce=None):
+    """The loop body of main.py:165-169 with the step tail fused: forward -> one-launch MSE loss + gradient -> backward with
+    deferred reductions -> ONE launch for all gradient reductions + AdamW (world == 1), or reductions into the flat arena ->
+    ``all_reduce(arena.flat)`` -> AdamW (world > 1; the 1/world of the gradient mean rides on the loss gradient).
+    ``param.grad`` are the arena views (overwritten every step, never accumulated)."""
+    from . import ops
+    arena.install()
+    with ops.grad_sink_scope(arena.sink):
+        y_pred = model(x).reshape(len(x), -1)
+        loss, dpred = ops.mse_loss_and_grad(y_pred, y, grad_scale=1.0 / world)
+        y_pred.backward(dpred)
+    if world <= 1 and hasattr(optimizer, "flush_with"):
+        optimizer.flush_with(arena.sink, arena.grads)
+    else:
+        arena.sink.flush(stream=torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else None)
+        if world > 1 and all_reduce is not None:
+            all_reduce(arena.flat)
+        optimizer.step()
+    return loss[0]
+
+
 def train_step(model, optimizer, x, y, allreduce: Optional[FlatGradAllReduce] = None):
     """zero_grad -> forward -> MSELoss -> backward -> [all-reduce] -> optimizer.step (main.py:165-169).
     Returns the loss tensor (no host sync: the reference's per-step .item() at main.py:170 is deferred)."""
     optimizer.zero_grad(set_to_none=True)
-    y_pred = model(x).reshape(len(x), -1)
-    loss = torch.nn.functional.mse_loss(y_pred, y)
-    loss.backward()
+    loss = fwd_loss_bwd(model, x, y)
     if allreduce is not None:
         allreduce()
     optimizer.step()
@@ -153,16 +206,22 @@ class GraphedTrainStep:
       * the dropout offset comes from a device counter (``DropoutStream.use_device_counter``);
       * the optimizer is built ``capturable`` (device-side step counts).
     With world > 1 the step is split into two graphs around ONE eager RCCL all-reduce of the flat gradient
-    buffer (fwd+bwd+flatten | all-reduce | unflatten+AdamW).
+    buffer (fwd+bwd+reductions into the flat ``GradArena`` | all-reduce | AdamW).
+    ``fused`` (default on, ``STGCN_FUSED_STEP=0`` disables): the step tail of ``fused_train_step``.
     """
 
     def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3,
-                 chains: int = 1):
+                 chains: int = 1, fused: Optional[bool] = None):
         from .layers import DropoutStream
         assert x_example.is_cuda, "hipGraph capture needs the MI355X path"
         self.model, self.opt, self.world = model, optimizer, world
         dev = x_example.device
         self.chains = int(chains)                 # micro-batch chains on concurrent streams (chained_fwd_bwd)
+        if fused is None:
+            fused = os.environ.get("STGCN_FUSED_STEP", "1") != "0"
+        # fused step tail (GradArena / GradSink): one-launch loss, one launch for all gradient reductions + AdamW
+        self.fused = bool(fused) and self.chains == 1 and hasattr(optimizer, "flush_with")
+        self.arena: Optional[GradArena] = None
         self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.chains - 1)]
         self.x = torch.empty_like(x_example)
         self.y = torch.empty_like(y_example)
@@ -175,27 +234,47 @@ class GraphedTrainStep:
         self.flat = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        self.fold = False       # step counters advanced by the weight-pack launch instead of two tiny launches of their own
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._eager_once()
+            for i in range(max(warmup, 2 if self.fused else 1)):
+                if self.fused and i > 0:
+                    if self.arena is None:    # the first (unfused) step showed which parameters receive gradients
+                        self.arena = GradArena([p for p in model.parameters() if p.grad is not None])
+                        if world == 1:
+                            self._try_fold_counters(dev)     # (is itself one fused training step)
+                            continue
+                    self._eager_fused_once()
+                else:
+                    self._eager_once()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.opt.zero_grad(set_to_none=True)
+        if not self.fused:
+            self.opt.zero_grad(set_to_none=True)
         self.g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g1):
-            self.loss = self._fwd_bwd()
-            if world > 1:
-                self.live = [p for p in model.parameters() if p.grad is not None]
-                self.flat = torch.cat([p.grad.reshape(-1) for p in self.live])
+            if self.fused:
+                self.loss = self._fused_fwd_bwd()
+                if world > 1:
+                    self.flat = self.arena.flat
+                else:
+                    self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
+                    if not self.fold:
+                        DropoutStream.advance()
             else:
-                self.opt.step()
-                DropoutStream.advance()
+                self.loss = self._fwd_bwd()
+                if world > 1:
+                    self.live = [p for p in model.parameters() if p.grad is not None]
+                    self.flat = torch.cat([p.grad.reshape(-1) for p in self.live])
+                else:
+                    self.opt.step()
+                    DropoutStream.advance()
         self.g2 = None
         if world > 1:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2, pool=self.g1.pool()):
-                self.flat.mul_(1.0 / world)
-                torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
+                if not self.fused:
+                    self.flat.mul_(1.0 / world)
+                    torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
                 self.opt.step()
                 DropoutStream.advance()
         # one full replay inside the constructor: a capture / replay problem surfaces here (where the caller can
@@ -206,10 +285,47 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         if self.chains > 1:
             return chained_fwd_bwd(self.model, self.x, self.y, self.chains, self.streams)
-        y_pred = self.model(self.x).reshape(len(self.x), -1)
-        loss = torch.nn.functional.mse_loss(y_pred, self.y)
-        loss.backward()
-        return loss.detach()
+        return fwd_loss_bwd(self.model, self.x, self.y)
+
+    def _fused_fwd_bwd(self):
+        """forward, one-launch loss + gradient (carrying the 1/world of the gradient mean), backward with deferred reductions;
+        with world > 1 the reductions are flushed into the flat arena here (the all-reduce follows outside the graph)."""
+        from . import ops
+        self.arena.install()
+        with ops.grad_sink_scope(self.arena.sink):
+            y_pred = self.model(self.x).reshape(len(self.x), -1)
+            loss, dpred = ops.mse_loss_and_grad(y_pred, self.y, grad_scale=1.0 / self.world)
+            y_pred.backward(dpred)
+        if self.world > 1:
+            self.arena.sink.flush(stream=torch.cuda.current_stream(self.x.device).cuda_stream)
+        return loss[0]
+
+    def _try_fold_counters(self, dev):
+        """Let the model's weight-pack launch advance the dropout position and the optimizer step count; verified by one
+        eager step (a model whose forward does not go through stgcn_prepack keeps the explicit bumps)."""
+        from .layers import DropoutStream
+        step_t = self.opt.device_step_counter(dev)
+        self.model._step_counters = [(DropoutStream.counter, DropoutStream.SITE_STRIDE, 0), (step_t, 1, 0)]
+        c0, s0 = int(DropoutStream.counter.item()), int(step_t.item())
+        self.fold = True
+        self._eager_fused_once()
+        if int(DropoutStream.counter.item()) != c0 + DropoutStream.SITE_STRIDE or int(step_t.item()) != s0 + 1:
+            self.model._step_counters = None          # the pack launch did not run: advance them the explicit way
+            DropoutStream.counter.fill_(c0 + DropoutStream.SITE_STRIDE)
+            step_t.fill_(s0 + 1)
+            self.fold = False
+
+    def _eager_fused_once(self):
+        from .layers import DropoutStream
+        self._fused_fwd_bwd()
+        if self.world > 1:
+            dist.all_reduce(self.arena.flat)
+            self.opt.step()
+            DropoutStream.advance()
+        else:
+            self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
+            if not self.fold:
+                DropoutStream.advance()
 
     def _eager_once(self):
         from .layers import DropoutStream

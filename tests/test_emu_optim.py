@@ -52,3 +52,79 @@ def test_training_trajectory_with_fused_adamw_matches_reference_golden():
     for k, v in model.state_dict().items():
         if ("steps.param." + k) in fx:
             assert maxabs(v.numpy(), fx["steps.param." + k]) <= 1e-4, k
+
+
+def test_mse_loss_and_grad_matches_torch():
+    """stgcn_mse_loss_grad = nn.MSELoss() (main.py:136) + the gradient l.backward() feeds into the model output."""
+    from stgcn_amd import ops
+    from tests.emu_util import bind_emulator
+    bind_emulator()
+    g = torch.Generator().manual_seed(3)
+    for shape in ((8, 207), (3, 5), (32, 325)):
+        pred = torch.randn(*shape, generator=g)
+        y = torch.randn(*shape, generator=g)
+        loss, dpred = ops.mse_loss_and_grad(pred, y)
+        p = pred.clone().requires_grad_(True)
+        ref = torch.nn.MSELoss()(p, y)
+        ref.backward()
+        assert abs(float(loss[0]) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert float((dpred - p.grad).abs().max()) <= 1e-7 * float(p.grad.abs().max()) + 1e-12
+
+
+def test_fused_step_tail_equals_plain_step():
+    """train.fused_train_step (deferred reductions flushed by ONE stgcn_grad_flush launch with AdamW applied in place, gradients
+    in a flat GradArena) is bitwise the plain step (per-module reduce launches + stgcn_adamw_step) -- same partials, same
+    summation order, same optimizer arithmetic."""
+    import types
+    from stgcn_amd import models
+    from stgcn_amd.train import GradArena, fused_train_step, make_optimizer, train_step
+    from tests.emu_util import bind_emulator
+    from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture
+    bind_emulator()
+    fx = load_fixture("tiny_cheb_f32")
+    cfg = cfg_from_fixture(fx)
+    N, B = int(fx["n_vertex"]), int(fx["B"])
+
+    def build():
+        args = types.SimpleNamespace(Kt=cfg.Kt, Ks=cfg.Ks, act_func=cfg.act_func, graph_conv_type=cfg.graph_conv_type,
+                                     gso=torch.from_numpy(fixture_gso("tiny_cheb_f32", fx)), enable_bias=True, droprate=cfg.droprate, n_his=cfg.n_his)
+        m = models.STGCNChebGraphConv(args, cfg.blocks, N)
+        m.load_state_dict(fixture_params(fx, cfg, torch.float32), strict=True)
+        m.train()
+        return m, make_optimizer(m, lr=1e-2, weight_decay=1e-2)
+
+    g = torch.Generator().manual_seed(5)
+    xs = torch.randn(4, B, 1, cfg.n_his, N, generator=g)
+    ys = torch.randn(4, B, N, generator=g)
+    m1, o1 = build()
+    m2, o2 = build()
+    l1 = [float(train_step(m1, o1, xs[i], ys[i])) for i in range(4)]
+    l2 = [float(train_step(m2, o2, xs[0], ys[0]))]
+    arena = GradArena([p for p in m2.parameters() if p.grad is not None])
+    assert len(arena.params) == len([p for p in m1.parameters() if p.grad is not None])
+    l2 += [float(fused_train_step(m2, o2, xs[i], ys[i], arena)) for i in range(1, 4)]
+    assert l1 == l2, (l1, l2)
+    for (k, a), b in zip(m1.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert (p1.grad is None) == (p2.grad is None)
+        if p1.grad is not None:
+            assert torch.equal(p1.grad, p2.grad)
+            assert p2.grad.data_ptr() == arena.grads[p2].data_ptr()     # gradients live in the flat arena
+    # reduce-only flush (data-parallel path): gradients identical, parameters untouched until optimizer.step()
+    before = [p.detach().clone() for p in m2.parameters()]
+    from stgcn_amd import ops
+    arena.install()
+    with ops.grad_sink_scope(arena.sink):
+        pred = m2(xs[0]).reshape(B, -1)
+        _, dpred = ops.mse_loss_and_grad(pred, ys[0])
+        pred.backward(dpred)
+    arena.sink.flush()
+    for b, p in zip(before, m2.parameters()):
+        assert torch.equal(b, p.detach())
+    m1.zero_grad(set_to_none=True)
+    from stgcn_amd.train import fwd_loss_bwd
+    fwd_loss_bwd(m1, xs[0], ys[0])
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        if p1.grad is not None:
+            assert torch.equal(p1.grad, p2.grad)

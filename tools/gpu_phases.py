@@ -22,7 +22,7 @@ from tests.helpers import real_gso  # noqa: E402
 
 L = _lib.lib()
 dev = "cuda:0"
-NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd"}
+NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd", 7: "tconv_fwd(tc2, v3)"}
 
 
 def run_block(c_in, T):
@@ -32,7 +32,7 @@ def run_block(c_in, T):
                            droprate=0.5)
     gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev), ops.graph_terms(bcfg))
     params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", "cheb_graph_conv")]
-    x = torch.randn(32, c_in, T, 207, device=dev).requires_grad_(c_in > 1)
+    x = torch.randn(int(os.environ.get("STGCN_PHASE_B", "32")), c_in, T, 207, device=dev).requires_grad_(c_in > 1)
     wsc = ops.WorkspaceCache()
 
     def go():
@@ -101,5 +101,5 @@ KIDS = [int(k) for k in os.environ.get("STGCN_PHASE_KIDS", "1,2,3,4,6").split(",
 for kid in KIDS:
     report(kid, "blk1", go1)
 for kid in KIDS:
-    if kid in (1, 3, 4, 6):
+    if kid in (1, 3, 4, 6, 7):
         report(kid, "blk0", go0)
