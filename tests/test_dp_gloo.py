@@ -48,6 +48,11 @@ def _worker(rank, world, port, out):
     opt = make_optimizer(model)
     ar = FlatGradAllReduce(list(model.parameters()), world)
     loss = train_step(model, opt, xs, ys, ar)
+    # second step through the fused tail (what GraphedTrainStep captures for world > 1): deferred reductions flushed into the
+    # flat GradArena, ONE all-reduce of that buffer, 1/world carried by the loss gradient, then AdamW
+    from stgcn_amd.train import GradArena, fused_train_step
+    arena = GradArena([p for p in model.parameters() if p.grad is not None])
+    fused_train_step(model, opt, xs, ys, arena, world=world, all_reduce=dist.all_reduce)
     res = {"loss": float(loss), "grads": {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
            "params": {k: v.clone() for k, v in model.state_dict().items()}}
     if rank == 0:
@@ -65,6 +70,7 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     x, y = _data()
     opt = make_optimizer(model)
     train_step(model, opt, x, y, None)
+    train_step(model, opt, x, y, None)
     n_live = 0
     for k, p in model.named_parameters():
         if p.grad is None:
@@ -75,4 +81,4 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
         assert (got["grads"][k] - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), k
     assert n_live == 28        # 38 tensors, 10 unused align convs never get a gradient
     for k, v in model.state_dict().items():
-        assert (got["params"][k] - v).abs().max() <= 1e-6, k
+        assert (got["params"][k] - v).abs().max() <= 2e-6, k

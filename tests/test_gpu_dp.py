@@ -1,0 +1,80 @@
+"""-m gpu: the data-parallel captured step (two hipGraphs around one all-reduce of the flat gradient arena) on ONE GPU:
+two processes share cuda:0 and exchange through gloo (RCCL needs one GPU per rank; the collective itself is not what is
+tested here, the capture / replay / arena plumbing of GraphedTrainStep(world=2) is).  2 ranks x bs 4 == 1 process x bs 8."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import real_gso
+
+pytestmark = pytest.mark.gpu
+BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make():
+    from stgcn_amd import models
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    gso = torch.from_numpy(real_gso("metr_la.cheb_sym_norm_lap")).to("cuda:0")
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True,
+                                 droprate=0.0, n_his=12)
+    torch.manual_seed(1)
+    return models.STGCNChebGraphConv(args, BLOCKS, 207).to("cuda:0")
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    return torch.randn(4, 8, 1, 12, 207, generator=g), torch.randn(4, 8, 207, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model = _make()
+    opt = make_optimizer(model, capturable=True)
+    xs, ys = _data()
+    bl = xs.shape[1] // world
+    sl = slice(rank * bl, (rank + 1) * bl)
+    gs = GraphedTrainStep(model, opt, xs[0][sl].cuda(), ys[0][sl].cuda(), world=world, warmup=2)
+    assert gs.fused and gs.g2 is not None
+    for i in range(1, 4):
+        gs(xs[i][sl].cuda(), ys[i][sl].cuda())
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_graphed_step_equals_one_big_batch(tmp_path):
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import make_optimizer, train_step
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    DropoutStream.disable_device_counter()
+    model = _make()
+    opt = make_optimizer(model)
+    xs, ys = _data()
+    # the constructor trains on batch 0 three times (2 warm-up steps + 1 verification replay), then batches 1..3
+    for i in (0, 0, 0, 1, 2, 3):
+        train_step(model, opt, xs[i].cuda(), ys[i].cuda())
+    torch.cuda.synchronize()
+    worst = max(float((got[k] - v.cpu()).abs().max()) for k, v in model.state_dict().items())
+    assert worst <= 2e-5, worst
