@@ -144,7 +144,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("STGCN_CHAINS", "1")),
                     help="micro-batch chains of the minibatch run concurrently on separate HIP streams (train.chained_fwd_bwd)")
-    ap.add_argument("--chain-graphs", action="store_true", help="one hipGraph per chain, replayed on its own stream")
     args = ap.parse_args()
 
     from stgcn_amd import DropoutStream, _lib, models
@@ -182,11 +181,7 @@ def main():
     graph_err = None
     if use_graph:
         try:
-            if args.chain_graphs and world == 1:
-                from stgcn_amd.train import ChainGraphsTrainStep
-                graphed = ChainGraphsTrainStep(model, opt, *batch(0), chains=args.chains)
-            else:
-                graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains)
+            graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains)
 
             def run_step(xb, yb):
                 return graphed(xb, yb)

@@ -283,40 +283,6 @@ int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st
     }
     return STGCN_OK;
 }
-// v2 kernels (batched loads, weights in registers): tile rows 16*TM with 4 waves; KC = chunks per weight round
-template <int NT, int KC>
-int launch_tconv_fwd2_kc(const char* label, const TconvFwdArgs& a, hipStream_t st) {
-    static const int force_tr = getenv("STGCN_TCONV_TR") ? atoi(getenv("STGCN_TCONV_TR")) : 0;
-    constexpr int MAXTM = NT == 2 ? 4 : 2;
-    const int KP = a.KCH * 16, NC = 4 * a.Cout / 2;
-    int best = -1, best_rounds = 1 << 30;
-    for (int tm = 1; tm <= MAXTM; ++tm) {
-        const size_t lds = (size_t)tconv2_lds_floats(KP, NC, 16 * tm) * sizeof(float);
-        int cap;
-        switch (tm) {
-            case 1: cap = wg_capacity(tconv_fwd2_kernel<NT, 1, KC>, 256, lds); break;
-            case 2: cap = wg_capacity(tconv_fwd2_kernel<NT, 2, KC>, 256, lds); break;
-            case 3: cap = wg_capacity(tconv_fwd2_kernel<NT, (MAXTM >= 3 ? 3 : 1), KC>, 256, lds); break;
-            default: cap = wg_capacity(tconv_fwd2_kernel<NT, (MAXTM >= 4 ? 4 : 1), KC>, 256, lds); break;
-        }
-        const int r = rounds_of(cdiv(a.ts.rows, 16 * tm), cap);
-        if (force_tr ? 16 * tm == force_tr : r < best_rounds) {
-            best = tm;
-            best_rounds = r;
-            if (force_tr) break;
-        }
-    }
-    if (best < 0) best = 2;
-    const dim3 grid(cdiv(a.ts.rows, 16 * best));
-    const size_t lds = (size_t)tconv2_lds_floats(KP, NC, 16 * best) * sizeof(float);
-    switch (best) {
-        case 1: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, 1, KC>), grid, dim3(256), lds, a); break;
-        case 2: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, 2, KC>), grid, dim3(256), lds, a); break;
-        case 3: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, (MAXTM >= 3 ? 3 : 1), KC>), grid, dim3(256), lds, a); break;
-        default: STGCN_LAUNCH(label, st, (tconv_fwd2_kernel<NT, (MAXTM >= 4 ? 4 : 1), KC>), grid, dim3(256), lds, a); break;
-    }
-    return STGCN_OK;
-}
 // v3 kernels (time-complete tiles: one workgroup = 16 nodes x all time steps of one window, weights of the whole K in registers)
 template <int WAVES, int NT, int KCW>
 int launch_tconv_fwd3(const char* label, const TconvFwdArgs& a, hipStream_t st) {
@@ -347,7 +313,7 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
         aa.f = a;
         return launch_tconv_fwd4<false>(label, aa, st);
     }
-    static const int ver = getenv("STGCN_TCONV_V") ? atoi(getenv("STGCN_TCONV_V")) : 1;   // 1: row tiles, per-chunk loads (fastest at C2); 2: row tiles, batched loads; 3: time-complete tiles
+    static const int ver = getenv("STGCN_TCONV_V") ? atoi(getenv("STGCN_TCONV_V")) : 1;   // 1: row tiles (fastest at C2); 3: time-complete tiles (opt-in)
     if (ver == 3 && (a.ts.C & 15) == 0 && a.KCH * 16 == a.ts.taps * a.ts.C && a.c1 == 16 * (a.Wap ? 1 : a.c1 / 16) &&
         tconv3_lds_bytes(a.ts.Tsrc, a.ts.C, 2 * a.Cout, 2) <= 64 * 1024) {
         if (a.Cout == 64 && a.KCH <= 3) return launch_tconv_fwd3<4, 2, 3>(label, a, st);
@@ -355,9 +321,7 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
         if (a.Cout == 128 && a.KCH <= 4) return launch_tconv_fwd3<8, 2, 4>(label, a, st);
         if (a.Cout == 128 && a.KCH <= 16) return launch_tconv_fwd3<8, 2, 16>(label, a, st);
     }
-    if (ver == 1) return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
-    if (a.Cout == 64) return a.KCH <= 4 ? launch_tconv_fwd2_kc<2, 4>(label, a, st) : launch_tconv_fwd2_kc<2, 12>(label, a, st);
-    return a.KCH <= 4 ? launch_tconv_fwd2_kc<4, 4>(label, a, st) : launch_tconv_fwd2_kc<4, 8>(label, a, st);
+    return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
 }
 
 // graph-conv launch geometry: a (b, t) slab is split over `parts` workgroups (part p owns node tiles p, p + parts, ..) of

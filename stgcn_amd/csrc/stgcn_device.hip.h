@@ -68,8 +68,9 @@ __device__ __forceinline__ int xcd_item(int b, int n) {
 __device__ __forceinline__ int pow2_shift(int d) { return (d > 0 && (d & (d - 1)) == 0) ? 31 - __builtin_clz((unsigned)d) : -1; }
 __device__ __forceinline__ int fast_div(int x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
 
-// v_exp_f32 + v_rcp_f32 (1 ulp each): a full-precision IEEE divide costs ~10 instructions per element in the epilogues
-__device__ __forceinline__ float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each), 4 instructions.  (__frcp_rn / "1.0f / x" expand to the 11-instruction IEEE divide
+// sequence, __expf to a range-reduced polynomial: together they were a quarter of the gated conv's row pass.)
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
 
 // ---- gate math (reference model/layers.py:105 GLU, :109 GTU) --------------------------------
 // forward: h = act(u) * s ; act = identity (glu) or tanh (gtu)

@@ -497,19 +497,11 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 }
 
 // ================================================================================================
-// F1 (v2): the same gated temporal convolution with a SHORT dependent-latency chain per workgroup.
-// The C2 launches of this path are 10-40 us long with a handful of workgroups per CU, so a workgroup's run time is the
-// sum of its dependent memory round trips, not its FLOPs (profiles/r40_batch_sweep.log: half of the step time is
-// independent of the batch size).  v1 staged a tile with a load -> wait -> LDS-store loop (one HBM round trip per 16 B
-// and thread) and fetched the weight fragments of every K chunk inside the MFMA loop (one L2 round trip per chunk).
-// Here every global load a phase needs is ISSUED before the first wait:
-//   1. weight fragments of a whole round of KC chunks (the entire K for the ST blocks) + bias -> registers,
-//   2. the whole im2col tile [TR x K] (all taps) -> registers -> LDS in batches of SB 16-byte loads per thread; row
-//      coordinates are computed in registers (no LDS row table, no barrier before the loads),
-//   3. MFMA loop fed from registers (B) and LDS (A) only,
-//   4. the align weights are requested before the accumulators go through LDS, the epilogue loop is unrolled.
-// Template: NT n-tiles per wave (NC = 64*NT, Cout = 32*NT), TM m-tiles (rows = 16*TM, shared by the 4 waves),
-// KC chunks of 16 K-columns per weight round.
+// Batched whole-tile staging (used by the wide-output kernels below): every global load of the im2col tile [TR x K] (all
+// taps) is ISSUED before the first wait, SB 16-byte loads per thread in flight, row coordinates computed in registers (no
+// LDS row table, no barrier before the loads).  The row-tile kernel above stages with a load -> wait -> LDS-store loop,
+// which the many co-resident workgroups of the ST-block shapes hide; a variant of it with these batched loads and the
+// weights of a whole K round in registers was faster only at tiny batch sizes (profiles/r19_r33_experiments.md v42).
 // ================================================================================================
 // (b, t, n) of a flat output row of a tap source, two 32-bit divisions (once per thread)
 struct RowCoord { int b, t, n; };
@@ -595,140 +587,6 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
 }
 
 inline int tconv2_lds_floats(int kp, int nc, int rows) { return rows * ((kp > nc ? kp : nc) + 4); }
-
-template <int NT, int TM, int KC>
-__global__ __launch_bounds__(256) void tconv_fwd2_kernel(TconvFwdArgs a) {
-    constexpr int TR = TM * 16, THREADS = 256, COUT = 32 * NT, NC = 2 * COUT, C4N = COUT / 4, LDZ = NC + 4;
-    constexpr int NIT = TR * C4N / THREADS;   // epilogue iterations (TM * NT / 2)
-    static_assert(TR * C4N % THREADS == 0, "tile rows x channel quads must be a multiple of the workgroup size");
-    extern __shared__ float stgcn_smem[];
-    float* At = stgcn_smem;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
-    const int KCH = a.KCH, KP = KCH * 16, lda = KP + 4;
-    const bool do_align = a.Wap != nullptr;
-
-    STGCN_PHASE(1, 0);
-    // ---- 1. weights of the first round + bias: requested before anything else -----------------------------------
-    f32x4 wb[KC][NT];
-    auto load_round = [&](int kc0) {
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                wb[kc][j] = (kc0 + kc < KCH) ? ld4(a.Wp + ((size_t)((wave + 4 * j) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
-    };
-    load_round(0);
-    const int c4 = tid & (C4N - 1);   // the channel quad of this thread in every epilogue iteration (256 % C4N == 0)
-    const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + COUT + 4 * c4);
-
-    STGCN_PHASE(1, 1);
-    // ---- 2. whole tile -> LDS ------------------------------------------------------------------------------------
-    stage_tile_fwd<TR, 8>(a.ts, row0, KP, At, lda);
-    STGCN_PHASE(1, 2);
-    __syncthreads();
-    STGCN_PHASE(1, 3);
-
-    // ---- 3. MFMA rounds ------------------------------------------------------------------------------------------
-    f32x4 acc[TM][NT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-    const float* arow = At + l15 * lda + 4 * g;
-    for (int kc0 = 0; kc0 < KCH; kc0 += KC) {
-        if (kc0 > 0) load_round(kc0);
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            if (kc0 + kc < KCH) {
-                f32x4 av[TM];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = ld4(arow + i * 16 * lda + (kc0 + kc) * 16);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i][s], wb[kc][j][s], acc[i][j]);
-            }
-        }
-    }
-    STGCN_PHASE(1, 4);
-    // align weights (K = COUT: 2*NT chunks, one n-tile since c1 = 16): in flight while the accumulators go through LDS
-    f32x4 wa[2 * NT];
-    float bal = 0.f;
-    if (do_align && wave < TM) {
-#pragma unroll
-        for (int kc = 0; kc < 2 * NT; ++kc) wa[kc] = ld4(a.Wap + ((size_t)kc * 64 + lane) * 4);
-        bal = a.ba[l15];
-    }
-
-    // ---- 4. epilogue: accumulators -> LDS tile Zt[TR][NC + 4] -> row-major float4 pass (coalesced U/S/H stores) ----
-    float* Zt = At;
-    __syncthreads();   // every wave is done reading At
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = (wave + 4 * j) * 16 + l15;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * LDZ + col] = acc[i][j][r];
-    }
-    __syncthreads();
-    STGCN_PHASE(1, 5);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int row = (tid + it * THREADS) / C4N;
-        const long R = row0 + row;
-        const f32x4 p = ld4(Zt + row * LDZ + 4 * c4), q = ld4(Zt + row * LDZ + COUT + 4 * c4);
-        f32x4 u, sg, h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u[i] = p[i] + bp[i];
-            sg[i] = sigmoid_f(q[i] + bq[i]);
-            h[i] = gate_fwd(u[i], sg[i], a.act);
-        }
-        if (R < a.ts.rows) {
-            const size_t o = (size_t)R * COUT + 4 * c4;
-            if (a.U) st4(a.U + o, u);
-            if (a.S) st4(a.S + o, sg);
-            if (a.H) st4(a.H + o, h);
-        }
-        if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
-            float sr = (h[0] + h[1]) + (h[2] + h[3]);
-#pragma unroll
-            for (int m = C4N >> 1; m >= 1; m >>= 1) sr += __shfl_xor(sr, m);
-            const float mr = sr / (float)COUT;
-            float d2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
-#pragma unroll
-            for (int m = C4N >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
-            if (c4 == 0 && R < a.ts.rows) a.rowstat[R] = make_float2(mr, d2);
-        }
-        if (do_align) st4(Zt + row * LDZ + 4 * c4, h);   // H tile in place of the P half
-    }
-    STGCN_PHASE(1, 6);
-    if (!do_align) return;
-    __syncthreads();
-    // ---- align epilogue: A[TR x 16] = H[TR x COUT] @ Wa + ba ; wave w (< TM) owns rows 16w..16w+15 ----------------
-    if (wave >= TM) return;
-    f32x4 c0 = zero4(), c1v = zero4();
-#pragma unroll
-    for (int kc = 0; kc < 2 * NT; ++kc) {
-        const f32x4 av = ld4(Zt + (wave * 16 + l15) * LDZ + kc * 16 + 4 * g);
-        c0 = mfma4(av[0], wa[kc][0], c0);
-        c1v = mfma4(av[1], wa[kc][1], c1v);
-        c0 = mfma4(av[2], wa[kc][2], c0);
-        c1v = mfma4(av[3], wa[kc][3], c1v);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long R = row0 + wave * 16 + 4 * g + r;
-        if (R < a.ts.rows) a.A[(size_t)R * a.c1 + l15] = c0[r] + c1v[r] + bal;
-    }
-    STGCN_PHASE(1, 7);
-}
 
 // ================================================================================================
 // F1 (v3, "time-complete tiles"): one workgroup owns 16 consecutive nodes of one window b for ALL time steps.

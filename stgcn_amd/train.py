@@ -348,79 +348,3 @@ class GraphedTrainStep:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.g2.replay()
         return self.loss
-
-
-class ChainGraphsTrainStep:
-    """The training step as ``chains`` micro-batch chains, each captured into its OWN single-stream hipGraph and replayed on
-    its own HIP stream (so the chains' kernels can be resident on the GPU together), followed by a tail graph on the main
-    stream (fixed-order gradient sum, AdamW, dropout-counter bump).  Single GPU only.  A hipGraph with parallel branches
-    (``GraphedTrainStep(chains=k)``) measured slower than one chain on ROCm 7.2 (branches are not overlapped); independent
-    graphs on independent streams leave the overlap to the hardware queues."""
-
-    def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, chains: int = 2, warmup: int = 3):
-        from . import ops
-        from .layers import DropoutStream
-        assert x_example.is_cuda and chains >= 1 and len(x_example) % chains == 0
-        self.model, self.opt, self.chains = model, optimizer, int(chains)
-        dev = x_example.device
-        self.x, self.y = x_example.clone(), y_example.clone()
-        if DropoutStream.counter is None or DropoutStream.counter.device != dev:
-            DropoutStream.use_device_counter(dev)
-        self.counter = DropoutStream.counter
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.chains)]
-        Bc = len(self.x) // self.chains
-
-        def chain_body(c):
-            with ops.chain_scope(c):
-                xc, yc = self.x[c * Bc:(c + 1) * Bc], self.y[c * Bc:(c + 1) * Bc]
-                loss = torch.nn.functional.mse_loss(self.model(xc).reshape(Bc, -1), yc) * (1.0 / self.chains)
-                return loss.detach(), torch.autograd.grad(loss, self.params, allow_unused=True)
-
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                outs = [chain_body(c) for c in range(self.chains)]
-                self._tail(outs)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graphs, outs = [], []
-        for c in range(self.chains):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs.append(chain_body(c))
-            self.graphs.append(g)
-        self.tail = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.tail):
-            self.loss = self._tail(outs)
-        self(x_example, y_example)
-        torch.cuda.synchronize(dev)
-
-    def _tail(self, outs):
-        from .layers import DropoutStream
-        live = [i for i, g in enumerate(outs[0][1]) if g is not None]
-        acc = [outs[0][1][i] for i in live]
-        for c in range(1, self.chains):
-            torch._foreach_add_(acc, [outs[c][1][i] for i in live])
-        for i, g in zip(live, acc):
-            self.params[i].grad = g
-        self.opt.step()
-        DropoutStream.advance()
-        total = outs[0][0]
-        for l, _ in outs[1:]:
-            total = total + l
-        return total
-
-    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        main = torch.cuda.current_stream(self.x.device)
-        self.x.copy_(x, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
-        for s, g in zip(self.streams, self.graphs):
-            s.wait_stream(main)
-            with torch.cuda.stream(s):
-                g.replay()
-        for s in self.streams:
-            main.wait_stream(s)
-        self.tail.replay()
-        return self.loss
