@@ -323,6 +323,40 @@ __device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, i
     }
 }
 
+// Weight fragments of a WHOLE (small) K held in registers, requested in one batch at kernel start: kernels with a couple
+// of workgroups per CU (the head's fc GEMMs) cannot hide one L2 round trip per K chunk behind other waves.
+template <int NT, int KMAX>
+struct PreW {
+    f32x4 b[KMAX][NT];
+};
+template <int NT, int KMAX>
+__device__ __forceinline__ void pre_load_weights(PreW<NT, KMAX>& w, const float* Wp, int KCH, int nt0, int nts) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kc = 0; kc < KMAX; ++kc)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) w.b[kc][j] = kc < KCH ? ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc) * 64 + lane) * 4) : zero4();
+}
+template <int WM, int NT, int KMAX>
+__device__ __forceinline__ void pre_mma(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int KCH, const PreW<NT, KMAX>& w) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = At + (mt0 * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
+#pragma unroll
+    for (int kc = 0; kc < KMAX; ++kc) {
+        if (kc < KCH) {
+            f32x4 a[WM];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], w.b[kc][j][s], acc[i][j]);
+        }
+    }
+}
+
 // LDS carve for the row-tile GEMM kernels (floats): [rowbase 64 ints][rowt 64 ints][4 scratch words][At 64 x (kSegMax+4)]
 constexpr int kTileHdr = 132;
 // (tconv_fwd re-uses At as its [64][NC + 4] epilogue tile: tile_lds_floats(NC))

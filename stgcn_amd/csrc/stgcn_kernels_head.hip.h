@@ -34,22 +34,21 @@ template <int WM>
 __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     constexpr int TR = WM * 16, NT = 2;
     extern __shared__ float stgcn_smem[];
-    int* rowbase = reinterpret_cast<int*>(stgcn_smem);
-    int* rowt = rowbase + 64;
     float* At = stgcn_smem + kTileHdr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
     const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
-    tile_rowinfo<TR>(a.ts, row0, rowbase, rowt);
-    __syncthreads();
-    const int KP = a.KCH * 16;   // = c0 <= 128: one segment
-    tile_load_segment<TR>(a.ts, rowbase, rowt, 0, KP, At, KP + 4);
+    const int KP = a.KCH * 16;   // = c0 <= 128
+    // every load of the tile is requested up front: the fc1 weight fragments of the whole K (<= 8 chunks), then the rows
+    PreW<NT, 8> w;
+    pre_load_weights<NT, 8>(w, a.W1p, a.KCH, wave, 4);
+    stage_tile_fwd<TR, 4>(a.ts, row0, KP, At, KP + 4);
     __syncthreads();
     f32x4 acc[WM][NT];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-    seg_mma<WM, NT>(acc, At, KP + 4, 0, a.KCH, a.W1p, 0, a.KCH, wave, 4);
+    pre_mma<WM, NT, 8>(acc, At, KP + 4, 0, a.KCH, w);
     __syncthreads();
     const int c1 = a.c1, ldz = c1 + 4;
     float* Zt = At;
@@ -124,6 +123,8 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
     f32x4 dw2 = zero4();
     float db2 = 0.f;
     const f32x4 w2 = ld4(a.w2 + 4 * c4);
+    PreW<NT, 8> w;   // fc1 weight fragments of the whole K = c1 (8 chunks), requested before the first tile is touched
+    pre_load_weights<NT, 8>(w, a.W1d, a.KCH, wave, 4);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * TR;
         __syncthreads();
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-        seg_mma<WM, NT>(acc, At, lda, 0, a.KCH, a.W1d, 0, a.KCH, wave, 4);
+        pre_mma<WM, NT, 8>(acc, At, lda, 0, a.KCH, w);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = (wave + 4 * j) * 16 + l15;
