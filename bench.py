@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
+N_PRED = 12                         # C2 is "12 -> 12": n_his 12, n_pred 12
 N_HIS, KT, KS, B_LOCAL = 12, 3, 3, int(os.environ.get("STGCN_BENCH_B", "32"))   # (env: batch-size sweeps of tools/, not the headline)
 BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
 
@@ -142,6 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-resident-series", action="store_true",
+                    help="feed (num, 1, n_his, N) window tensors copied per step instead of device-side windows of a resident series")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("STGCN_CHAINS", "1")),
                     help="micro-batch chains of the minibatch run concurrently on separate HIP streams (train.chained_fwd_bwd)")
     args = ap.parse_args()
@@ -176,15 +179,21 @@ def main():
         s = (i % n_batches) * B_LOCAL * world + rank * B_LOCAL
         return x_all[s:s + B_LOCAL], y_all[s:s + B_LOCAL]
 
+    # the same amount of data as ONE resident (time, N) series (z-scored synthetic speeds): the captured step windows it on
+    # the device (script/dataloader.py:32-47 without the 12x replicated tensor and without per-step input copies)
+    resident = use_graph and not args.no_resident_series and args.chains == 1
+    series = torch.randn(n_batches * B_LOCAL * world + N_HIS + N_PRED - 1, N, generator=g).to(dev) if resident else None
+
     model.train()
     step_i = 0
     graph_err = None
     if use_graph:
         try:
-            graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains)
+            graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains, series=series, n_his=N_HIS, n_pred=N_PRED,
+                                       rank=rank)
 
             def run_step(xb, yb):
-                return graphed(xb, yb)
+                return graphed() if resident else graphed(xb, yb)
         except Exception as e:  # noqa: BLE001  -- same HIP path, just launched eagerly
             graph_err = repr(e)
             use_graph = False
@@ -233,7 +242,9 @@ def main():
                       "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
                       "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
                       "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err,
-                      "chains": args.chains if use_graph else 1}}
+                      "chains": args.chains if use_graph else 1,
+                      "input": ("device-side windows (n_his 12, n_pred 12) of a resident (time, N) series, batch position on the device"
+                                if (resident and use_graph) else "(num, 1, n_his, N) window tensors, one batch copied per step")}}
 
     if rank == 0 and not args.no_profile:
         # per-kernel durations with hipEvents on the launch stream, over the same K steps (second pass)

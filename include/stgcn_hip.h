@@ -54,6 +54,14 @@ typedef struct stgcn_stblock_desc {
     int32_t reserved;         /* free-form tag (e.g. block index); only used to label the built-in kernel timer   */
     int32_t prepacked;        /* 1: stgcn_prepack already rewrote this call's weights into ws (forward skips its pack launch) */
     int32_t defer_reduce;     /* backward: 1 = leave the per-workgroup gradient partials in ws; stgcn_grad_flush reduces them     */
+    /* Device-side windowing (script/dataloader.py:32-47 builds a (num, 1, n_his, N) tensor that repeats every time step n_his
+     * times; here the first block can read its windows straight from the resident (time, N) series): window b of `x` starts
+     * x_bstride ROWS (of c_in floats) after window b-1 (0 = dense, T*N; N = windows one time step apart), and the whole input
+     * is shifted by *x_index_dev * x_index_stride floats (nullable: the batch position of a captured training step).
+     * Only for blocks whose input needs no gradient (need_dx = 0).                                                          */
+    int64_t x_bstride;
+    const int64_t* x_index_dev;
+    int64_t x_index_stride;
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -252,8 +260,10 @@ int stgcn_grad_flush(int32_t n_blocks, const stgcn_flush_block* blocks, const st
 /* ---- Loss: nn.MSELoss() as main.py:136 builds it (mean over all n = B*N elements) together with the gradient that
  *      l.backward() (main.py:168) feeds into the model output, in one launch:
  *          loss[0] = mean((pred - target)^2) ;  dpred[i] = 2 (pred[i] - target[i]) * grad_scale / n
- *      grad_scale = 1 for the reference's loop (1/k for a minibatch processed as k micro-batches).                        */
-int stgcn_mse_loss_grad(const float* pred, const float* target, int64_t n, float grad_scale, float* loss, float* dpred, void* stream);
+ *      grad_scale = 1 for the reference's loop (1/k for a minibatch processed as k micro-batches).  target is read at
+ *      target + *target_index_dev * target_index_stride floats (nullable: labels taken from the resident series).        */
+int stgcn_mse_loss_grad(const float* pred, const float* target, int64_t n, float grad_scale, float* loss, float* dpred,
+                        const int64_t* target_index_dev, int64_t target_index_stride, void* stream);
 
 /* Built-in kernel timer (no reference counterpart; feeds bench.py's roofline object).  While enabled,
  * every kernel launch is bracketed by a hipEvent pair on the launch stream.  collect() synchronises on the

@@ -26,7 +26,8 @@ class StblockDesc(C.Structure):
                 ("c0", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32), ("Kt", C.c_int32), ("Ks", C.c_int32),
                 ("act", C.c_int32), ("graph_conv", C.c_int32), ("training", C.c_int32),
                 ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32),
-                ("prepacked", C.c_int32), ("defer_reduce", C.c_int32)]
+                ("prepacked", C.c_int32), ("defer_reduce", C.c_int32),
+                ("x_bstride", C.c_int64), ("x_index_dev", C.c_void_p), ("x_index_stride", C.c_int64)]
 
 
 PARAM_FIELDS = ["tc1_w", "tc1_b", "tc1_aw", "tc1_ab", "al_w", "al_b", "gc_w", "gc_b",
@@ -139,7 +140,8 @@ class _Lib:
         d.stgcn_grad_flush.argtypes = [C.c_int32, C.POINTER(FlushBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockGrads), C.c_void_p,
                                        C.POINTER(AdamwTensor), C.c_int32, C.POINTER(AdamwHyper), C.c_void_p]
         d.stgcn_grad_flush.restype = C.c_int
-        d.stgcn_mse_loss_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.stgcn_mse_loss_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p]
         d.stgcn_mse_loss_grad.restype = C.c_int
         d.stgcn_profile_enable.argtypes = [C.c_int]
         d.stgcn_profile_enable.restype = C.c_int

@@ -130,6 +130,8 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
     if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
         return fail(STGCN_ERR_UNSUPPORTED, "c_in=%d: input channels must be a multiple of 4 unless Kt*c_in <= 16", d->c_in);
+    if (d->x_bstride < 0 || ((d->x_bstride != 0 || d->x_index_dev) && d->need_dx))
+        return fail(STGCN_ERR_INVALID, "strided / indexed input windows (x_bstride, x_index_dev) need need_dx = 0 and x_bstride >= 0");
     return STGCN_OK;
 }
 
@@ -658,6 +660,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         memset(&t1, 0, sizeof(t1));
         t1.ts.src = x; t1.ts.C = d->c_in; t1.ts.taps = d->Kt; t1.ts.N = d->N; t1.ts.Tsrc = d->T; t1.ts.Tdst = v.T1; t1.ts.dir = 1;
         t1.ts.rows = v.rows1;
+        t1.ts.bstride = d->x_bstride; t1.ts.idx_dev = reinterpret_cast<const long*>(d->x_index_dev); t1.ts.idx_stride = d->x_index_stride;
         t1.Wp = ws + pl.ws_W1p; t1.bias = ws + pl.ws_b1; t1.KCH = v.KP1 / 16; t1.Cout = d->c0; t1.act = d->act;
         t1.U = pl.recompute_tc1 ? nullptr : saved + pl.sv_U1; t1.S = pl.recompute_tc1 ? nullptr : saved + pl.sv_S1; t1.H = nullptr;
         t1.Wap = ws + pl.ws_Wap; t1.ba = ws + pl.ws_ba; t1.A = saved + pl.sv_A; t1.c1 = d->c1;

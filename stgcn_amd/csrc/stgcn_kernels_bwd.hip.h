@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
                     s = ld4(a.S + (size_t)R * c0 + 4 * c4);
                 } else {   // cheap conv (K <= 16): Z = im2col(x) @ W_eff + b_eff recomputed instead of stored
                     const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N), Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
-                    const float* xr = a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem) * a.ts.C;
+                    const float* xr = tap_base(a.ts) + ((size_t)b * tap_bstride(a.ts) + rem) * a.ts.C;
                     u = ld4(a.bias + 4 * c4);
                     f32x4 qv = ld4(a.bias + c0 + 4 * c4);
                     const int K = a.ts.taps * a.ts.C;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
             if (R < a.rows && k < K) {
                 const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                 const int tap = k / a.ts.C, ch = k - tap * a.ts.C;
-                v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+                v = tap_base(a.ts)[((size_t)b * tap_bstride(a.ts) + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
             }
             xt[r * LDX + k] = v;
         }
@@ -838,6 +838,8 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
     const int K = a.ts.taps * a.ts.C;
     const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N);   // rows < 2^31 (checked on the host): 32-bit divisions only
     const int csh = pow2_shift(a.ts.C);
+    const float* const xsrc = tap_base(a.ts);
+    const size_t xbs = (size_t)tap_bstride(a.ts);
 
     // staging registers (next step's tiles are fetched while the current step's MFMAs run)
     constexpr int NCR = (SR * (MC / 4) + kThreads - 1) / kThreads;   // float4 of the im2col tile per thread (vector path)
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
                     if (R < crow1 && kidx < K) {
                         const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                         const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
-                        v = ld4(a.ts.src + ((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+                        v = ld4(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
                     }
                 }
                 creg[i] = v;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
                     if (R < crow1 && kidx < K) {
                         const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                         const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
-                        v = a.ts.src[((size_t)b * a.ts.Tsrc * a.ts.N + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+                        v = xsrc[((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
                     }
                 }
                 cs[i] = v;

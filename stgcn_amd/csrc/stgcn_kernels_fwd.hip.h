@@ -145,7 +145,17 @@ struct TapSrc {
     const float* src;
     int C, taps, N, Tsrc, Tdst, dir;
     long rows;   // B * Tdst * N
+    // Windows that are NOT laid out back to back (device-side windowing): consecutive windows b
+    // start bstride rows apart (0 = dense, Tsrc * N) -- e.g. N rows when window b is rows [s + b, s + b + Tsrc) of the
+    // resident (time, N) series, which the reference replicates 12x into a (num, 1, n_his, N) tensor (dataloader.py:32-47)
+    // -- and the whole source is shifted by *idx_dev * idx_stride floats (the position of a captured training step in the
+    // resident series; idx_dev == nullptr: no shift).
+    long bstride;
+    const long* idx_dev;
+    long idx_stride;
 };
+__device__ __forceinline__ const float* tap_base(const TapSrc& ts) { return ts.src + (ts.idx_dev ? *ts.idx_dev * ts.idx_stride : 0); }
+__device__ __forceinline__ long tap_bstride(const TapSrc& ts) { return ts.bstride ? ts.bstride : (long)ts.Tsrc * ts.N; }
 
 // per-tile row bookkeeping in LDS: rowbase[r] = flat source row of tap 0, rowt[r] = t (or -2^20 if the
 // row is beyond the tensor, which makes every tap invalid)
@@ -160,7 +170,7 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
             const unsigned b = Ru / per_b;
             const unsigned rem = Ru - b * per_b;
             t = (int)(rem / (unsigned)ts.N);
-            base = (int)(b * (unsigned)(ts.Tsrc * ts.N) + rem);   // = (b*Tsrc + t)*N + n
+            base = (int)(b * (unsigned)tap_bstride(ts) + rem);   // = (b*Tsrc + t)*N + n for dense windows
         }
         rowbase[r] = base;
         rowt[r] = t;
@@ -172,6 +182,7 @@ template <int TR = kTileRows, int THREADS = kThreads>
 __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                   float* At, int lda) {
     const int K = ts.taps * ts.C, csh = pow2_shift(ts.C);
+    const float* const src = tap_base(ts);
     if ((ts.C & 3) == 0) {
         const int q4 = kseg >> 2, qsh = pow2_shift(q4);
         for (int idx = threadIdx.x; idx < TR * q4; idx += THREADS) {
@@ -181,7 +192,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             if (kidx < K) {
                 const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+                if (tt >= 0 && tt < ts.Tsrc) v = ld4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
             st4(At + r * lda + 4 * q, v);
         }
@@ -194,7 +205,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             if (kidx < K) {
                 const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = ts.src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
+                if (tt >= 0 && tt < ts.Tsrc) v = src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
             }
             At[r * lda + q] = v;
         }
@@ -237,6 +248,7 @@ __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const in
                                                       TileRegs<TR, THREADS>& regs) {
     constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
     const int K = ts.taps * ts.C, q4 = kseg >> 2, qsh = pow2_shift(q4), csh = pow2_shift(ts.C);
+    const float* const src = tap_base(ts);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * THREADS;
@@ -247,7 +259,7 @@ __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const in
             if (kidx < K) {
                 const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = ld4(ts.src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+                if (tt >= 0 && tt < ts.Tsrc) v = ld4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
         }
         regs.v[i] = v;
@@ -561,6 +573,8 @@ template <int TR, int SB, int THREADS = kThreads>
 __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int KP, float* At, int lda) {
     const int tid = threadIdx.x, K = ts.taps * ts.C;
     const RowCoord c0 = row_coord(ts, row0 < ts.rows ? row0 : 0);
+    const float* const src = tap_base(ts);
+    const long bs = tap_bstride(ts);
     if ((ts.C & 3) == 0) {
         const int c4n = ts.C >> 2, c4sh = pow2_shift(c4n), per_tap = TR * c4n, total = ts.taps * per_tap;
         for (int base = 0; base < total; base += THREADS * SB) {
@@ -578,7 +592,7 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
                     dst[i] = r * lda + tap * ts.C + 4 * c4;
                     if (row0 + r < ts.rows) {
                         const RowCoord c = row_advance(ts, c0, r);
-                        v[i] = ld4(ts.src + ((size_t)(c.b * ts.Tsrc + c.t + tap) * ts.N + c.n) * ts.C + 4 * c4);
+                        v[i] = ld4(src + ((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + 4 * c4);
                     }
                 }
             }
@@ -609,7 +623,7 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
                     if (q < K && row0 + r < ts.rows) {
                         const int tap = q / ts.C, ch = q - tap * ts.C;
                         const RowCoord c = row_advance(ts, c0, r);
-                        v[i] = ts.src[((size_t)(c.b * ts.Tsrc + c.t + tap) * ts.N + c.n) * ts.C + ch];
+                        v[i] = src[((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + ch];
                     }
                 }
             }
@@ -678,7 +692,7 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, 
     // ---- 2. the input tile: all time steps of 16 nodes, once -----------------------------------------------------
     {
         const int c4n = C >> 2, c4sh = pow2_shift(c4n), total = Tsrc * 16 * c4n;
-        const float* xb = ts.src + (size_t)b * Tsrc * N * C;
+        const float* xb = tap_base(ts) + (size_t)b * tap_bstride(ts) * C;
         for (int base = 0; base < total; base += THREADS * 8) {
             f32x4 v[8];
 #pragma unroll

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
 // order (bitwise reproducible).
 // ================================================================================================
 __global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* pred, const float* y, long n, float gscale, float* loss,
-                                                              float* dpred) {
+                                                              float* dpred, const long* y_idx_dev, long y_idx_stride) {
+    if (y_idx_dev) y += *y_idx_dev * y_idx_stride;   // labels straight from the resident series (device-side windowing)
     extern __shared__ float stgcn_smem[];   // [16] wave sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float k = 2.0f * gscale / (float)n;

@@ -51,7 +51,41 @@ def _check_device(t: torch.Tensor, what: str):
         raise RuntimeError(f"{what}: stgcn_amd runs on MI355X only (tensor is on {t.device}); there is no CPU fallback")
 
 
-def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False) -> StblockDesc:
+_input_index: Dict[int, Tuple[torch.Tensor, int]] = {}
+
+
+def bind_input_index(base: torch.Tensor, index: torch.Tensor, stride_floats: int) -> None:
+    """Device-side batch position: from now on a fused-operator input (or an MSE target) whose storage starts at
+    ``base.data_ptr()`` is read ``index[0] * stride_floats`` floats further on, with ``index`` an int64 DEVICE scalar that a
+    captured training step advances by itself (``stgcn_prepack`` counters).  Kernel arguments are frozen inside a hipGraph;
+    this is how the replayed step walks through a resident series without per-step input copies."""
+    assert index.dtype == torch.int64 and index.numel() == 1 and index.device == base.device
+    _input_index[base.data_ptr()] = (index, int(stride_floats))
+
+
+def unbind_input_index(base: torch.Tensor) -> None:
+    _input_index.pop(base.data_ptr(), None)
+
+
+def _index_of(t: torch.Tensor):
+    e = _input_index.get(t.data_ptr())
+    return (None, 0) if e is None else (e[0].data_ptr(), e[1])
+
+
+def window_strided_rows(x_p: torch.Tensor) -> Optional[int]:
+    """``x_p``: the (B, T, N, C) permutation of a block input.  Returns the window stride in rows of C floats if every window is a
+    dense (T, N, C) slab but consecutive windows are NOT back to back (e.g. overlapping windows of one resident series built with
+    ``torch.as_strided``), else None (dense input, or a layout that needs a contiguous copy)."""
+    B, T, N, Cc = x_p.shape
+    sb, st, sn, sc = x_p.stride()
+    inner = (Cc == 1 or sc == 1) and sn == Cc and st == N * Cc
+    if B > 1 and inner and sb >= 0 and sb % Cc == 0 and sb != T * N * Cc:
+        return sb // Cc
+    return None
+
+
+def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False,
+              x_bstride: int = 0, x_index: Optional[int] = None, x_index_stride: int = 0) -> StblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")  # layers.py:117-118
     if cfg.graph_conv_type not in _lib.GRAPH_CONV:
@@ -69,6 +103,7 @@ def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, p
     d.reserved = int(cfg.tag)
     d.prepacked = 1 if prepacked else 0
     d.defer_reduce = 1 if defer else 0
+    d.x_bstride, d.x_index_dev, d.x_index_stride = int(x_bstride), x_index, int(x_index_stride)
     return d
 
 
@@ -135,8 +170,9 @@ def mse_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, grad_scale: floa
         raise ValueError(f"mse_loss_and_grad: contiguous float32 tensors of one shape expected, got {tuple(p.shape)} / {tuple(target.shape)}")
     loss = torch.empty(1, dtype=torch.float32, device=p.device)
     dpred = torch.empty_like(p)
+    ti, tis = _index_of(target)
     L.check(L.dll.stgcn_mse_loss_grad(p.data_ptr(), target.data_ptr(), p.numel(), float(grad_scale), loss.data_ptr(), dpred.data_ptr(),
-                                      _stream_of(p)), "stgcn_mse_loss_grad")
+                                      ti, tis, _stream_of(p)), "stgcn_mse_loss_grad")
     return loss, dpred
 
 
@@ -254,7 +290,10 @@ class _STBlockFn(torch.autograd.Function):
         L = _lib.lib()
         B, T, N, c_in = x_cl.shape
         need_dx = bool(x_cl.requires_grad)
-        desc = make_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked())
+        bstride = 0 if x_cl.is_contiguous() else window_strided_rows(x_cl)
+        assert bstride is not None and not (bstride and need_dx), "st_conv_block hands over dense or window-strided inputs only"
+        xi, xis = _index_of(x_cl)
+        desc = make_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked(), x_bstride=bstride, x_index=xi, x_index_stride=xis)
         plan = query_plan(desc)
         dev = x_cl.device
         ps = [None if p is None else p.detach() for p in params]
@@ -273,6 +312,7 @@ class _STBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.training, ctx.seed, ctx.offset, ctx.wsc, ctx.ws = cfg, training, seed, offset, wsc, ws
         ctx.offset_dev = offset_dev
         ctx.need_dx = need_dx
+        ctx.x_window = (bstride, xi, xis)
         ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
         return y
 
@@ -285,7 +325,8 @@ class _STBlockFn(torch.autograd.Function):
         cfg = ctx.cfg
         B, T, N, c_in = x_cl.shape
         sink = _sink
-        desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None)
+        desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None, x_bstride=ctx.x_window[0], x_index=ctx.x_window[1],
+                         x_index_stride=ctx.x_window[2])
         plan = query_plan(desc)
         dy = dy.contiguous()
         dev = x_cl.device
@@ -329,7 +370,10 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     _check_device(x, "x")
     if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
         raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
-    x_cl = x.permute(0, 2, 3, 1).contiguous()       # no copy when x is already channels-last (or c_in == 1)
+    x_cl = x.permute(0, 2, 3, 1)
+    if x.requires_grad or window_strided_rows(x_cl) is None:
+        x_cl = x_cl.contiguous()                    # no copy when x is already channels-last (or c_in == 1)
+    # (else: overlapping windows of a resident series are read in place -- device-side windowing, no 12x replicated tensor)
     y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, offset_dev, wsc, *params)
     return y_cl.permute(0, 3, 1, 2)
 

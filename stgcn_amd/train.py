@@ -211,11 +211,19 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3,
-                 chains: int = 1, fused: Optional[bool] = None):
+                 chains: int = 1, fused: Optional[bool] = None, series: Optional[torch.Tensor] = None, n_his: int = 12,
+                 n_pred: int = 3, rank: int = 0):
+        """``series``: optional resident (time, N) float32 device tensor (already z-scored).  The step then takes its windows
+        straight from it (device-side windowing): window b of the minibatch is rows
+        [s + b, s + b + n_his) of the series (read in place through a strided view, no (num, 1, n_his, N) tensor, no per-step
+        input copies), its label row s + b + n_his + n_pred - 1 (script/dataloader.py:32-47), and s advances by the global
+        batch on the device every replay (unshuffled order like main.py:127, wrapping at the end of the series).  Call the
+        step without arguments; ``x_example`` / ``y_example`` only give the batch size."""
         from .layers import DropoutStream
         assert x_example.is_cuda, "hipGraph capture needs the MI355X path"
         self.model, self.opt, self.world = model, optimizer, world
         dev = x_example.device
+        self.series, self.index, self._index_bump = series, None, None
         self.chains = int(chains)                 # micro-batch chains on concurrent streams (chained_fwd_bwd)
         if fused is None:
             fused = os.environ.get("STGCN_FUSED_STEP", "1") != "0"
@@ -223,10 +231,24 @@ class GraphedTrainStep:
         self.fused = bool(fused) and self.chains == 1 and hasattr(optimizer, "flush_with")
         self.arena: Optional[GradArena] = None
         self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.chains - 1)]
-        self.x = torch.empty_like(x_example)
-        self.y = torch.empty_like(y_example)
-        self.x.copy_(x_example)
-        self.y.copy_(y_example)
+        if series is None:
+            self.x = torch.empty_like(x_example)
+            self.y = torch.empty_like(y_example)
+            self.x.copy_(x_example)
+            self.y.copy_(y_example)
+        else:
+            from . import ops
+            B, N = len(x_example), series.shape[1]
+            assert series.is_cuda and series.dtype == torch.float32 and series.is_contiguous() and B > 1
+            num = series.shape[0] - n_his - n_pred + 1                  # windows the series holds (dataloader.py:34-35)
+            usable = num // (B * world) * (B * world)
+            assert usable > 0, "series shorter than one global minibatch of windows"
+            self.x = torch.as_strided(series, (B, 1, n_his, N), (N, n_his * N, N, 1))           # window b = rows [b, b + n_his)
+            self.y = series[n_his + n_pred - 1:n_his + n_pred - 1 + B]                         # label rows, (B, N) contiguous
+            self.index = torch.full((1,), rank * B, dtype=torch.int64, device=dev)             # first window of this rank
+            self._index_bump = (self.index, B * world, usable)
+            ops.bind_input_index(self.x, self.index, N)
+            ops.bind_input_index(self.y, self.index, N)
         if DropoutStream.counter is None or DropoutStream.counter.device != dev:
             DropoutStream.use_device_counter(dev)
         self.counter = DropoutStream.counter     # the captured kernels hold this address: keep it alive with the graph
@@ -260,6 +282,7 @@ class GraphedTrainStep:
                     self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
                     if not self.fold:
                         DropoutStream.advance()
+                        self._advance_series()
             else:
                 self.loss = self._fwd_bwd()
                 if world > 1:
@@ -268,6 +291,7 @@ class GraphedTrainStep:
                 else:
                     self.opt.step()
                     DropoutStream.advance()
+                    self._advance_series()
         self.g2 = None
         if world > 1:
             self.g2 = torch.cuda.CUDAGraph()
@@ -277,6 +301,7 @@ class GraphedTrainStep:
                     torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
                 self.opt.step()
                 DropoutStream.advance()
+                self._advance_series()
         # one full replay inside the constructor: a capture / replay problem surfaces here (where the caller can
         # still fall back to eager launches of the same kernels), not inside a timed loop
         self(x_example, y_example)
@@ -306,6 +331,13 @@ class GraphedTrainStep:
         from .layers import DropoutStream
         step_t = self.opt.device_step_counter(dev)
         self.model._step_counters = [(DropoutStream.counter, DropoutStream.SITE_STRIDE, 0), (step_t, 1, 0)]
+        i0 = None
+        if self._index_bump is not None:
+            # unfolded steps advance the window position AFTER the step, the pack launch advances it BEFORE: step back once
+            idx, inc, mod = self._index_bump
+            i0 = int(idx.item())
+            idx.sub_(inc).remainder_(mod)
+            self.model._step_counters.append(self._index_bump)
         c0, s0 = int(DropoutStream.counter.item()), int(step_t.item())
         self.fold = True
         self._eager_fused_once()
@@ -313,6 +345,8 @@ class GraphedTrainStep:
             self.model._step_counters = None          # the pack launch did not run: advance them the explicit way
             DropoutStream.counter.fill_(c0 + DropoutStream.SITE_STRIDE)
             step_t.fill_(s0 + 1)
+            if i0 is not None:
+                self._index_bump[0].fill_((i0 + self._index_bump[1]) % self._index_bump[2])
             self.fold = False
 
     def _eager_fused_once(self):
@@ -322,10 +356,12 @@ class GraphedTrainStep:
             dist.all_reduce(self.arena.flat)
             self.opt.step()
             DropoutStream.advance()
+            self._advance_series()
         else:
             self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
             if not self.fold:
                 DropoutStream.advance()
+                self._advance_series()
 
     def _eager_once(self):
         from .layers import DropoutStream
@@ -339,10 +375,18 @@ class GraphedTrainStep:
             torch._foreach_copy_([p.grad.reshape(-1) for p in live], list(flat.split([p.numel() for p in live])))
         self.opt.step()
         DropoutStream.advance()
+        self._advance_series()
 
-    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        self.x.copy_(x, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
+    def _advance_series(self):
+        """the window position when no pack launch carries it (world > 1 or an unfolded step): two tiny launches"""
+        if self._index_bump is not None and not self.fold:
+            idx, inc, mod = self._index_bump
+            idx.add_(inc).remainder_(mod)
+
+    def __call__(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.series is None:
+            self.x.copy_(x, non_blocking=True)
+            self.y.copy_(y, non_blocking=True)
         self.g1.replay()
         if self.g2 is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

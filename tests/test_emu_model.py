@@ -107,3 +107,40 @@ def test_chained_microbatches_equal_whole_batch():
         assert (r is None) == (p.grad is None)
         if r is not None:
             assert maxabs(p.grad.numpy(), r.numpy()) <= 1e-5 * max(1e-30, float(r.abs().max())) + 1e-8
+
+
+def test_device_side_windows_equal_replicated_tensor():
+    """Device-side windowing: the model reading overlapping windows in place from a resident (time, N)
+    series (strided view + device batch index) gives bitwise the outputs / gradients of the reference's replicated
+    (num, 1, n_his, N) tensor (script/dataloader.py:32-47), and the MSE target can be indexed the same way."""
+    from stgcn_amd import ops
+    from stgcn_amd.train import fwd_loss_bwd
+    fx, model, x, y = _build("tiny_cheb_f32")
+    model.train()
+    B, _, n_his, N = x.shape
+    n_pred, start = 3, 5
+    g = torch.Generator().manual_seed(9)
+    series = torch.randn(start + B + n_his + n_pred + 4, N, generator=g)
+    # the reference's layout: window b = rows [start + b, start + b + n_his), label row start + b + n_his + n_pred - 1
+    xw = torch.stack([series[start + b:start + b + n_his] for b in range(B)]).unsqueeze(1).contiguous()
+    yw = torch.stack([series[start + b + n_his + n_pred - 1] for b in range(B)]).contiguous()
+    model.zero_grad(set_to_none=True)
+    l_ref = fwd_loss_bwd(model, xw, yw)
+    ref = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    # in place: strided view of the series at window 0 + index = start
+    xv = torch.as_strided(series, (B, 1, n_his, N), (N, n_his * N, N, 1))
+    yv = series[n_his + n_pred - 1:n_his + n_pred - 1 + B]
+    idx = torch.tensor([start], dtype=torch.int64)
+    ops.bind_input_index(xv, idx, N)
+    ops.bind_input_index(yv, idx, N)
+    try:
+        model.zero_grad(set_to_none=True)
+        l_win = fwd_loss_bwd(model, xv, yv)
+    finally:
+        ops.unbind_input_index(xv)
+        ops.unbind_input_index(yv)
+    assert float(l_ref) == float(l_win)
+    for r, p in zip(ref, model.parameters()):
+        assert (r is None) == (p.grad is None)
+        if r is not None:
+            assert torch.equal(r, p.grad)

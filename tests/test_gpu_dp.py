@@ -1,6 +1,7 @@
 """-m gpu: the data-parallel captured step (two hipGraphs around one all-reduce of the flat gradient arena) on ONE GPU:
 two processes share cuda:0 and exchange through gloo (RCCL needs one GPU per rank; the collective itself is not what is
-tested here, the capture / replay / arena plumbing of GraphedTrainStep(world=2) is).  2 ranks x bs 4 == 1 process x bs 8."""
+tested here, the capture / replay / arena plumbing of GraphedTrainStep(world=2) is), both ranks windowing the same resident
+series on the device at their own offsets.  2 ranks x bs 4 == 1 process x bs 8 over six global steps."""
 import os
 import socket
 import types
@@ -36,9 +37,18 @@ def _make():
     return models.STGCNChebGraphConv(args, BLOCKS, 207).to("cuda:0")
 
 
-def _data():
+N_HIS, N_PRED, BG = 12, 3, 8          # global batch 8 = 2 ranks x 4
+
+
+def _series():
     g = torch.Generator().manual_seed(0)
-    return torch.randn(4, 8, 1, 12, 207, generator=g), torch.randn(4, 8, 207, generator=g)
+    return torch.randn(8 * BG + N_HIS + N_PRED - 1, 207, generator=g)
+
+
+def _windows(series, s, n):
+    x = torch.stack([series[s + b:s + b + N_HIS] for b in range(n)]).unsqueeze(1).contiguous()
+    y = torch.stack([series[s + b + N_HIS + N_PRED - 1] for b in range(n)]).contiguous()
+    return x, y
 
 
 def _worker(rank, world, port, out):
@@ -48,14 +58,16 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(0)
     model = _make()
     opt = make_optimizer(model, capturable=True)
-    xs, ys = _data()
-    bl = xs.shape[1] // world
-    sl = slice(rank * bl, (rank + 1) * bl)
-    gs = GraphedTrainStep(model, opt, xs[0][sl].cuda(), ys[0][sl].cuda(), world=world, warmup=2)
-    assert gs.fused and gs.g2 is not None
-    for i in range(1, 4):
-        gs(xs[i][sl].cuda(), ys[i][sl].cuda())
+    series = _series().cuda()
+    bl = BG // world
+    # device-side windows of the resident series: rank r takes windows [k*BG + r*bl, ... + bl) of global step k
+    x0, y0 = _windows(series, rank * bl, bl)
+    gs = GraphedTrainStep(model, opt, x0, y0, world=world, warmup=2, series=series, n_his=N_HIS, n_pred=N_PRED, rank=rank)
+    assert gs.fused and gs.g2 is not None and not gs.fold
+    for _ in range(3):
+        gs()
     torch.cuda.synchronize()
+    assert int(gs.index.item()) == 6 * BG + rank * bl
     if rank == 0:
         torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out)
     dist.barrier()
@@ -71,10 +83,10 @@ def test_two_rank_graphed_step_equals_one_big_batch(tmp_path):
     DropoutStream.disable_device_counter()
     model = _make()
     opt = make_optimizer(model)
-    xs, ys = _data()
-    # the constructor trains on batch 0 three times (2 warm-up steps + 1 verification replay), then batches 1..3
-    for i in (0, 0, 0, 1, 2, 3):
-        train_step(model, opt, xs[i].cuda(), ys[i].cuda())
+    series = _series().cuda()
+    # the constructor runs global steps 0, 1 (warm-up) and 2 (verification replay), then 3 replays: positions k * BG, k = 0..5
+    for k in range(6):
+        train_step(model, opt, *_windows(series, k * BG, BG))
     torch.cuda.synchronize()
     worst = max(float((got[k] - v.cpu()).abs().max()) for k, v in model.state_dict().items())
     assert worst <= 2e-5, worst

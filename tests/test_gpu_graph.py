@@ -121,3 +121,36 @@ def test_chained_graph_step_equals_single_chain():
         for k, v in sd.items():
             d = float((v - finals[0][1][k]).abs().max())
             assert d <= 2e-5, (k, d)       # AdamW normalises gradients: tiny summation-order differences stay tiny
+
+
+def test_resident_series_step_equals_explicit_batches():
+    """GraphedTrainStep(series=...): device-side windows of a resident series, batch position advanced on the device by the pack
+    launch, trains exactly like the same windows materialised as (B, 1, n_his, N) tensors and fed one batch per step."""
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer, train_step
+    n_his, n_pred, B, N = 12, 3, 8, 207
+    g = torch.Generator().manual_seed(6)
+    series = torch.randn(5 * B + n_his + n_pred - 1, N, generator=g).to(DEV)         # 5 minibatches of windows, then it wraps
+
+    def windows(s):
+        x = torch.stack([series[s + b:s + b + n_his] for b in range(B)]).unsqueeze(1).contiguous()
+        y = torch.stack([series[s + b + n_his + n_pred - 1] for b in range(B)]).contiguous()
+        return x, y
+
+    DropoutStream.use_device_counter(torch.device(DEV))
+    DropoutStream.manual_seed(3)
+    m = _make(0.0)
+    o = make_optimizer(m, capturable=True)
+    gs = GraphedTrainStep(m, o, *windows(0), warmup=2, series=series, n_his=n_his, n_pred=n_pred)
+    assert gs.fold, "the pack launch should carry the batch position"
+    losses = [float(gs().item()) for _ in range(4)]        # positions 3B, 4B, 0 (wrap), B after the constructor's 0, B, 2B
+    torch.cuda.synchronize()
+    assert int(gs.index.item()) == B
+    DropoutStream.disable_device_counter()
+    m2 = _make(0.0)
+    o2 = make_optimizer(m2)
+    ref_losses = [float(train_step(m2, o2, *windows((k * B) % (5 * B))).item()) for k in range(3 + 4)]
+    torch.cuda.synchronize()
+    assert np.allclose(losses, ref_losses[-4:], rtol=1e-5, atol=0), (losses, ref_losses)
+    for k, v in m2.state_dict().items():
+        assert float((v - m.state_dict()[k]).abs().max()) <= 2e-5, k
