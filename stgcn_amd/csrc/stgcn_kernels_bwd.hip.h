@@ -63,7 +63,7 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
-    g.thin = (Kt * c_in <= 16 && c0 == 64 && c1 == 16) ? 1 : 0;
+    g.thin = (Kt * c_in <= 4 && c0 == 64 && c1 == 16) ? 1 : 0;   // thin_tc1_bwd_kernel keeps K <= 4 rows of W_eff in registers
     // grid-stride workgroups of align_gate_bwd (23.5 KB of LDS each: several per CU for latency hiding).  The thin
     // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there
     // (measured; 512 = 2 resident workgroups per CU at 62 KB of LDS -- a 513th would wait for a second round).
@@ -676,24 +676,39 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
     f32x4 gacc[2] = {zero4(), zero4()};          // dW_eff tiles: n-tiles 2*wave, 2*wave+1 (NC == 128)
     float bsum = 0.f, zsum = 0.f;                // dba column (tid&15), db_eff column (tid % NC)
     const int zcol = tid % NC, zpart = tid / NC, zrows = 64 / (kThreads / NC);
+    // per-thread constants of the row pass: the channel quad c4 = tid % c4n is the same in every iteration (256 % c4n == 0), so
+    // the dense W_eff rows (K <= 4 taps x 2 halves) and the bias of that quad live in registers for the whole kernel
+    constexpr int kThinK = 4;
+    const int c4 = tid & (c4n - 1);
+    f32x4 wpr[kThinK], wqr[kThinK];
+#pragma unroll
+    for (int k = 0; k < kThinK; ++k) {
+        wpr[k] = k < K ? ld4(a.Wd + (size_t)k * NC + 4 * c4) : zero4();
+        wqr[k] = k < K ? ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4) : zero4();
+    }
+    const f32x4 bu = ld4(a.bias + 4 * c4), bqv = ld4(a.bias + c0 + 4 * c4);
+    const float* const xsrc = tap_base(a.ts);
+    const size_t xbs = (size_t)tap_bstride(a.ts);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * kTileRows;
         __syncthreads();
-        for (int idx = tid; idx < kTileRows * 4; idx += kThreads) {
-            const int r = idx >> 2, q = idx & 3;
-            st4(dAt + r * LDA + 4 * q, row0 + r < a.rows ? ld4(a.dA + (size_t)(row0 + r) * 16 + 4 * q) : zero4());
+        // dA rows (one 16-byte load per thread) and the K valid taps of x (one scalar load for the first 64*K threads) are
+        // requested together; the 16 - K padding columns of the im2col tile are zero-filled meanwhile
+        const int ra = tid >> 2, qa = tid & 3;
+        const f32x4 dav = row0 + ra < a.rows ? ld4(a.dA + (size_t)(row0 + ra) * 16 + 4 * qa) : zero4();
+        float xv0 = 0.f;
+        const int rx = tid / K, kx = tid - rx * K;
+        if (tid < kTileRows * K && row0 + rx < a.rows) {
+            const unsigned Ru = (unsigned)(row0 + rx), b = Ru / per_b, rem = Ru - b * per_b;
+            const int tap = kx / a.ts.C, ch = kx - tap * a.ts.C;
+            xv0 = xsrc[((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
         }
-        for (int idx = tid; idx < kTileRows * 16; idx += kThreads) {
-            const int r = idx >> 4, k = idx & 15;
-            const long R = row0 + r;
-            float v = 0.f;
-            if (R < a.rows && k < K) {
-                const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
-                const int tap = k / a.ts.C, ch = k - tap * a.ts.C;
-                v = tap_base(a.ts)[((size_t)b * tap_bstride(a.ts) + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
-            }
-            xt[r * LDX + k] = v;
+        for (int idx = tid; idx < kTileRows * (16 - K); idx += kThreads) {
+            const int r = idx / (16 - K), k = K + idx - r * (16 - K);
+            xt[r * LDX + k] = 0.f;
         }
+        st4(dAt + ra * LDA + 4 * qa, dav);
+        if (tid < kTileRows * K) xt[rx * LDX + kx] = xv0;
         __syncthreads();
         {
             const int rg = tid >> 4, jj = tid & 15;
@@ -711,19 +726,21 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         __syncthreads();
         // row-major pass: recompute gate inputs, gate backward, dZ / H tiles
         for (int idx = tid; idx < kTileRows * c4n; idx += kThreads) {
-            const int row = fast_div(idx, c4n, pow2_shift(c4n)), c4 = idx - row * c4n;
+            const int row = idx / c4n;            // (c4 = idx % c4n == tid % c4n)
             const long R = row0 + row;
             f32x4 h = zero4(), du = zero4(), dq = zero4();
             if (R < a.rows) {
                 const f32x4 dh = ld4(Ht + row * LDH + 4 * c4);
-                f32x4 u = ld4(a.bias + 4 * c4), qv = ld4(a.bias + c0 + 4 * c4);
-                for (int k = 0; k < K; ++k) {
-                    const float xv = xt[row * LDX + k];
-                    const f32x4 wp = ld4(a.Wd + (size_t)k * NC + 4 * c4), wq = ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4);
+                f32x4 u = bu, qv = bqv;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        u[i] = fmaf(xv, wp[i], u[i]);
-                        qv[i] = fmaf(xv, wq[i], qv[i]);
+                for (int k = 0; k < kThinK; ++k) {
+                    if (k < K) {
+                        const float xv = xt[row * LDX + k];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            u[i] = fmaf(xv, wpr[k][i], u[i]);
+                            qv[i] = fmaf(xv, wqr[k][i], qv[i]);
+                        }
                     }
                 }
 #pragma unroll

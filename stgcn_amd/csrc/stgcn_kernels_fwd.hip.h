@@ -196,17 +196,20 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             }
             st4(At + r * lda + 4 * q, v);
         }
-    } else {   // narrow inputs (C = 1 for the first block): scalar gather
-        const int ksh = pow2_shift(kseg);
-        for (int idx = threadIdx.x; idx < TR * kseg; idx += THREADS) {
-            const int r = fast_div(idx, kseg, ksh), q = idx - r * kseg;
+    } else {   // narrow inputs (C = 1 for the first block): scalar gather of the K valid columns only (one round of loads per
+               // thread for 64 rows x 3 taps instead of one per 256 of the 16 padded columns), zeros in the padding
+        const int kv = (K - k0) < kseg ? (K - k0 > 0 ? K - k0 : 0) : kseg, padw = kseg - kv;
+        for (int idx = threadIdx.x; idx < TR * padw; idx += THREADS) {
+            const int r = idx / padw, q = idx - r * padw;
+            At[r * lda + kv + q] = 0.f;
+        }
+        for (int idx = threadIdx.x; idx < TR * kv; idx += THREADS) {
+            const int r = idx / kv, q = idx - r * kv;
             const int kidx = k0 + q;
+            const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
+            const int tt = rowt[r] + ts.dir * tap;
             float v = 0.f;
-            if (kidx < K) {
-                const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
-                const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
-            }
+            if (tt >= 0 && tt < ts.Tsrc) v = src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
             At[r * lda + q] = v;
         }
     }
