@@ -120,6 +120,9 @@ typedef struct stgcn_stblock_plan {
     int64_t ws_dZ1;                   /* [rows1][2*c0]                                                 */
     int64_t ws_part;                  /* partial-sum arena for the parameter gradients                 */
     int64_t part_floats;
+    int64_t tiled_gc;                 /* 1: the graph conv runs the tiled GEMM path (N > 512 nodes, or more terms than the
+                                         slab-resident backward holds in LDS); NP = roundup128(N) then                    */
+    int64_t ws_Gk;                    /* tiled_gc: [terms][rows1][c1] Clenshaw buffers of the graph-conv backward         */
 } stgcn_stblock_plan;
 
 int stgcn_version(void);
@@ -134,6 +137,18 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* desc, stgcn_stblock_plan*
  * reference applies to the activations, applied once to the constant operator) and their transposes, zero padded and
  * stored in MFMA fragment order (layout: stgcn_kernels_fwd.hip.h, gso_frag_kernel).  scratch: 3*NP*NP floats.        */
 int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad, float* gso_t_pad, float* scratch, void* stream);
+
+/* Buffer sizes of stgcn_gso_prepare for a graph of N nodes and `terms` operator terms: gso_pad / gso_t_pad hold `mats`
+ * matrices of NP x NP floats each, scratch `scratch_mats` (0: scratch may be NULL).  Slab-resident graph conv (N <= 512):
+ * NP = roundup16(N), mats = max(terms-1, 1) fragment-ordered polynomials.  Tiled graph conv (*tiled = 1; N > 512, the
+ * 8192-node configs[4] of BASELINE.json): NP = roundup128(N), mats = 1 -- the dense zero-padded operator (gso_pad) and its
+ * transpose (gso_t_pad), row major; the Chebyshev recursion of layers.py:153-161 then runs on the activations, one GEMM
+ * launch per term (stgcn_kernels_gctile.hip.h).                                                                         */
+int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled);
+
+/* Tuning / test knob: graphs with at least n nodes use the tiled graph conv (default 513).  Returns the previous value;
+ * n < 1 only queries.  Operators prepared under one setting must be used under the same setting.                        */
+int stgcn_set_gc_tiled_min_nodes(int32_t n);
 
 /* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
  * offset is the high 64 counter bits).  offset_dev (nullable) points to a DEVICE uint64 added to `offset` when

@@ -134,15 +134,22 @@ def pack_gc_weight(weight, graph_conv_type):
     return np.stack([np.zeros_like(weight), weight], axis=0)
 
 
+def _gso_apply(L, X):
+    """einsum('hi,btic->bthc', L, X) (layers.py:154/158/161) as ONE BLAS GEMM (N x N) . (N x B*T*C): the same sums in
+    another order, minutes faster on the 8192-node graph."""
+    B, T, N, C = X.shape
+    return (L @ X.transpose(2, 0, 1, 3).reshape(N, B * T * C)).reshape(N, B, T, C).transpose(1, 2, 0, 3)
+
+
 def gconv_fwd(A, gso, Wk, bias):
     """X0=A, X1=L X0, Xk = 2 L X_{k-1} - X_{k-2} (layers.py:147-161); Y = sum_k Xk Wk + b (:165-168);
     G = relu(Y + A) (layers.py:229, 253).  Returns ([X0..X_{Ks-1}], G)."""
     Ks = Wk.shape[0]
     Xs = [A]
     if Ks >= 2:
-        Xs.append(np.einsum("hi,btic->bthc", gso, A))
+        Xs.append(_gso_apply(gso, A))
     for k in range(2, Ks):
-        Xs.append(2.0 * np.einsum("hi,btic->bthc", gso, Xs[k - 1]) - Xs[k - 2])
+        Xs.append(2.0 * _gso_apply(gso, Xs[k - 1]) - Xs[k - 2])
     Y = sum(Xs[k] @ Wk[k] for k in range(Ks))
     if bias is not None:
         Y = Y + bias
@@ -160,11 +167,11 @@ def gconv_bwd(dG, G, Xs, gso, Wk):
     Gk = [dY @ Wk[k].T for k in range(Ks)]
     gT = gso.T
     for k in range(Ks - 1, 1, -1):
-        Gk[k - 1] = Gk[k - 1] + 2.0 * np.einsum("hi,btic->bthc", gT, Gk[k])
+        Gk[k - 1] = Gk[k - 1] + 2.0 * _gso_apply(gT, Gk[k])
         Gk[k - 2] = Gk[k - 2] - Gk[k]
     dA = Gk[0] + dY
     if Ks >= 2:
-        dA = dA + np.einsum("hi,btic->bthc", gT, Gk[1])
+        dA = dA + _gso_apply(gT, Gk[1])
     return dA, dWk, dbias
 
 

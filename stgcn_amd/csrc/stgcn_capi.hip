@@ -10,6 +10,7 @@
 
 #include "stgcn_kernels_bwd.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
+#include "stgcn_kernels_gctile.hip.h"
 #include "stgcn_kernels_head.hip.h"
 
 using namespace stgcn;
@@ -125,7 +126,7 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (!(d->c0 == 64 || d->c0 == 128) || !(d->c2 == 64 || d->c2 == 128))
         return fail(STGCN_ERR_UNSUPPORTED, "temporal-conv output channels must be 64 or 128 (got c0=%d c2=%d)", d->c0, d->c2);
     if (d->c1 != 16) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv channels c1 must be 16 (got %d)", d->c1);
-    if (d->N > 512) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 512: slab-resident graph conv needs the tiled variant", d->N);
+    if (d->N > 32768) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 32768 nodes", d->N);
     if ((int64_t)d->B * d->T * d->N >= (1ll << 31) / 256) return fail(STGCN_ERR_UNSUPPORTED, "B*T*N too large for 32-bit row indexing");
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
     if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
@@ -138,21 +139,22 @@ int check_desc(const stgcn_stblock_desc* d) {
 inline int terms(const stgcn_stblock_desc* d) { return d->graph_conv == STGCN_GC_KIPF ? 2 : d->Ks; }
 
 struct Derived {
-    int T1, T2, NP, KP1, KP2, NC1, NC2, CP_in, CP1, terms;
+    int T1, T2, NP, KP1, KP2, NC1, NC2, CP_in, CP1, terms, tiled;
     int64_t rows0, rows1, rows2, slabs1, slabs2;
 };
 Derived derive(const stgcn_stblock_desc* d) {
     Derived v;
     v.T1 = d->T - d->Kt + 1;
     v.T2 = v.T1 - d->Kt + 1;
-    v.NP = (int)rup(d->N, 16);
+    v.terms = terms(d);
+    v.tiled = gc_is_tiled(d->N, v.terms) ? 1 : 0;
+    v.NP = gc_padded_nodes(d->N, v.terms);
     v.KP1 = (int)rup((int64_t)d->Kt * d->c_in, 16);
     v.KP2 = (int)rup((int64_t)d->Kt * d->c1, 16);
     v.NC1 = 2 * d->c0;
     v.NC2 = 2 * d->c2;
     v.CP_in = (int)rup(d->c_in, 16);
     v.CP1 = (int)rup(d->c1, 16);
-    v.terms = terms(d);
     v.rows0 = (int64_t)d->B * d->T * d->N;
     v.rows1 = (int64_t)d->B * v.T1 * d->N;
     v.rows2 = (int64_t)d->B * v.T2 * d->N;
@@ -352,7 +354,63 @@ inline void gc_parts_override(int& fwd, int& bwd) {
     if (b > 0) bwd = b;
 }
 
+// ---- tiled graph conv (stgcn_kernels_gctile.hip.h): one GEMM launch per operator term + one row pass -----------------
+int launch_gso_gemm(const char* label, const float* M, const float* X, float alpha, const float* Z1, float b1, const float* Z2, float b2,
+                    float* out, int N, int NP, long slabs, hipStream_t st) {
+    GsoGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.X = X; g.Z1 = Z1; g.Z2 = Z2; g.out = out; g.alpha = alpha; g.b1 = b1; g.b2 = b2;
+    g.N = N; g.NP = NP; g.slabs = slabs;
+    g.row_tiles = cdiv(N, kGtBM);
+    g.col_tiles = cdiv(slabs, kGtSL);
+    STGCN_LAUNCH(label, st, gso_gemm_kernel, dim3((unsigned)(g.row_tiles * g.col_tiles)), dim3(256), kGtLdsFloats * sizeof(float), g);
+    return STGCN_OK;
+}
+int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
+    if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
+    if (a.Ks > 1 && !a.Xk) return fail(STGCN_ERR_INVALID, "tiled graph conv needs the X_k buffers");
+    const long ks = a.slabs * a.N * 16;
+    // X_1 = L X_0 ; X_k = 2 L X_{k-1} - X_{k-2}   (layers.py:153-161; GraphConv: X_1 = A_hat X_0, layers.py:198)
+    for (int k = 1; k < a.Ks; ++k) {
+        const float* Xm1 = k == 1 ? a.A : a.Xk + (size_t)(k - 2) * ks;
+        const float* Xm2 = k == 1 ? nullptr : (k == 2 ? a.A : a.Xk + (size_t)(k - 3) * ks);
+        const int rc = launch_gso_gemm("gso_gemm_fwd", a.Lp, Xm1, k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f, a.Xk + (size_t)(k - 1) * ks,
+                                       a.N, a.NP, a.slabs, st);
+        if (rc) return rc;
+    }
+    GcRowsFwdArgs r;
+    memset(&r, 0, sizeof(r));
+    r.X0 = a.A; r.Xk = a.Xk; r.W = a.W; r.bias = a.bias; r.G = a.G; r.rows = a.slabs * a.N; r.kstride = ks; r.terms = a.Ks; r.kipf = a.kipf;
+    const long tiles = (r.rows + 15) / 16;
+    const long wgs = (tiles + 3) / 4;
+    STGCN_LAUNCH("gconv_rows_fwd", st, gconv_rows_fwd_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, r);
+    return STGCN_OK;
+}
+// backward: row pass (g_k, parameter-gradient partials), then dA = sum_k T_k(L^T) g_k by the Clenshaw recurrence
+//     b_K = g_K ; b_k = g_k + 2 L^T b_{k+1} - b_{k+2} (in place over g_k) ; dA = g_0 + L^T b_1 - b_2
+int launch_gconv_bwd_tiled(const GconvBwdArgs& a, hipStream_t st) {
+    if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
+    if (!a.Gk || a.wgs < 1 || a.tiles_per_wg < 1) return fail(STGCN_ERR_INVALID, "tiled graph-conv backward: missing workspace / geometry");
+    const long ks = a.slabs * a.N * 16;
+    const int K = a.Ks - 1;
+    GcRowsBwdArgs r;
+    memset(&r, 0, sizeof(r));
+    r.dY = a.dY; r.X0 = a.X0; r.Xk = a.Xk; r.W = a.W; r.part = a.part; r.rows = a.slabs * a.N; r.kstride = ks; r.gstride = ks;
+    r.Gk = K == 0 ? a.dA : a.Gk;   // a single term: g_0 (+ dY) is dA itself
+    r.terms = a.Ks; r.kipf = a.kipf; r.tiles_per_wg = a.tiles_per_wg;
+    STGCN_LAUNCH("gconv_rows_bwd", st, gconv_rows_bwd_kernel, dim3((unsigned)a.wgs), dim3(256), (size_t)4 * (a.Ks + 1) * 256 * sizeof(float), r);
+    if (K == 0) return STGCN_OK;
+    auto gk = [&](int k) { return a.Gk + (size_t)k * ks; };
+    for (int k = K - 1; k >= 1; --k) {
+        const int rc = launch_gso_gemm("gso_gemm_bwd", a.LTp, gk(k + 1), 2.f, gk(k), 1.f, k + 2 <= K ? gk(k + 2) : nullptr, -1.f, gk(k), a.N, a.NP,
+                                       a.slabs, st);
+        if (rc) return rc;
+    }
+    return launch_gso_gemm("gso_gemm_bwd", a.LTp, gk(1), 1.f, gk(0), 1.f, K >= 2 ? gk(2) : nullptr, -1.f, a.dA, a.N, a.NP, a.slabs, st);
+}
+
 int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
+    if (gc_is_tiled(a.N, a.Ks)) return launch_gconv_fwd_tiled(a, st);
     const int HT = a.NP / 16;
     int pf = (HT + 3) / 4, pb = 1;
     gc_parts_override(pf, pb);
@@ -415,6 +473,7 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
 }
 
 int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
+    if (gc_is_tiled(a.N, a.Ks)) return launch_gconv_bwd_tiled(a, st);
     const int HT = a.NP / 16;
     int pf = 0, pb = 1;
     gc_parts_override(pf, pb);
@@ -507,9 +566,9 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
         L.add(G->al_w, part + bg.off_al, bg.al_wgs, bg.al_stride, 1, d->c0, d->c1, 0, d->c1, 1, 0, 1, d->c0);
         L.add_flat(G->al_b, part + bg.off_al + (long)d->c0 * d->c1, bg.al_wgs, bg.al_stride, d->c1);
     }
-    if (d->graph_conv == STGCN_GC_KIPF) L.add_flat(G->gc_w, part + bg.off_gc + 256, (int)v.slabs1, bg.gc_stride, 256);
-    else L.add_flat(G->gc_w, part + bg.off_gc, (int)v.slabs1, bg.gc_stride, v.terms * 256);
-    L.add_flat(G->gc_b, part + bg.off_gc + (long)v.terms * 256, (int)v.slabs1, bg.gc_stride, 16);
+    if (d->graph_conv == STGCN_GC_KIPF) L.add_flat(G->gc_w, part + bg.off_gc + 256, bg.gc_count, bg.gc_stride, 256);
+    else L.add_flat(G->gc_w, part + bg.off_gc, bg.gc_count, bg.gc_stride, v.terms * 256);
+    L.add_flat(G->gc_b, part + bg.off_gc + (long)v.terms * 256, bg.gc_count, bg.gc_stride, 16);
     const int n = d->N * d->c2;
     L.add_flat(G->ln_w, part + bg.off_ln_g, bg.ln_sg, n, n);
     L.add_flat(G->ln_b, part + bg.off_ln_b, bg.ln_sg, n, n);
@@ -597,19 +656,42 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_dYg = take(v.rows1 * d->c1);
     p->ws_dA = take(v.rows1 * d->c1);
     p->ws_dZ1 = take(v.rows1 * v.NC1);
+    p->tiled_gc = v.tiled;
+    p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
     p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;
     return STGCN_OK;
 }
 
+int stgcn_set_gc_tiled_min_nodes(int32_t n) {
+    const int prev = g_gc_tiled_min_n;
+    if (n >= 1) g_gc_tiled_min_n = n;
+    return prev;
+}
+
+int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled) {
+    if (N < 1 || N > 32768 || terms < 1 || terms > 9) return fail(STGCN_ERR_INVALID, "stgcn_gso_layout: bad arguments (1 <= N <= 32768, 1 <= terms <= 9)");
+    const bool t = gc_is_tiled(N, terms);
+    if (NP) *NP = gc_padded_nodes(N, terms);
+    if (mats) *mats = t ? 1 : (terms > 1 ? terms - 1 : 1);
+    if (scratch_mats) *scratch_mats = t ? 0 : 3;
+    if (tiled) *tiled = t ? 1 : 0;
+    return STGCN_OK;
+}
+
 int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad, float* gso_t_pad, float* scratch, void* stream) {
-    if (!gso || !gso_pad || !gso_t_pad || !scratch || N < 1 || terms < 1 || terms > 9)
+    if (!gso || !gso_pad || !gso_t_pad || (!scratch && !gc_is_tiled(N, terms)) || N < 1 || N > 32768 || terms < 1 || terms > 9)
         return fail(STGCN_ERR_INVALID, "stgcn_gso_prepare: bad arguments (N >= 1, 1 <= terms <= 9)");
     hipStream_t st = (hipStream_t)stream;
-    const int NP = (int)rup(N, 16);
+    const int NP = gc_padded_nodes(N, terms);
     const size_t M = (size_t)NP * NP;
     const dim3 grid(cdiv((int64_t)M, kThreads)), blk(kThreads);
+    if (gc_is_tiled(N, terms)) {   // dense padded operator and its transpose; the recursion runs on the activations
+        STGCN_LAUNCH("gso_dense", st, gso_dense_kernel, grid, blk, 0, gso, (int)N, NP, gso_pad);
+        STGCN_LAUNCH("gso_dense_t", st, gso_dense_t_kernel, grid, blk, 0, gso, (int)N, NP, gso_t_pad);
+        return STGCN_OK;
+    }
     float* D[3] = {scratch, scratch + M, scratch + 2 * M};   // D[0] = L (kept), D[1] / D[2]: T_{k-1} / T_{k-2} ring
     STGCN_LAUNCH("gso_dense", st, gso_dense_kernel, grid, blk, 0, gso, (int)N, NP, D[0]);
     const float* tm1 = D[0];      // T_1

@@ -9,8 +9,21 @@
 #pragma once
 #include "stgcn_device.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
+#include "stgcn_kernels_gctile.hip.h"
 
 namespace stgcn {
+
+// ---- which graph-conv implementation a block uses (host side; plan, launchers and stgcn_gso_prepare must agree) -------
+// Slab-resident kernels (gconv_fwd_kernel / gconv_bwd_kernel): up to 512 nodes and as many terms as the backward's LDS
+// footprint allows; everything else runs the tiled GEMM path of stgcn_kernels_gctile.hip.h.  The node threshold is a
+// runtime knob (stgcn_set_gc_tiled_min_nodes) so that both paths can be compared on the same graph.
+inline int g_gc_tiled_min_n = 513;
+inline bool gc_is_tiled(int N, int terms) {
+    if (N >= g_gc_tiled_min_n) return true;
+    const long NP = (N + 15) / 16 * 16;
+    return ((long)terms * 16 * (NP + 4) + NP * 20) * (long)sizeof(float) > 160 * 1024;
+}
+inline int gc_padded_nodes(int N, int terms) { return gc_is_tiled(N, terms) ? (N + kGtBM - 1) / kGtBM * kGtBM : (N + 15) / 16 * 16; }
 
 // ================================================================================================
 // Geometry of the backward launches and of the partial-sum arena (host + plan use the same numbers)
@@ -26,6 +39,8 @@ struct BwdGeom {
     WgradGeom w1, w2;
     long off_ln_g, off_ln_b, off_gc, off_al, total;
     int gc_stride;           // floats per slab in the graph-conv partials: (terms + 1) * 256
+    int gc_count;            // partial blocks of the graph conv: slabs (slab kernels) or workgroups of the tiled row pass
+    int gc_tiles_per_wg;     // tiled row pass: 16-row tiles per workgroup
     int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1 (+ 16*2*c0 + 2*c0 on the thin path)
     int thin;                // first layer handled by thin_tc1_bwd_kernel (Kt*c_in <= 16, c0 == 64)
 };
@@ -74,7 +89,16 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.off_ln_g = take((long)g.ln_sg * n);
     g.off_ln_b = take((long)g.ln_sg * n);
     g.gc_stride = (terms + 1) * 256;
-    g.off_gc = take(slabs1 * g.gc_stride);
+    g.gc_count = (int)slabs1;
+    g.gc_tiles_per_wg = 0;
+    if (gc_is_tiled(N, terms)) {   // ~1024 workgroups, whole groups of 4 tiles (one per wave)
+        const long tiles16 = (rows1 + 15) / 16;
+        long per = (tiles16 + 1023) / 1024;
+        per = (per + 3) / 4 * 4;
+        g.gc_tiles_per_wg = (int)per;
+        g.gc_count = (int)((tiles16 + per - 1) / per);
+    }
+    g.off_gc = take((long)g.gc_count * g.gc_stride);
     g.al_stride = c0 * c1 + c1 + (g.thin ? 16 * 2 * c0 + 2 * c0 : 0);
     g.off_al = take((long)g.al_wgs * g.al_stride);
     g.w1 = wgrad_geom(rows1, Kt * c_in, 2 * c0, 0);
@@ -371,6 +395,10 @@ struct GconvBwdArgs {
     int N, NP, Ks, kipf;
     int parts;           // workgroups per slab (see GconvFwdArgs); every part stages the slab and forms all G_k
     long slabs;
+    // tiled path only (launch_gconv_bwd_tiled; the slab kernel ignores them)
+    float* Gk;           // [terms][slabs][N][16] Clenshaw buffers g_k / b_k
+    int tiles_per_wg;    // BwdGeom::gc_tiles_per_wg
+    int wgs;             // BwdGeom::gc_count
 };
 
 template <int MAXQ, int MAXW>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)

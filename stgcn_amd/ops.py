@@ -122,24 +122,35 @@ def query_plan(desc: StblockDesc) -> StblockPlan:
 
 
 def gso_prepare(gso: torch.Tensor, terms: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Once per model (main.py:101-103 upload): the Chebyshev polynomials T_1 .. T_{terms-1} of the dense (N, N) graph
-    shift operator and their transposes, zero padded and in MFMA fragment order.  ``terms`` = operator terms of the graph
-    conv including the identity: Ks for ChebGraphConv, 2 for GraphConv (``graph_terms``)."""
+    """Once per model (main.py:101-103 upload): the dense (N, N) graph shift operator in the layout the graph-conv kernels
+    read (``stgcn_gso_layout``).  Up to 512 nodes: the Chebyshev polynomials T_1 .. T_{terms-1} and their transposes, zero
+    padded and in MFMA fragment order; beyond (tiled graph conv): the dense zero-padded operator and its transpose.
+    ``terms`` = operator terms of the graph conv including the identity: Ks for ChebGraphConv, 2 for GraphConv
+    (``graph_terms``)."""
     L = _lib.lib()
     gso = gso.detach().to(torch.float32).contiguous()
     _check_device(gso, "gso")
     N = gso.shape[0]
     assert gso.shape == (N, N)
-    NP = (N + 15) // 16 * 16
-    nm = max(int(terms) - 1, 1)
+    np_, nm_, ns_, tiled_ = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+    L.check(L.dll.stgcn_gso_layout(N, int(terms), C.byref(np_), C.byref(nm_), C.byref(ns_), C.byref(tiled_)), "stgcn_gso_layout")
+    NP, nm = int(np_.value), int(nm_.value)
     gp = torch.zeros(nm, NP, NP, dtype=torch.float32, device=gso.device)
     gt = torch.zeros(nm, NP, NP, dtype=torch.float32, device=gso.device)
-    scratch = torch.empty(3, NP, NP, dtype=torch.float32, device=gso.device)
+    scratch = torch.empty(max(int(ns_.value), 1), NP if ns_.value else 1, NP if ns_.value else 1, dtype=torch.float32, device=gso.device)
     L.check(L.dll.stgcn_gso_prepare(gso.data_ptr(), N, int(terms), gp.data_ptr(), gt.data_ptr(), scratch.data_ptr(), _stream_of(gso)),
             "stgcn_gso_prepare")
     if gso.is_cuda:
         torch.cuda.current_stream(gso.device).synchronize()     # scratch is freed on return
     return gp, gt
+
+
+def set_gc_tiled_min_nodes(n: int) -> int:
+    """Graphs with at least ``n`` nodes use the tiled graph conv (default 513); returns the previous threshold.  Operators
+    (``gso_prepare``) and plans made under one setting must be used under the same setting (test / tuning knob)."""
+    prev = int(_lib.lib().dll.stgcn_set_gc_tiled_min_nodes(int(n)))
+    _plan_cache.clear()
+    return prev
 
 
 def graph_terms(cfg: "BlockConfig") -> int:

@@ -37,3 +37,12 @@ def params_in_field_order(p, prefix, gct):
              gc + "weight", gc + "bias", "tmp_conv2.causal_conv.weight", "tmp_conv2.causal_conv.bias",
              "tmp_conv2.align.align_conv.weight", "tmp_conv2.align.align_conv.bias", "tc2_ln.weight", "tc2_ln.bias"]
     return [p.get(prefix + n) for n in names]
+
+
+def big_gso(n, seed, density=0.4):
+    """Dense non-symmetric operator for large graphs without an eigen-decomposition: rows scaled so that the infinity norm
+    (hence the spectral radius) is <= 1, like the rescaled Laplacian the reference feeds the Chebyshev recursion."""
+    rs = np.random.RandomState(seed)
+    a = rs.uniform(-1, 1, (n, n)).astype(np.float32)
+    a *= rs.uniform(size=(n, n)) < density
+    return (a / np.abs(a).sum(1).max()).astype(np.float32)
