@@ -123,6 +123,8 @@ typedef struct stgcn_stblock_plan {
     int64_t tiled_gc;                 /* 1: the graph conv runs the tiled GEMM path (N > 512 nodes, or more terms than the
                                          slab-resident backward holds in LDS); NP = roundup128(N) then                    */
     int64_t ws_Gk;                    /* tiled_gc: [terms][rows1][c1] Clenshaw buffers of the graph-conv backward         */
+    int64_t ws_XT;                    /* tiled_gc: two bf16 operand-form buffers (hi, lo planes of [CP][NP]) for the bf16 /
+                                         bf16x3 operator products (stgcn_set_gc_precision)                                */
 } stgcn_stblock_plan;
 
 int stgcn_version(void);
@@ -141,14 +143,22 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
 /* Buffer sizes of stgcn_gso_prepare for a graph of N nodes and `terms` operator terms: gso_pad / gso_t_pad hold `mats`
  * matrices of NP x NP floats each, scratch `scratch_mats` (0: scratch may be NULL).  Slab-resident graph conv (N <= 512):
  * NP = roundup16(N), mats = max(terms-1, 1) fragment-ordered polynomials.  Tiled graph conv (*tiled = 1; N > 512, the
- * 8192-node configs[4] of BASELINE.json): NP = roundup128(N), mats = 1 -- the dense zero-padded operator (gso_pad) and its
- * transpose (gso_t_pad), row major; the Chebyshev recursion of layers.py:153-161 then runs on the activations, one GEMM
- * launch per term (stgcn_kernels_gctile.hip.h).                                                                         */
+ * 8192-node configs[4] of BASELINE.json): NP = roundup128(N), mats = 2 -- the dense zero-padded operator (gso_pad) and its
+ * transpose (gso_t_pad), row major fp32, followed by the same matrix as two bf16 planes (hi, lo = bf16(x - hi)); the
+ * Chebyshev recursion of layers.py:153-161 then runs on the activations, one GEMM launch per term
+ * (stgcn_kernels_gctile.hip.h).                                                                                         */
 int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled);
 
 /* Tuning / test knob: graphs with at least n nodes use the tiled graph conv (default 513).  Returns the previous value;
  * n < 1 only queries.  Operators prepared under one setting must be used under the same setting.                        */
 int stgcn_set_gc_tiled_min_nodes(int32_t n);
+
+/* Arithmetic of the operator products (L X) on the tiled graph-conv path: 0 = fp32 MFMA (exact fp32 products, default: the
+ * 1e-4 parity bar of the fp32 configs), 1 = "bf16x3" (operands split into two bf16 each, three bf16 MFMAs per product,
+ * fp32 accumulation: fp32-class results at 16/3 of the fp32 MFMA rate), 2 = bf16 operands, fp32 accumulation
+ * (BASELINE.json configs[4] is quoted in bf16).  Everything else of the block stays fp32.  Returns the previous mode;
+ * a mode outside 0..2 only queries.                                                                                     */
+int stgcn_set_gc_precision(int32_t mode);
 
 /* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
  * offset is the high 64 counter bits).  offset_dev (nullable) points to a DEVICE uint64 added to `offset` when

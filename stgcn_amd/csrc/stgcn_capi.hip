@@ -366,16 +366,60 @@ int launch_gso_gemm(const char* label, const float* M, const float* X, float alp
     STGCN_LAUNCH(label, st, gso_gemm_kernel, dim3((unsigned)(g.row_tiles * g.col_tiles)), dim3(256), kGtLdsFloats * sizeof(float), g);
     return STGCN_OK;
 }
+// bf16 / bf16x3 operator product (g_gc_precision 2 / 1): operand planes as laid out by stgcn_gso_prepare (second matrix
+// slot: hi plane then lo plane) and by gc_pack_operand_kernel / the previous GEMM's epilogue
+struct OperandBuf { float* hi; float* lo; };
+inline OperandBuf operand_buf(float* XT, int which, long CP, int NP) {
+    float* base = XT + (size_t)which * CP * NP;   // CP * NP bf16 per plane = CP * NP / 2 floats, two planes per buffer
+    return OperandBuf{base, base + (size_t)CP * NP / 2};
+}
+int launch_pack_operand(const float* X, int N, int NP, long slabs, OperandBuf o, hipStream_t st) {
+    STGCN_LAUNCH("gc_pack_operand", st, gc_pack_operand_kernel, dim3((unsigned)cdiv(NP, 256), (unsigned)slabs), dim3(256), 256 * 17 * sizeof(float),
+                 X, N, NP, o.hi, o.lo);
+    return STGCN_OK;
+}
+int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, float alpha, const float* Z1, float b1, const float* Z2, float b2,
+                         float* out, const OperandBuf* next, int N, int NP, long slabs, hipStream_t st) {
+    GsoGemmBfArgs g;
+    memset(&g, 0, sizeof(g));
+    const size_t M = (size_t)NP * NP;
+    g.Mh = Mpad + M; g.Ml = Mpad + M + M / 2;
+    g.Xh = x.hi; g.Xl = x.lo;
+    if (next) { g.Oh = next->hi; g.Ol = next->lo; }
+    g.Z1 = Z1; g.Z2 = Z2; g.out = out; g.alpha = alpha; g.b1 = b1; g.b2 = b2;
+    g.N = N; g.NP = NP; g.slabs = slabs;
+    g.row_tiles = cdiv(N, 128);
+    g.col_tiles = (int)(gc_operand_cols(slabs) / 128);
+    const dim3 grid((unsigned)(g.row_tiles * g.col_tiles));
+    if (g_gc_precision == 1) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1>), grid, dim3(256), gb_lds_floats(1) * sizeof(float), g);
+    else STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0>), grid, dim3(256), gb_lds_floats(0) * sizeof(float), g);
+    return STGCN_OK;
+}
+
 int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
     if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
     if (a.Ks > 1 && !a.Xk) return fail(STGCN_ERR_INVALID, "tiled graph conv needs the X_k buffers");
     const long ks = a.slabs * a.N * 16;
+    const bool bf = g_gc_precision > 0 && a.Ks > 1;
+    if (bf && !a.XT) return fail(STGCN_ERR_INVALID, "tiled graph conv (bf16 operator products) needs the operand workspace");
+    const long CP = gc_operand_cols(a.slabs);
+    if (bf) {
+        const int rc = launch_pack_operand(a.A, a.N, a.NP, a.slabs, operand_buf(a.XT, 0, CP, a.NP), st);
+        if (rc) return rc;
+    }
     // X_1 = L X_0 ; X_k = 2 L X_{k-1} - X_{k-2}   (layers.py:153-161; GraphConv: X_1 = A_hat X_0, layers.py:198)
     for (int k = 1; k < a.Ks; ++k) {
         const float* Xm1 = k == 1 ? a.A : a.Xk + (size_t)(k - 2) * ks;
         const float* Xm2 = k == 1 ? nullptr : (k == 2 ? a.A : a.Xk + (size_t)(k - 3) * ks);
-        const int rc = launch_gso_gemm("gso_gemm_fwd", a.Lp, Xm1, k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f, a.Xk + (size_t)(k - 1) * ks,
-                                       a.N, a.NP, a.slabs, st);
+        float* out = a.Xk + (size_t)(k - 1) * ks;
+        int rc;
+        if (bf) {
+            const OperandBuf next = operand_buf(a.XT, k & 1, CP, a.NP);   // term k reads buffer (k - 1) & 1
+            rc = launch_gso_gemm_bf16("gso_gemm_fwd", a.Lp, operand_buf(a.XT, (k - 1) & 1, CP, a.NP), k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f,
+                                      out, k + 1 < a.Ks ? &next : nullptr, a.N, a.NP, a.slabs, st);
+        } else {
+            rc = launch_gso_gemm("gso_gemm_fwd", a.Lp, Xm1, k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f, out, a.N, a.NP, a.slabs, st);
+        }
         if (rc) return rc;
     }
     GcRowsFwdArgs r;
@@ -401,6 +445,22 @@ int launch_gconv_bwd_tiled(const GconvBwdArgs& a, hipStream_t st) {
     STGCN_LAUNCH("gconv_rows_bwd", st, gconv_rows_bwd_kernel, dim3((unsigned)a.wgs), dim3(256), (size_t)4 * (a.Ks + 1) * 256 * sizeof(float), r);
     if (K == 0) return STGCN_OK;
     auto gk = [&](int k) { return a.Gk + (size_t)k * ks; };
+    if (g_gc_precision > 0) {   // bf16 / bf16x3 products: b_{k+1} travels in operand form from epilogue to epilogue
+        if (!a.XT) return fail(STGCN_ERR_INVALID, "tiled graph-conv backward (bf16 operator products) needs the operand workspace");
+        const long CP = gc_operand_cols(a.slabs);
+        int cur = 0;
+        int rc = launch_pack_operand(gk(K), a.N, a.NP, a.slabs, operand_buf(a.XT, cur, CP, a.NP), st);
+        if (rc) return rc;
+        for (int k = K - 1; k >= 1; --k) {
+            const OperandBuf next = operand_buf(a.XT, cur ^ 1, CP, a.NP);
+            rc = launch_gso_gemm_bf16("gso_gemm_bwd", a.LTp, operand_buf(a.XT, cur, CP, a.NP), 2.f, gk(k), 1.f, k + 2 <= K ? gk(k + 2) : nullptr, -1.f,
+                                      gk(k), &next, a.N, a.NP, a.slabs, st);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+        return launch_gso_gemm_bf16("gso_gemm_bwd", a.LTp, operand_buf(a.XT, cur, CP, a.NP), 1.f, gk(0), 1.f, K >= 2 ? gk(2) : nullptr, -1.f, a.dA,
+                                    nullptr, a.N, a.NP, a.slabs, st);
+    }
     for (int k = K - 1; k >= 1; --k) {
         const int rc = launch_gso_gemm("gso_gemm_bwd", a.LTp, gk(k + 1), 2.f, gk(k), 1.f, k + 2 <= K ? gk(k + 2) : nullptr, -1.f, gk(k), a.N, a.NP,
                                        a.slabs, st);
@@ -658,6 +718,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_dZ1 = take(v.rows1 * v.NC1);
     p->tiled_gc = v.tiled;
     p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
+    p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)v.NP : 0);
     p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;
@@ -670,11 +731,17 @@ int stgcn_set_gc_tiled_min_nodes(int32_t n) {
     return prev;
 }
 
+int stgcn_set_gc_precision(int32_t mode) {
+    const int prev = g_gc_precision;
+    if (mode >= 0 && mode <= 2) g_gc_precision = mode;
+    return prev;
+}
+
 int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled) {
     if (N < 1 || N > 32768 || terms < 1 || terms > 9) return fail(STGCN_ERR_INVALID, "stgcn_gso_layout: bad arguments (1 <= N <= 32768, 1 <= terms <= 9)");
     const bool t = gc_is_tiled(N, terms);
     if (NP) *NP = gc_padded_nodes(N, terms);
-    if (mats) *mats = t ? 1 : (terms > 1 ? terms - 1 : 1);
+    if (mats) *mats = t ? 2 : (terms > 1 ? terms - 1 : 1);   // tiled: fp32 matrix, then its bf16 hi / lo planes
     if (scratch_mats) *scratch_mats = t ? 0 : 3;
     if (tiled) *tiled = t ? 1 : 0;
     return STGCN_OK;
@@ -690,6 +757,10 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
     if (gc_is_tiled(N, terms)) {   // dense padded operator and its transpose; the recursion runs on the activations
         STGCN_LAUNCH("gso_dense", st, gso_dense_kernel, grid, blk, 0, gso, (int)N, NP, gso_pad);
         STGCN_LAUNCH("gso_dense_t", st, gso_dense_t_kernel, grid, blk, 0, gso, (int)N, NP, gso_t_pad);
+        unsigned short* hp = reinterpret_cast<unsigned short*>(gso_pad + M);
+        unsigned short* ht = reinterpret_cast<unsigned short*>(gso_t_pad + M);
+        STGCN_LAUNCH("gso_bf16", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, 0, hp, hp + M);
+        STGCN_LAUNCH("gso_bf16_t", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, 1, ht, ht + M);
         return STGCN_OK;
     }
     float* D[3] = {scratch, scratch + M, scratch + 2 * M};   // D[0] = L (kept), D[1] / D[2]: T_{k-1} / T_{k-2} ring
@@ -756,6 +827,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     gc.A = saved + pl.sv_A; gc.Lp = gso_pad; gc.W = P->gc_w; gc.bias = P->gc_b;
     gc.Xk = saved + pl.sv_Xk; gc.G = saved + pl.sv_G;
     gc.N = d->N; gc.NP = v.NP; gc.Ks = v.terms; gc.kipf = d->graph_conv == STGCN_GC_KIPF; gc.slabs = v.slabs1;
+    gc.XT = pl.tiled_gc && v.terms > 1 ? ws + pl.ws_XT : nullptr;
     rc = launch_gconv_fwd(gc, st);
     if (rc) return rc;
 

@@ -18,6 +18,10 @@ namespace stgcn {
 // footprint allows; everything else runs the tiled GEMM path of stgcn_kernels_gctile.hip.h.  The node threshold is a
 // runtime knob (stgcn_set_gc_tiled_min_nodes) so that both paths can be compared on the same graph.
 inline int g_gc_tiled_min_n = 513;
+// arithmetic of the operator products on the tiled path: 0 = fp32 MFMA (exact fp32, default), 1 = bf16x3 (split operands,
+// fp32-class), 2 = bf16 (stgcn_set_gc_precision; see stgcn_kernels_gctile.hip.h)
+inline int g_gc_precision = 0;
+inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
 inline bool gc_is_tiled(int N, int terms) {
     if (N >= g_gc_tiled_min_n) return true;
     const long NP = (N + 15) / 16 * 16;
@@ -397,6 +401,7 @@ struct GconvBwdArgs {
     long slabs;
     // tiled path only (launch_gconv_bwd_tiled; the slab kernel ignores them)
     float* Gk;           // [terms][slabs][N][16] Clenshaw buffers g_k / b_k
+    float* XT;           // two bf16 operand-form buffers (plan: ws_XT), used when g_gc_precision > 0
     int tiles_per_wg;    // BwdGeom::gc_tiles_per_wg
     int wgs;             // BwdGeom::gc_count
 };

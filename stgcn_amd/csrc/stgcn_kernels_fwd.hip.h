@@ -976,6 +976,7 @@ struct GconvFwdArgs {
     int N, NP, Ks, kipf; // Ks = number of terms (kipf: 2)
     int parts;           // workgroups per slab: part p owns node tiles p, p + parts, ... (grid = slabs * parts)
     long slabs;
+    float* XT;           // tiled path only: two bf16 operand-form buffers (plan: ws_XT), used when g_gc_precision > 0
 };
 
 template <int MAXQ, int MAXW>

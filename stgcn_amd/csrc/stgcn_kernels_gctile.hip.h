@@ -286,4 +286,218 @@ __global__ __launch_bounds__(256) void gso_dense_t_kernel(const float* L, int N,
     D[e] = (h < N && i < N) ? L[(size_t)i * N + h] : 0.f;
 }
 
+// ================================================================================================
+// bf16 operator products (opt-in: stgcn_set_gc_precision; BASELINE.json configs[4] is a bf16 config).
+// The fp32-input MFMA runs at 1/16 of the bf16 rate, and at N = 8192 the operator GEMMs are 99 % of the step's FLOPs, so
+// the tiled path can form them on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation):
+//     precision 2 ("bf16")   : operands rounded to bf16                      -- ~3 significant digits per product
+//     precision 1 ("bf16x3") : operands split x = hi + lo (two bf16), M X ~= Mh Xh + Mh Xl + Ml Xh (the dropped Ml Xl term
+//                              and the split residuals are ~2^-17 relative): fp32-class results at 3 bf16 MFMAs per product,
+//                              still 16/3 of the fp32 MFMA rate
+// Both operands are k-contiguous 16-bit planes so that a fragment (8 consecutive k of one row) is one 16-B LDS read:
+//     operator          Mh, Ml : [NP][NP]                      (stgcn_gso_prepare, second matrix slot of gso_pad / gso_t_pad)
+//     activations  "operand form" Xh, Xl : [CP][NP], row = GEMM column = slab * 16 + channel, CP = roundup128(slabs * 16)
+// gc_pack_operand_kernel converts [slabs][N][16] fp32 into operand form once per chain; every GEMM of the recursion writes
+// its fp32 result AND the operand form of that result for the next term from its epilogue (D leaves a lane with 4
+// consecutive nodes of one column = one 8-B store per plane), so no other transposition pass exists.
+// The k order inside the 32-deep MFMA is irrelevant for correctness: lane (row l15, group g) of A and lane (column l15,
+// group g) of B hold the same 8 k values.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kGbBK = 64;                       // bf16 k values per pipeline step
+constexpr int kGbLD = (kGbBK + 8) / 2;          // LDS row stride in floats: 72 bf16 = 144 B (odd number of 16-B units)
+constexpr int kGbPlane = 128 * kGbLD;           // floats per staged plane (128 rows)
+inline int gb_lds_floats(int split) { return 2 * (split ? 4 : 2) * kGbPlane; }   // 73.7 KB (bf16) / 147.5 KB (bf16x3)
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {   // round-to-nearest-even, finite inputs
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
+// 4 consecutive values -> 4 bf16 (hi) and 4 bf16 of the remainders (lo), packed little-endian
+__device__ __forceinline__ void bf16_split4(f32x4 v, u32x2& hi, u32x2& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = bf16_rne(v[i]);
+        l[i] = bf16_rne(v[i] - bf16_to_f32(h[i]));
+    }
+    hi[0] = h[0] | (h[1] << 16); hi[1] = h[2] | (h[3] << 16);
+    lo[0] = l[0] | (l[1] << 16); lo[1] = l[2] | (l[3] << 16);
+}
+
+// dense zero-padded bf16 planes of the operator (T = 0) or of its transpose (T = 1): hi[h][i], lo[h][i]
+__global__ __launch_bounds__(256) void gso_bf16_kernel(const float* L, int N, int NP, int T, unsigned short* hi, unsigned short* lo) {
+    const long e = (long)blockIdx.x * kThreads + (long)threadIdx.x;
+    if (e >= (long)NP * NP) return;
+    const int h = (int)(e / NP), i = (int)(e - (long)h * NP);
+    const float v = (h < N && i < N) ? (T ? L[(size_t)i * N + h] : L[(size_t)h * N + i]) : 0.f;
+    const unsigned hh = bf16_rne(v);
+    hi[e] = (unsigned short)hh;
+    lo[e] = (unsigned short)bf16_rne(v - bf16_to_f32(hh));
+}
+
+// X [slabs][N][16] fp32 -> operand form (hi, lo) [CP][NP]; grid = (ceil(NP / 256), slabs), 256 nodes of one slab per workgroup
+__global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, int N, int NP, float* Oh, float* Ol) {
+    extern __shared__ float stgcn_smem[];   // [256][17]
+    const int tid = threadIdx.x, m0 = (int)blockIdx.x * 256;
+    const long slab = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i, node = f >> 2, c4 = f & 3, m = m0 + node;
+        const f32x4 v = m < N ? ld4(X + ((size_t)slab * N + m) * 16 + c4 * 4) : zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stgcn_smem[node * 17 + c4 * 4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, c = e >> 6, q = e & 63, m = m0 + 4 * q;   // a wave writes 512 contiguous bytes of one column
+        if (m < NP) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = stgcn_smem[(4 * q + j) * 17 + c];
+            u32x2 hi, lo;
+            bf16_split4(v, hi, lo);
+            const size_t o = (((size_t)slab * 16 + c) * NP + m) >> 1;   // float units (2 bf16 each)
+            *reinterpret_cast<u32x2*>(Oh + o) = hi;
+            *reinterpret_cast<u32x2*>(Ol + o) = lo;
+        }
+    }
+}
+
+struct GsoGemmBfArgs {
+    const float* Mh;     // operator planes, [NP][NP] bf16 viewed as [NP][NP/2] floats
+    const float* Ml;
+    const float* Xh;     // operand form of the input, [CP][NP] bf16
+    const float* Xl;
+    float* Oh;           // operand form of the result for the next term (nullable)
+    float* Ol;
+    const float* Z1;     // fp32 epilogue exactly as gso_gemm_kernel
+    const float* Z2;
+    float* out;
+    float alpha, b1, b2;
+    int N, NP, row_tiles, col_tiles;
+    long slabs;
+};
+
+// Same 128 x 128 workgroup tile, 2 x 2 waves of 64 x 64 and register-prefetched double buffering as gso_gemm_kernel;
+// per 64-deep step a wave issues 32 (bf16) or 96 (bf16x3) MFMAs of 16 cycles against 8 / 16 16-B loads per lane.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
+    extern __shared__ float stgcn_smem[];
+    constexpr int NPL = SPLIT ? 2 : 1;              // planes per operand
+    constexpr int BUF = 2 * NPL * kGbPlane;         // floats per pipeline buffer: A planes then B planes
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wm = w & 1, wn = w >> 1;
+    const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
+    const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
+    const int n0 = rt * 128, c0 = ct * 128, N = a.N, NP = a.NP, NPH = NP >> 1;   // NPH: floats per 16-bit row
+
+    f32x4 pa[NPL][4], pb[NPL][4];
+    auto fetch = [&](int kb) {
+        const int k0h = kb * (kGbBK / 2);   // float units
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c8 = f & 7;   // 8 x 16 B per 64-k row
+            const size_t oa = (size_t)(n0 + row) * NPH + k0h + c8 * 4, ob = (size_t)(c0 + row) * NPH + k0h + c8 * 4;
+            pa[0][i] = ld4(a.Mh + oa);
+            pb[0][i] = ld4(a.Xh + ob);
+            if (SPLIT) {
+                pa[NPL - 1][i] = ld4(a.Ml + oa);
+                pb[NPL - 1][i] = ld4(a.Xl + ob);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        float* base = stgcn_smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c8 = f & 7, o = row * kGbLD + c8 * 4;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                st4(base + p * kGbPlane + o, pa[p][i]);
+                st4(base + (NPL + p) * kGbPlane + o, pb[p][i]);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4();
+
+    const int nkb = (N + kGbBK - 1) / kGbBK;   // k >= N: zero operator columns, zero operand padding
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) fetch(kb + 1);
+        const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * kGbLD + 4 * g;
+        const float* Bs = stgcn_smem + buf * BUF + NPL * kGbPlane + (wn * 64 + l15) * kGbLD + 4 * g;
+#pragma unroll
+        for (int ks = 0; ks < kGbBK / 32; ++ks) {
+            bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * kGbLD + ks * 16));
+                bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * kGbLD + ks * 16));
+                if (SPLIT) {
+                    al[t] = __builtin_bit_cast(bf16x8, ld4(As + kGbPlane + t * 16 * kGbLD + ks * 16));
+                    bl[t] = __builtin_bit_cast(bf16x8, ld4(Bs + kGbPlane + t * 16 * kGbLD + ks * 16));
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (SPLIT) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (kb + 1 < nkb) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*64 + nt*16 + l15]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = c0 + wn * 64 + nt * 16 + l15;
+        const long slab = col >> 4;
+        const int ch = col & 15;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int nb = n0 + wm * 64 + mt * 16 + 4 * g;
+            f32x4 v = zero4();
+            if (slab < a.slabs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r < N) {
+                        const size_t o = ((size_t)slab * N + nb + r) * 16 + ch;
+                        float t = a.alpha * acc[mt][nt][r];
+                        if (a.Z1) t += a.b1 * a.Z1[o];
+                        if (a.Z2) t += a.b2 * a.Z2[o];
+                        a.out[o] = t;
+                        v[r] = t;
+                    }
+                }
+            }
+            if (a.Oh) {   // operand form of the result (zeros in the node / column padding)
+                u32x2 hi, lo;
+                bf16_split4(v, hi, lo);
+                const size_t o = ((size_t)col * NP + nb) >> 1;
+                *reinterpret_cast<u32x2*>(a.Oh + o) = hi;
+                *reinterpret_cast<u32x2*>(a.Ol + o) = lo;
+            }
+        }
+    }
+}
+
 }  // namespace stgcn

@@ -153,6 +153,18 @@ def set_gc_tiled_min_nodes(n: int) -> int:
     return prev
 
 
+GC_PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def set_gc_precision(mode) -> str:
+    """Arithmetic of the operator products of the tiled graph conv (graphs beyond 512 nodes): "fp32" (default, exact fp32
+    MFMA), "bf16x3" (split bf16 operands, fp32-class results) or "bf16" (``stgcn_set_gc_precision``).  Returns the previous
+    mode's name."""
+    code = GC_PRECISION[mode] if isinstance(mode, str) else int(mode)
+    prev = int(_lib.lib().dll.stgcn_set_gc_precision(code))
+    return {v: k for k, v in GC_PRECISION.items()}[prev]
+
+
 def graph_terms(cfg: "BlockConfig") -> int:
     return int(cfg.Ks) if cfg.graph_conv_type == "cheb_graph_conv" else 2
 

@@ -73,6 +73,7 @@ struct Fiber {
 };
 struct WaveState {
     float a[kWave], b[kWave];
+    float a8[kWave][8], b8[kWave][8];   // operands of the 32-deep bf16 MFMA
     uint32_t u[kWave];
     int arrived = 0;
     unsigned gen = 0;
@@ -131,6 +132,37 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
+
+// v_mfma_f32_16x16x32_bf16: lane l holds 8 bf16 of A[i = l & 15][k = 8 * (l >> 4) + e] and of B[k][j = l & 15]
+// (cdna_hip_programming.md section 3); C/D as the f32 form.  Products of bf16 values are exact in fp32; the
+// accumulation order of the hardware is not specified, an fmaf chain in k order stands in for it.
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short emu_u16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+    const unsigned t = emu::g.threadIdx_.x;
+    emu::WaveState& w = emu::g.waves[t / emu::kWave];
+    const int lane = t % emu::kWave;
+    const emu_u16x8 ua = __builtin_bit_cast(emu_u16x8, a), ub = __builtin_bit_cast(emu_u16x8, b);
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t xa = (uint32_t)ua[e] << 16, xb = (uint32_t)ub[e] << 16;
+        memcpy(&w.a8[lane][e], &xa, 4);
+        memcpy(&w.b8[lane][e], &xb, 4);
+    }
+    emu::wave_barrier();
+    emu_f32x4 d = c;
+    const int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 8; ++e) acc = fmaf(w.a8[i + 16 * kg][e], w.b8[j + 16 * kg][e], acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    if (lane == 0) emu::g.n_mfma++;
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)

@@ -29,7 +29,7 @@ CASES = [
     (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5, True),       # 5 terms: three Clenshaw steps
     (32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False),     # single term: no GEMM at all
     (128, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 10, 1, 5, True),
-    (64, (64, 16, 64), 3, 4, "cheb_graph_conv", "glu", 150, 3, 7, True),      # 2 operator row tiles, 15 slabs = 2 column tiles (ragged)
+    (64, (64, 16, 64), 3, 4, "cheb_graph_conv", "glu", 150, 3, 6, True),      # 2 operator row tiles, 12 slabs = 2 column tiles (ragged)
 ]
 
 
@@ -44,9 +44,16 @@ def test_tiled_block_against_stage_oracle(tiled_everywhere, c_in, channels, Kt, 
 def test_tiled_operator_layout(tiled_everywhere):
     gso = nonsym_gso(37, 2)
     gp, gt = ops.gso_prepare(torch.from_numpy(gso), 3)
-    assert gp.shape == (1, 128, 128) and gt.shape == (1, 128, 128)
+    assert gp.shape == (2, 128, 128) and gt.shape == (2, 128, 128)      # fp32 matrix, then its bf16 hi / lo planes
     assert np.array_equal(gp[0, :37, :37].numpy(), gso) and np.array_equal(gt[0, :37, :37].numpy(), gso.T)
     assert gp[0, 37:].abs().sum() == 0 and gp[0, :, 37:].abs().sum() == 0 and gt[0, 37:].abs().sum() == 0 and gt[0, :, 37:].abs().sum() == 0
+    for planes, ref in ((gp[1], gso), (gt[1], gso.T)):
+        u = planes.numpy().view(np.uint16).reshape(2, 128, 128)
+        hi = (u[0].astype(np.uint32) << 16).view(np.float32)
+        lo = (u[1].astype(np.uint32) << 16).view(np.float32)
+        assert np.abs(hi[:37, :37] - ref).max() <= 2.0 ** -8 * np.abs(ref).max()              # bf16 rounding
+        assert np.abs(hi[:37, :37] + lo[:37, :37] - ref).max() <= 2.0 ** -16 * np.abs(ref).max()   # split: 16 bits of mantissa
+        assert np.abs(hi[37:]).sum() == 0 and np.abs(hi[:, 37:]).sum() == 0 and np.abs(lo[37:]).sum() == 0 and np.abs(lo[:, 37:]).sum() == 0
 
 
 def _run(c_in, channels, Kt, Ks, gct, act, N, B, T, x_np, dy_np, p, gso):
@@ -101,3 +108,102 @@ def test_tiled_model_matches_reference_golden(tiled_everywhere, name):
     """Whole drop-in model through the tiled graph conv against the golden fixtures the reference itself produced."""
     from tests.test_emu_model import test_model_matches_reference_golden as run_model_case
     run_model_case(name)
+
+
+@pytest.fixture
+def precision():
+    """ops.set_gc_precision(...) for one test, restored afterwards."""
+    prev = {}
+
+    def use(mode):
+        prev.setdefault("mode", ops.set_gc_precision(mode))
+    try:
+        yield use
+    finally:
+        if "mode" in prev:
+            ops.set_gc_precision(prev["mode"])
+
+
+def _block_inputs(gct, Ks, N, B, T):
+    c_in, channels, Kt, act = 64, (64, 16, 64), 3, "glu"
+    _, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    gso = nonsym_gso(N, 9)
+    rs = np.random.RandomState(4)
+    x_np = rs.standard_normal((B, c_in, T, N)).astype(np.float32)
+    dy_np = rs.standard_normal((B, channels[2], T - 2 * (Kt - 1), N)).astype(np.float32)
+    return (c_in, channels, Kt, Ks, gct, act, N, B, T, x_np, dy_np, p, gso)
+
+
+_rms = lambda a: float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
+_rel = lambda a, b: float(np.abs(a - b).max() / max(1e-30, np.abs(a).max()))
+
+SHAPES = [("cheb_graph_conv", 3, 45, 2, 6), ("cheb_graph_conv", 5, 130, 3, 5), ("graph_conv", 1, 45, 2, 6)]      # 130 nodes x 9 slabs: 2 x 2 ragged tiles
+
+
+@pytest.mark.parametrize("gct,Ks,N,B,T", SHAPES)
+def test_bf16x3_operator_products_track_fp32(tiled_everywhere, precision, gct, Ks, N, B, T):
+    """Split-bf16 operands (three bf16 MFMAs per product, fp32 accumulation): ~2^-17 relative per product.  Against the
+    exact-fp32 path on an operator with row sums up to 6 (worse than any rescaled Laplacian): block output within 1e-3
+    abs after five recursion steps (1.5e-4 for Ks <= 3), every gradient within the 1e-3 relative bar of the fp32 configs."""
+    args = _block_inputs(gct, Ks, N, B, T)
+    ya, dxa, ga = _run(*args)
+    precision("bf16x3")
+    yb, dxb, gb = _run(*args)
+    assert 0 < np.abs(ya - yb).max() < (1e-3 if Ks > 3 else 1.5e-4)          # > 0: the bf16 kernels really ran
+    assert _rel(dxa, dxb) < 1e-3
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert _rel(a, b) < 1e-3
+
+
+@pytest.mark.parametrize("gct,Ks,N,B,T", SHAPES)
+def test_bf16_operator_products_track_fp32(tiled_everywhere, precision, gct, Ks, N, B, T):
+    """Plain bf16 operands (~3 significant digits per product): block output within 1 % rms of the fp32 path; gradients
+    upstream of the ReLU see its mask flip on ~0.3 % of the elements, i.e. ~6 % rms (inherent to a perturbed forward)."""
+    args = _block_inputs(gct, Ks, N, B, T)
+    ya, dxa, ga = _run(*args)
+    precision("bf16")
+    yb, dxb, gb = _run(*args)
+    assert 0 < _rms(ya - yb) < 1e-2 * _rms(ya)
+    assert _rms(dxa - dxb) < 0.15 * _rms(dxa)
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert _rms(a - b) <= 0.15 * _rms(a)
+
+
+def test_bf16_gemm_equals_rounded_operand_product(tiled_everywhere, precision):
+    """The bf16 kernel itself, exactly: X_1 = bf16(L) bf16(X_0) and X_2 = 2 bf16(L) bf16(X_1) - X_0 with fp32 accumulation,
+    checked against numpy on the rounded operands (only the summation order differs)."""
+    import ctypes as C
+    from stgcn_amd import _lib
+
+    def bf16(a):      # round to nearest even, as bf16_rne in the kernels
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    c_in, channels, Kt, Ks, gct, act, N, B, T, x_np, _, p, gso = _block_inputs("cheb_graph_conv", 3, 130, 3, 5)
+    L = _lib.lib()
+    bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=channels, act_func=act, graph_conv_type=gct, droprate=0.5)
+    desc = ops.make_desc(bcfg, B, T, training=False, need_dx=True)
+    plan = ops.query_plan(desc)
+    precision("bf16")
+    gp, _ = ops.gso_prepare(torch.from_numpy(gso), 3)
+    pst = ops._param_struct(_lib.StblockParams, params_in_field_order(p, "st_blocks.0.", gct))
+    x_cl = torch.from_numpy(np.ascontiguousarray(x_np.transpose(0, 2, 3, 1)))
+    y = torch.zeros(B, plan.T2, N, channels[2])
+    saved = torch.zeros(plan.saved_floats)
+    ws = torch.zeros(plan.ws_floats)
+    L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gp.data_ptr(), y.data_ptr(), saved.data_ptr(),
+                                        ws.data_ptr(), 1, 1, None, None), "fwd")
+    n = B * plan.T1 * N * 16
+    shape = (B * plan.T1, N, 16)
+    A = saved[plan.sv_A:plan.sv_A + n].numpy().reshape(shape)
+    X1 = saved[plan.sv_Xk:plan.sv_Xk + n].numpy().reshape(shape)
+    X2 = saved[plan.sv_Xk + n:plan.sv_Xk + 2 * n].numpy().reshape(shape)
+    Lr = bf16(gso).astype(np.float64)
+    X1_ref = np.einsum("hi,sic->shc", Lr, bf16(A).astype(np.float64))
+    X2_ref = 2.0 * np.einsum("hi,sic->shc", Lr, bf16(X1).astype(np.float64)) - A
+    assert np.abs(X1 - X1_ref).max() < 2e-5 and np.abs(X2 - X2_ref).max() < 4e-5
+    assert np.abs(X1 - np.einsum("hi,sic->shc", gso.astype(np.float64), A.astype(np.float64))).max() > 1e-4      # and it IS bf16

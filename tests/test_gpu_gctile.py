@@ -100,3 +100,114 @@ def test_tiled_equals_slab_resident_on_c2():
         assert (a is None) == (b is None)
         if a is not None:
             assert rel(a, b) < 5e-5
+
+
+# ---- bf16 / bf16x3 operator products (ops.set_gc_precision) -------------------------------------------------------------
+def _block_run(N, B, T, Ks, gso_np, tiled_min=None, precision="fp32", c_in=64, dev="cuda:0"):
+    """One training-mode block call (fixed inputs / dropout stream) -> y, dx, parameter gradients, saved tensor, plan."""
+    from stgcn_amd import ops
+    from tests.emu_util import block_case, params_in_field_order
+    from tests.gpu_util import bind_hip
+    bind_hip()
+    channels, Kt, gct, act = (64, 16, 64), 3, "cheb_graph_conv", "glu"
+    _, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(B, c_in, T, N, generator=g).to(dev)
+    dy = torch.randn(B, channels[2], T - 2 * (Kt - 1), N, generator=g).to(dev)
+    bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=channels, act_func=act, graph_conv_type=gct, droprate=0.5)
+    prev_n = ops.set_gc_tiled_min_nodes(tiled_min if tiled_min else 0)
+    prev_p = ops.set_gc_precision(precision)
+    try:
+        gp, gt = ops.gso_prepare(torch.from_numpy(gso_np).to(dev), ops.graph_terms(bcfg))
+        params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", gct)]
+        x = x0.clone().requires_grad_(True)
+        y = ops.st_conv_block(x, gp, gt, bcfg, params, True, 5, 1, ops.WorkspaceCache())
+        y.backward(dy)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gc_precision(prev_p)
+        ops.set_gc_tiled_min_nodes(prev_n)
+    return y.detach(), x.grad, [None if q is None or q.grad is None else q.grad for q in params]
+
+
+_rel = lambda a, b: float((a - b).abs().max() / max(1e-30, float(a.abs().max())))
+_rms = lambda a: float(a.double().pow(2).mean().sqrt())
+
+
+def test_bf16_gemm_equals_rounded_operand_product_on_hardware():
+    """v_mfma_f32_16x16x32_bf16 on the real matrix cores: X_1 = bf16(L) bf16(X_0), X_2 = 2 bf16(L) bf16(X_1) - X_0 against
+    numpy on the rounded operands (600 nodes: 5 operator row tiles, ragged tiles in both directions)."""
+    import ctypes as C
+    from stgcn_amd import _lib, ops
+    from tests.emu_util import block_case, nonsym_gso, params_in_field_order
+    from tests.gpu_util import bind_hip
+    L = bind_hip()
+    dev = "cuda:0"
+
+    def bf16(a):
+        u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    c_in, channels, Kt, Ks, gct, act, N, B, T = 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 600, 3, 5
+    _, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    gso = nonsym_gso(N, 9)
+    x = torch.randn(B, T, N, c_in, generator=torch.Generator().manual_seed(2)).to(dev)
+    bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=channels, act_func=act, graph_conv_type=gct, droprate=0.5)
+    desc = ops.make_desc(bcfg, B, T, training=False, need_dx=True)
+    plan = ops.query_plan(desc)
+    assert plan.tiled_gc == 1
+    res = {}
+    for mode in ("bf16", "bf16x3"):
+        prev = ops.set_gc_precision(mode)
+        try:
+            gp, _ = ops.gso_prepare(torch.from_numpy(gso).to(dev), 3)
+            params = [None if t is None else t.to(dev) for t in params_in_field_order(p, "st_blocks.0.", gct)]
+            pst = ops._param_struct(_lib.StblockParams, params)
+            y = torch.zeros(B, plan.T2, N, channels[2], device=dev)
+            saved = torch.zeros(plan.saved_floats, device=dev)
+            ws = torch.zeros(plan.ws_floats, device=dev)
+            L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x.data_ptr(), gp.data_ptr(), y.data_ptr(), saved.data_ptr(),
+                                                ws.data_ptr(), 1, 1, None, torch.cuda.current_stream().cuda_stream), "fwd")
+            torch.cuda.synchronize()
+        finally:
+            ops.set_gc_precision(prev)
+        n = B * plan.T1 * N * 16
+        sv = saved.cpu().numpy()
+        shape = (B * plan.T1, N, 16)
+        res[mode] = (sv[plan.sv_A:plan.sv_A + n].reshape(shape), sv[plan.sv_Xk:plan.sv_Xk + n].reshape(shape),
+                     sv[plan.sv_Xk + n:plan.sv_Xk + 2 * n].reshape(shape))
+    A, X1, X2 = res["bf16"]
+    Lr = bf16(gso).astype(np.float64)
+    X1_ref = np.einsum("hi,sic->shc", Lr, bf16(A).astype(np.float64))
+    X2_ref = 2.0 * np.einsum("hi,sic->shc", Lr, bf16(X1).astype(np.float64)) - A
+    assert np.abs(X1 - X1_ref).max() < 5e-5 and np.abs(X2 - X2_ref).max() < 1e-4
+    g64 = gso.astype(np.float64)
+    X1_f = np.einsum("hi,sic->shc", g64, A.astype(np.float64))
+    assert np.abs(X1 - X1_f).max() > 1e-4                       # plain bf16 differs visibly from fp32 ...
+    A3, X13, X23 = res["bf16x3"]
+    assert np.abs(X13 - X1_f).max() < 5e-5                      # ... the split product does not
+    assert np.abs(X23 - (2.0 * np.einsum("hi,sic->shc", g64, X13.astype(np.float64)) - A3)).max() < 1e-4
+
+
+def test_bf16x3_tracks_fp32_on_c2_and_on_8192_nodes():
+    from tests.emu_util import big_gso
+    for N, B, T, Ks, gso, tiled_min in ((207, 32, 8, 3, real_gso("metr_la.cheb_sym_norm_lap"), 1), (8192, 1, 5, 5, big_gso(8192, 3), None)):
+        ya, dxa, ga = _block_run(N, B, T, Ks, gso, tiled_min, "fp32")
+        yb, dxb, gb = _block_run(N, B, T, Ks, gso, tiled_min, "bf16x3")
+        assert 0 < float((ya - yb).abs().max()) < 5e-4, N
+        assert _rel(dxa, dxb) < 1e-3, N
+        for a, b in zip(ga, gb):
+            if a is not None:
+                assert _rel(a, b) < 1e-3, N
+
+
+def test_bf16_tracks_fp32_on_8192_nodes():
+    from tests.emu_util import big_gso
+    gso = big_gso(8192, 3)
+    ya, dxa, ga = _block_run(8192, 1, 5, 5, gso, None, "fp32")
+    yb, dxb, gb = _block_run(8192, 1, 5, 5, gso, None, "bf16")
+    assert 0 < _rms(ya - yb) < 2e-2 * _rms(ya)
+    assert _rms(dxa - dxb) < 0.2 * _rms(dxa)
+    for a, b in zip(ga, gb):
+        if a is not None:
+            assert _rms(a - b) <= 0.2 * _rms(a)

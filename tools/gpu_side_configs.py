@@ -5,7 +5,7 @@
 Full training step of the drop-in model (zero_grad + forward + MSE + backward + AdamW, dropout on), eager launches, the
 library's own hipEvent timers for the per-kernel split.  One JSON line per config on stdout.
 
-  python tools/gpu_side_configs.py c5 [c3] [--steps K]
+  python tools/gpu_side_configs.py c5 [c3] [--steps K] [--precision fp32 bf16x3 bf16]
 """
 import argparse
 import ctypes as C
@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 CONFIGS = {"c3": dict(N=325, Ks=3, B=64), "c5": dict(N=8192, Ks=5, B=16)}
 N_HIS, KT = 12, 3
 BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
-PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # 16 x the fp32 MFMA rate (dense; AMD's 5 PF figure is 2:1 sparse)
 
 
 def synthetic_operator(N, dev):
@@ -36,14 +37,16 @@ def synthetic_operator(N, dev):
     return a.to(dev)
 
 
-def run(name, steps):
-    from stgcn_amd import DropoutStream, _lib, models
+def run(name, steps, precision="fp32"):
+    from stgcn_amd import DropoutStream, _lib, models, ops
     from stgcn_amd.train import make_optimizer, train_step
     cfg = CONFIGS[name]
     N, Ks, B = cfg["N"], cfg["Ks"], cfg["B"]
     dev = torch.device("cuda", 0)
     L = _lib.lib()
     assert L.backend == "hip-gfx950"
+    ops.set_gc_precision(precision)          # operator products of the tiled graph conv (graphs beyond 512 nodes only)
+    torch.cuda.reset_peak_memory_stats()
     gso = synthetic_operator(N, dev)
     args = types.SimpleNamespace(Kt=KT, Ks=Ks, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True, droprate=0.5,
                                  n_his=N_HIS)
@@ -72,7 +75,7 @@ def run(name, steps):
     L.check(L.dll.stgcn_profile_collect(buf, len(buf)), "stgcn_profile_collect")
     L.dll.stgcn_profile_enable(0)
     prof = json.loads(buf.value.decode())
-    out = {"config": name, "N": N, "Ks": Ks, "batch": B, "dtype": "f32", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
+    out = {"config": name, "N": N, "Ks": Ks, "batch": B, "dtype": "f32", "operator_products": precision if N > 512 else "fp32", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
            "windows_per_s": round(B * steps / el, 1), "final_loss": round(float(loss.item()), 5),
            "mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
            "per_kernel_ms_per_step": {k: round(v["total_ms"] / ksteps, 4) for k, v in sorted(prof.items())}}
@@ -82,10 +85,14 @@ def run(name, steps):
         for lab in ("gso_gemm_fwd", "gso_gemm_bwd"):
             rec = prof.get(f"{lab}@{blk}")
             if rec:
-                fl = 2.0 * N * N * B * T1 * 16
-                us = 1e3 * rec["total_ms"] / rec["calls"]
+                fl = 2.0 * N * N * B * T1 * 16                      # algorithmic FLOPs of one operator product
+                issued = fl * {"fp32": 1, "bf16x3": 3, "bf16": 1}[precision]      # bf16x3 issues three bf16 MFMAs per product
+                peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+                us = max(1e3 * rec["total_ms"] / rec["calls"], 1e-6)
                 gemm[f"{lab}@{blk}"] = {"launches_per_step": rec["calls"] // ksteps, "avg_us": round(us, 1), "gflop_per_launch": round(fl / 1e9, 2),
-                                        "tflops": round(fl / (us * 1e-6) / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl / (us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                                        "algorithmic_tflops": round(fl / (us * 1e-6) / 1e12, 2),
+                                        "issued_mfma_tflops": round(issued / (us * 1e-6) / 1e12, 2), "mfma_peak_tflops": peak,
+                                        "frac_of_mfma_peak": round(issued / (us * 1e-6) / 1e12 / peak, 4)}
     if gemm:
         out["operator_gemm"] = gemm
     print(json.dumps(out), flush=True)
@@ -95,6 +102,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="+", choices=sorted(CONFIGS))
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--precision", nargs="+", default=["fp32"], choices=["fp32", "bf16x3", "bf16"])
     a = ap.parse_args()
     for c in a.configs:
-        run(c, a.steps)
+        for prec in (a.precision if CONFIGS[c]["N"] > 512 else ["fp32"]):
+            run(c, a.steps, prec)
