@@ -711,7 +711,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W1dense = take(p->recompute_tc1 ? (int64_t)v.KP1 * v.NC1 : 0);
     p->thin_tc1 = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms).thin;
     p->ws_WaDense = take(p->thin_tc1 ? (int64_t)d->c0 * d->c1 : 0);
-    p->ws_rowstat_b = take(2 * v.rows2);
+    p->ws_rowstat_b = take(2 * v.rows2 + 2 * v.slabs2);   // row partials, then the per-slab constants (big slabs only)
     p->ws_dZ2 = take(v.rows2 * v.NC2);
     p->ws_dYg = take(v.rows1 * d->c1);
     p->ws_dA = take(v.rows1 * d->c1);

@@ -37,6 +37,10 @@ struct WgradGeom {
     long off;   // arena offset: [chunks][Mpad*NC] then [chunks][NC] bias partials
     long floats;
 };
+// LayerNorm backward on big slabs (N * C / 4 >= 64 * 256 float4 columns, e.g. the 8192-node graph): every workgroup of
+// ln_gate_bwd_kernel would rebuild the slab constants c1, c2 from N row partials (colgroups x slabs x N x 8 B: 4 GB at
+// C5), so a tiny kernel forms them once per slab (ln_slab_consts_kernel) and the workgroups read two floats per slab.
+constexpr int kLnBigColgroups = 64;
 struct BwdGeom {
     int ln_spg, ln_sg;       // slabs per group / groups for the LayerNorm parameter partials
     int al_wgs;              // workgroups of align_gate_bwd (grid-stride over 64-row tiles)
@@ -77,6 +81,7 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     const long n = (long)N * c2, n4 = n / 4;
     const int colgroups = (int)((n4 + kThreads - 1) / kThreads);
     int sg = (512 + colgroups - 1) / colgroups;   // ~512 workgroups
+    if (colgroups >= kLnBigColgroups) sg = (4096 + colgroups - 1) / colgroups;   // big slabs (N*C >= 64 K): ~4096 workgroups, short slab walks
     if (sg > slabs2) sg = (int)slabs2;
     if (sg < 1) sg = 1;
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
@@ -128,6 +133,7 @@ struct LnBwdArgs {
     const float* mean;
     const float* rstd;
     float2* rowstat;     // [slabs*N]  (sum g, sum g*xhat) per row
+    float2* slabconst;   // [slabs] (c1, c2) formed by ln_slab_consts_kernel, or null: ln_gate_bwd_kernel rebuilds them itself
     float* dZ;           // [slabs*N][2*C]
     float* dgam_part;    // [sg][n]
     float* dbet_part;
@@ -173,6 +179,22 @@ __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
     if (valid && (q & (c4n - 1)) == 0) a.rowstat[slab * a.N + fast_div(q, c4n, pow2_shift(c4n))] = make_float2(s1, s2);
 }
 
+// c1 = mean(g), c2 = mean(g * xhat) of one slab from its row partials (same summation as ln_gate_bwd_kernel's own
+// rebuild: thread-strided partial sums, block_sum2); grid = slabs.  Launched only for big slabs (kLnBigColgroups).
+__global__ __launch_bounds__(256) void ln_slab_consts_kernel(LnBwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const long slab = blockIdx.x;
+    float x = 0.f, y = 0.f;
+    const float2* rs = a.rowstat + slab * a.N;
+    for (int r = threadIdx.x; r < a.N; r += kThreads) {
+        const float2 v = rs[r];
+        x += v.x;
+        y += v.y;
+    }
+    block_sum2(x, y, stgcn_smem);
+    if (threadIdx.x == 0) a.slabconst[slab] = make_float2(x / (float)a.n, y / (float)a.n);
+}
+
 // ================================================================================================
 // B1b: dH = rstd * (g - c1 - xhat * c2), gate backward -> dZ = [dU | dQ]; partial dgamma / dbeta.
 // c1 = mean(g), c2 = mean(g * xhat) of each slab are rebuilt from the row partials by the workgroup.
@@ -188,18 +210,26 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
     const int sg = blockIdx.y;
     long s0 = (long)sg * a.spg, s1 = s0 + a.spg;
     if (s1 > a.slabs) s1 = a.slabs;
-    for (long slab = s0; slab < s1; ++slab) {
-        float x = 0.f, y = 0.f;
-        const float2* rs = a.rowstat + slab * a.N;
-        for (int r = threadIdx.x; r < a.N; r += kThreads) {
-            const float2 v = rs[r];
-            x += v.x;
-            y += v.y;
+    if (a.slabconst) {
+        for (long i = threadIdx.x; i < s1 - s0; i += kThreads) {
+            const float2 c = a.slabconst[s0 + i];
+            cs[2 * i] = c.x;
+            cs[2 * i + 1] = c.y;
         }
-        block_sum2(x, y, stgcn_smem);
-        if (threadIdx.x == 0) {
-            cs[2 * (slab - s0)] = x / (float)a.n;
-            cs[2 * (slab - s0) + 1] = y / (float)a.n;
+    } else {
+        for (long slab = s0; slab < s1; ++slab) {
+            float x = 0.f, y = 0.f;
+            const float2* rs = a.rowstat + slab * a.N;
+            for (int r = threadIdx.x; r < a.N; r += kThreads) {
+                const float2 v = rs[r];
+                x += v.x;
+                y += v.y;
+            }
+            block_sum2(x, y, stgcn_smem);
+            if (threadIdx.x == 0) {
+                cs[2 * (slab - s0)] = x / (float)a.n;
+                cs[2 * (slab - s0) + 1] = y / (float)a.n;
+            }
         }
     }
     __syncthreads();

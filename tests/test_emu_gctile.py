@@ -207,3 +207,12 @@ def test_bf16_gemm_equals_rounded_operand_product(tiled_everywhere, precision):
     X2_ref = 2.0 * np.einsum("hi,sic->shc", Lr, bf16(X1).astype(np.float64)) - A
     assert np.abs(X1 - X1_ref).max() < 2e-5 and np.abs(X2 - X2_ref).max() < 4e-5
     assert np.abs(X1 - np.einsum("hi,sic->shc", gso.astype(np.float64), A.astype(np.float64))).max() > 1e-4      # and it IS bf16
+
+
+def test_layernorm_backward_on_big_slabs():
+    """N * C / 4 >= 64 * 256 float4 columns per slab (here 520 nodes x 128 channels): the slab constants of the LayerNorm
+    backward come from ln_slab_consts_kernel instead of every workgroup's own rebuild -- ST block and output head."""
+    bind_emulator()
+    run_backward_case(32, (64, 16, 128), 3, 2, "cheb_graph_conv", "gtu", 516, 2, 5, True)      # (seeded; no ReLU input within 1e-6 of zero)
+    from tests.test_emu_head import test_head_fwd_bwd as run_head_case
+    run_head_case(16, (128, 128), 2, 520, 3, 2, "glu", True)
