@@ -396,30 +396,34 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
     const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
     const int n0 = rt * 128, c0 = ct * 128, N = a.N, NP = a.NP, NPH = NP >> 1;   // NPH: floats per 16-bit row
 
-    f32x4 pa[NPL][4], pb[NPL][4];
-    auto fetch = [&](int kb) {
+    // Register ring: D chunks in flight (chunk c lives in set c % D).  One 64-deep chunk is only 512 (bf16) / 1536 (bf16x3)
+    // MFMA cycles per wave, far less than an L2 / HBM round trip, so a one-deep prefetch (as in the fp32 kernel, whose chunk
+    // lasts 4096 cycles) leaves the wave waiting for its operands every step.
+    constexpr int D = SPLIT ? 2 : 3;
+    f32x4 pa[D][NPL][4], pb[D][NPL][4];
+    auto fetch = [&](int kb, f32x4 (&qa)[NPL][4], f32x4 (&qb)[NPL][4]) {
         const int k0h = kb * (kGbBK / 2);   // float units
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, c8 = f & 7;   // 8 x 16 B per 64-k row
             const size_t oa = (size_t)(n0 + row) * NPH + k0h + c8 * 4, ob = (size_t)(c0 + row) * NPH + k0h + c8 * 4;
-            pa[0][i] = ld4(a.Mh + oa);
-            pb[0][i] = ld4(a.Xh + ob);
+            qa[0][i] = ld4(a.Mh + oa);
+            qb[0][i] = ld4(a.Xh + ob);
             if (SPLIT) {
-                pa[NPL - 1][i] = ld4(a.Ml + oa);
-                pb[NPL - 1][i] = ld4(a.Xl + ob);
+                qa[NPL - 1][i] = ld4(a.Ml + oa);
+                qb[NPL - 1][i] = ld4(a.Xl + ob);
             }
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, const f32x4 (&qa)[NPL][4], const f32x4 (&qb)[NPL][4]) {
         float* base = stgcn_smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, c8 = f & 7, o = row * kGbLD + c8 * 4;
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
-                st4(base + p * kGbPlane + o, pa[p][i]);
-                st4(base + (NPL + p) * kGbPlane + o, pb[p][i]);
+                st4(base + p * kGbPlane + o, qa[p][i]);
+                st4(base + (NPL + p) * kGbPlane + o, qb[p][i]);
             }
         }
     };
@@ -431,39 +435,48 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4();
 
     const int nkb = (N + kGbBK - 1) / kGbBK;   // k >= N: zero operator columns, zero operand padding
-    fetch(0);
-    stage(0);
+    fetch(0, pa[0], pb[0]);
+    stage(0, pa[0], pb[0]);
+#pragma unroll
+    for (int c = 1; c < D; ++c)
+        if (c < nkb) fetch(c, pa[c], pb[c]);
     __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nkb) fetch(kb + 1);
-        const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * kGbLD + 4 * g;
-        const float* Bs = stgcn_smem + buf * BUF + NPL * kGbPlane + (wn * 64 + l15) * kGbLD + 4 * g;
+    for (int kb0 = 0; kb0 < nkb; kb0 += D) {
 #pragma unroll
-        for (int ks = 0; ks < kGbBK / 32; ++ks) {
-            bf16x8 ah[4], al[4], bh[4], bl[4];
+        for (int j = 0; j < D; ++j) {   // unrolled so that the ring sets are compile-time register names
+            const int kb = kb0 + j;
+            if (kb < nkb) {
+                const int buf = kb & 1;
+                if (kb + D < nkb) fetch(kb + D, pa[j], pb[j]);   // set j held chunk kb, staged one step ago
+                const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * kGbLD + 4 * g;
+                const float* Bs = stgcn_smem + buf * BUF + NPL * kGbPlane + (wn * 64 + l15) * kGbLD + 4 * g;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * kGbLD + ks * 16));
-                bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * kGbLD + ks * 16));
-                if (SPLIT) {
-                    al[t] = __builtin_bit_cast(bf16x8, ld4(As + kGbPlane + t * 16 * kGbLD + ks * 16));
-                    bl[t] = __builtin_bit_cast(bf16x8, ld4(Bs + kGbPlane + t * 16 * kGbLD + ks * 16));
-                }
-            }
+                for (int ks = 0; ks < kGbBK / 32; ++ks) {
+                    bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if (SPLIT) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) {
+                        ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * kGbLD + ks * 16));
+                        bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * kGbLD + ks * 16));
+                        if (SPLIT) {
+                            al[t] = __builtin_bit_cast(bf16x8, ld4(As + kGbPlane + t * 16 * kGbLD + ks * 16));
+                            bl[t] = __builtin_bit_cast(bf16x8, ld4(Bs + kGbPlane + t * 16 * kGbLD + ks * 16));
+                        }
                     }
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            if (SPLIT) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                            }
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        }
                 }
+                if (kb + 1 < nkb) stage(buf ^ 1, pa[(j + 1) % D], pb[(j + 1) % D]);   // chunk kb + 1, requested D - 1 steps ago
+                __syncthreads();
+            }
         }
-        if (kb + 1 < nkb) stage(buf ^ 1);
-        __syncthreads();
     }
 
     // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*64 + nt*16 + l15]
