@@ -143,8 +143,9 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
 /* Buffer sizes of stgcn_gso_prepare for a graph of N nodes and `terms` operator terms: gso_pad / gso_t_pad hold `mats`
  * matrices of NP x NP floats each, scratch `scratch_mats` (0: scratch may be NULL).  Slab-resident graph conv (N <= 512):
  * NP = roundup16(N), mats = max(terms-1, 1) fragment-ordered polynomials.  Tiled graph conv (*tiled = 1; N > 512, the
- * 8192-node configs[4] of BASELINE.json): NP = roundup128(N), mats = 2 -- the dense zero-padded operator (gso_pad) and its
- * transpose (gso_t_pad), row major fp32, followed by the same matrix as two bf16 planes (hi, lo = bf16(x - hi)); the
+ * 8192-node configs[4] of BASELINE.json): NP = roundup128(N) -- the dense zero-padded operator (gso_pad) and its
+ * transpose (gso_t_pad), row major fp32, followed by the same matrix as two bf16 planes (hi, lo = bf16(x - hi)) whose rows
+ * are NP + stgcn_set_gc_ld_pad elements apart (mats = 1 + ceil((NP + pad) / NP)); the
  * Chebyshev recursion of layers.py:153-161 then runs on the activations, one GEMM launch per term
  * (stgcn_kernels_gctile.hip.h).                                                                                         */
 int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled);
@@ -159,6 +160,12 @@ int stgcn_set_gc_tiled_min_nodes(int32_t n);
  * (BASELINE.json configs[4] is quoted in bf16).  Everything else of the block stays fp32.  Returns the previous mode;
  * a mode outside 0..2 only queries.                                                                                     */
 int stgcn_set_gc_precision(int32_t mode);
+
+/* Tuning knob: extra bf16 elements (multiple of 8) between consecutive rows of every 16-bit plane of the tiled graph conv
+ * (operator hi / lo planes, activation operand form), so that the rows of a tile do not all start in the same L2 channel
+ * when NP is a power of two.  Changes the sizes stgcn_gso_layout / stgcn_stblock_plan_query report: set it before preparing
+ * operators and workspaces.  Returns the previous value; an invalid value only queries.                                 */
+int stgcn_set_gc_ld_pad(int32_t pad);
 
 /* y: (B, T2, N, c2).  seed/offset select the dropout stream (Philox4x32-10, counter = element/4, the
  * offset is the high 64 counter bits).  offset_dev (nullable) points to a DEVICE uint64 added to `offset` when

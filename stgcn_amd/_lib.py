@@ -126,6 +126,8 @@ class _Lib:
         d.stgcn_set_gc_tiled_min_nodes.restype = C.c_int
         d.stgcn_set_gc_precision.argtypes = [C.c_int32]
         d.stgcn_set_gc_precision.restype = C.c_int
+        d.stgcn_set_gc_ld_pad.argtypes = [C.c_int32]
+        d.stgcn_set_gc_ld_pad.restype = C.c_int
         d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
@@ -193,4 +195,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
                     "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack",
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
-                    "stgcn_set_gc_precision"]
+                    "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad"]

@@ -355,6 +355,12 @@ inline void gc_parts_override(int& fwd, int& bwd) {
 }
 
 // ---- tiled graph conv (stgcn_kernels_gctile.hip.h): one GEMM launch per operator term + one row pass -----------------
+template <int NTW>
+int launch_gso_gemm_ntw(const char* label, GsoGemmArgs g, hipStream_t st) {
+    g.col_tiles = cdiv(g.slabs, 2 * NTW);
+    STGCN_LAUNCH(label, st, (gso_gemm_kernel<NTW>), dim3((unsigned)(g.row_tiles * g.col_tiles)), dim3(256), gt_lds_floats(NTW) * sizeof(float), g);
+    return STGCN_OK;
+}
 int launch_gso_gemm(const char* label, const float* M, const float* X, float alpha, const float* Z1, float b1, const float* Z2, float b2,
                     float* out, int N, int NP, long slabs, hipStream_t st) {
     GsoGemmArgs g;
@@ -362,20 +368,35 @@ int launch_gso_gemm(const char* label, const float* M, const float* X, float alp
     g.M = M; g.X = X; g.Z1 = Z1; g.Z2 = Z2; g.out = out; g.alpha = alpha; g.b1 = b1; g.b2 = b2;
     g.N = N; g.NP = NP; g.slabs = slabs;
     g.row_tiles = cdiv(N, kGtBM);
-    g.col_tiles = cdiv(slabs, kGtSL);
-    STGCN_LAUNCH(label, st, gso_gemm_kernel, dim3((unsigned)(g.row_tiles * g.col_tiles)), dim3(256), kGtLdsFloats * sizeof(float), g);
-    return STGCN_OK;
+    // column extent of the workgroup tile (2 * NTW slabs): the launch costs rounds-of-resident-workgroups x work per
+    // workgroup (~NTW); ties go to the wider tile (fewer operator re-reads).  STGCN_GEMM_NTW=<3|4|5> forces one (tuning knob).
+    static const int force = getenv("STGCN_GEMM_NTW") ? atoi(getenv("STGCN_GEMM_NTW")) : 0;
+    int best = 4;
+    long best_cost = -1;
+    for (int ntw = 5; ntw >= 3; --ntw) {
+        const long wgs = (long)g.row_tiles * cdiv(slabs, 2 * ntw);
+        const int cap = ntw == 5 ? wg_capacity(gso_gemm_kernel<5>, 256, gt_lds_floats(5) * sizeof(float))
+                      : ntw == 4 ? wg_capacity(gso_gemm_kernel<4>, 256, gt_lds_floats(4) * sizeof(float))
+                                 : wg_capacity(gso_gemm_kernel<3>, 256, gt_lds_floats(3) * sizeof(float));
+        const long cost = (long)rounds_of(wgs, cap) * ntw;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ntw; }
+    }
+    if (force >= 3 && force <= 5) best = force;
+    if (best == 5) return launch_gso_gemm_ntw<5>(label, g, st);
+    if (best == 3) return launch_gso_gemm_ntw<3>(label, g, st);
+    return launch_gso_gemm_ntw<4>(label, g, st);
 }
 // bf16 / bf16x3 operator product (g_gc_precision 2 / 1): operand planes as laid out by stgcn_gso_prepare (second matrix
 // slot: hi plane then lo plane) and by gc_pack_operand_kernel / the previous GEMM's epilogue
 struct OperandBuf { float* hi; float* lo; };
 inline OperandBuf operand_buf(float* XT, int which, long CP, int NP) {
-    float* base = XT + (size_t)which * CP * NP;   // CP * NP bf16 per plane = CP * NP / 2 floats, two planes per buffer
-    return OperandBuf{base, base + (size_t)CP * NP / 2};
+    const size_t LD = (size_t)gc_plane_ld(NP);
+    float* base = XT + (size_t)which * CP * LD;   // CP * LD bf16 per plane = CP * LD / 2 floats, two planes per buffer
+    return OperandBuf{base, base + (size_t)CP * LD / 2};
 }
 int launch_pack_operand(const float* X, int N, int NP, long slabs, OperandBuf o, hipStream_t st) {
     STGCN_LAUNCH("gc_pack_operand", st, gc_pack_operand_kernel, dim3((unsigned)cdiv(NP, 256), (unsigned)slabs), dim3(256), 256 * 17 * sizeof(float),
-                 X, N, NP, o.hi, o.lo);
+                 X, N, NP, gc_plane_ld(NP), o.hi, o.lo);
     return STGCN_OK;
 }
 int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, float alpha, const float* Z1, float b1, const float* Z2, float b2,
@@ -383,7 +404,8 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     GsoGemmBfArgs g;
     memset(&g, 0, sizeof(g));
     const size_t M = (size_t)NP * NP;
-    g.Mh = Mpad + M; g.Ml = Mpad + M + M / 2;
+    g.LD = gc_plane_ld(NP);
+    g.Mh = Mpad + M; g.Ml = Mpad + M + (size_t)NP * g.LD / 2;
     g.Xh = x.hi; g.Xl = x.lo;
     if (next) { g.Oh = next->hi; g.Ol = next->lo; }
     g.Z1 = Z1; g.Z2 = Z2; g.out = out; g.alpha = alpha; g.b1 = b1; g.b2 = b2;
@@ -718,7 +740,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_dZ1 = take(v.rows1 * v.NC1);
     p->tiled_gc = v.tiled;
     p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
-    p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)v.NP : 0);
+    p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
     p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;
@@ -728,6 +750,12 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
 int stgcn_set_gc_tiled_min_nodes(int32_t n) {
     const int prev = g_gc_tiled_min_n;
     if (n >= 1) g_gc_tiled_min_n = n;
+    return prev;
+}
+
+int stgcn_set_gc_ld_pad(int32_t pad) {
+    const int prev = g_gc_ld_pad;
+    if (pad >= 0 && pad <= 65536 && (pad & 7) == 0) g_gc_ld_pad = pad;
     return prev;
 }
 
@@ -741,7 +769,9 @@ int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64
     if (N < 1 || N > 32768 || terms < 1 || terms > 9) return fail(STGCN_ERR_INVALID, "stgcn_gso_layout: bad arguments (1 <= N <= 32768, 1 <= terms <= 9)");
     const bool t = gc_is_tiled(N, terms);
     if (NP) *NP = gc_padded_nodes(N, terms);
-    if (mats) *mats = t ? 2 : (terms > 1 ? terms - 1 : 1);   // tiled: fp32 matrix, then its bf16 hi / lo planes
+    // tiled: fp32 matrix, then its bf16 hi / lo planes with leading dimension gc_plane_ld (NP * LD floats for both)
+    const int64_t np = gc_padded_nodes(N, terms);
+    if (mats) *mats = t ? 1 + (gc_plane_ld((int)np) + np - 1) / np : (terms > 1 ? terms - 1 : 1);
     if (scratch_mats) *scratch_mats = t ? 0 : 3;
     if (tiled) *tiled = t ? 1 : 0;
     return STGCN_OK;
@@ -759,8 +789,9 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
         STGCN_LAUNCH("gso_dense_t", st, gso_dense_t_kernel, grid, blk, 0, gso, (int)N, NP, gso_t_pad);
         unsigned short* hp = reinterpret_cast<unsigned short*>(gso_pad + M);
         unsigned short* ht = reinterpret_cast<unsigned short*>(gso_t_pad + M);
-        STGCN_LAUNCH("gso_bf16", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, 0, hp, hp + M);
-        STGCN_LAUNCH("gso_bf16_t", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, 1, ht, ht + M);
+        const int LD = gc_plane_ld(NP);
+        STGCN_LAUNCH("gso_bf16", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, LD, 0, hp, hp + (size_t)NP * LD);
+        STGCN_LAUNCH("gso_bf16_t", st, gso_bf16_kernel, grid, blk, 0, gso, (int)N, NP, LD, 1, ht, ht + (size_t)NP * LD);
         return STGCN_OK;
     }
     float* D[3] = {scratch, scratch + M, scratch + 2 * M};   // D[0] = L (kept), D[1] / D[2]: T_{k-1} / T_{k-2} ring

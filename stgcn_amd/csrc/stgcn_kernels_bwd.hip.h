@@ -22,6 +22,11 @@ inline int g_gc_tiled_min_n = 513;
 // fp32-class), 2 = bf16 (stgcn_set_gc_precision; see stgcn_kernels_gctile.hip.h)
 inline int g_gc_precision = 0;
 inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
+// Leading dimension (bf16 elements) of every 16-bit plane (operator hi / lo, operand form).  NP itself is a power-of-two
+// multiple of 128 for the sizes that matter (8192 nodes: 16 KiB rows), so the 128 rows of a tile would all start in the same
+// L2 channel; the pad (stgcn_set_gc_ld_pad, multiple of 8 elements) staggers them.
+inline int g_gc_ld_pad = 0;
+inline int gc_plane_ld(int NP) { return NP + g_gc_ld_pad; }
 inline bool gc_is_tiled(int N, int terms) {
     if (N >= g_gc_tiled_min_n) return true;
     const long NP = (N + 15) / 16 * 16;

@@ -18,11 +18,14 @@
 namespace stgcn {
 
 constexpr int kGtBM = 128;                  // nodes (output rows) per workgroup tile
-constexpr int kGtSL = 8;                    // slabs per workgroup tile: 8 x 16 channels = 128 GEMM columns
 constexpr int kGtBK = 32;                   // contraction (source node) chunk staged per pipeline step
 constexpr int kGtLDM = kGtBK + 4;           // LDS row stride of the operator tile   [128][36]
-constexpr int kGtLDX = kGtSL * 16 + 4;      // LDS row stride of the activation tile [32][132]
-constexpr int kGtLdsFloats = 2 * (kGtBM * kGtLDM + kGtBK * kGtLDX);   // double buffered: 70.7 KB, two workgroups per CU
+// The column extent of a workgroup tile is a template parameter: NTW = slab tiles per wave (3, 4 or 5), a workgroup covers
+// 2 * NTW slabs = 96 / 128 / 160 GEMM columns.  The launcher picks the NTW whose grid wastes least of its last round of
+// resident workgroups (C5: 160 slabs -> NTW 5 = 16 x 64 = 1024 workgroups = exactly two rounds on 512 slots, where
+// NTW 4 needs 1280 = 2.5 rounds; 96 slabs -> NTW 3 = 1024 as well).
+inline int gt_ldx(int ntw) { return 2 * ntw * 16 + 4; }                                        // LDS row stride of the activation tile
+inline int gt_lds_floats(int ntw) { return 2 * (kGtBM * kGtLDM + kGtBK * gt_ldx(ntw)); }      // double buffered: 62.5 / 70.7 / 78.8 KB
 
 // out[s][n][c] = alpha * sum_m M[n][m] X[s][m][c] + b1 * Z1[s][n][c] + b2 * Z2[s][n][c]        n < N, s < slabs
 // (Z1 / Z2 nullable; out may alias Z1 or Z2: every element is read and written by the same lane, X must not alias out)
@@ -33,30 +36,32 @@ struct GsoGemmArgs {
     const float* Z2;
     float* out;
     float alpha, b1, b2;
-    int N, NP, row_tiles, col_tiles;   // row_tiles = ceil(N / 128), col_tiles = ceil(slabs / 8)
+    int N, NP, row_tiles, col_tiles;   // row_tiles = ceil(N / 128), col_tiles = ceil(slabs / (2 * NTW))
     long slabs;
 };
 
-// Workgroup = 4 waves in a 2 x 2 arrangement, wave (wm, wn) owns 64 nodes x 4 slabs = 4 x 4 MFMA tiles (64 accumulator
-// VGPRs, 16 independent MFMA chains).  A operand = operator rows (lane: node l15, 4 consecutive source nodes = one 16-B
-// LDS read, the "16-chunk" k permutation of stgcn_device.hip.h), B operand = activations (lane: source node 4g+s, channel
-// l15), so D leaves lane (g, l15) with channel l15 of nodes 4g..4g+3: 64-B store segments, the 16 x 16 tile is 1 KiB
-// contiguous.  Per 32-node chunk a wave issues 128 MFMAs (4096 cycles) against 8 x 16-B global loads and 40 LDS reads per
-// lane: the kernel is MFMA-bound as long as the next chunk (prefetched into registers during the MFMAs) arrives in time.
-// Tiles that share operator rows run on one XCD (xcd_item): per XCD the resident workgroups stream a few operator row
-// tiles and all column tiles in lockstep through its L2.
+// Workgroup = 4 waves in a 2 x 2 arrangement, wave (wm, wn) owns 64 nodes x NTW slabs = 4 x NTW MFMA tiles (16 NTW
+// accumulator VGPRs, 4 NTW independent MFMA chains).  A operand = operator rows (lane: node l15, 4 consecutive source nodes =
+// one 16-B LDS read, the "16-chunk" k permutation of stgcn_device.hip.h), B operand = activations (lane: source node 4g+s,
+// channel l15), so D leaves lane (g, l15) with channel l15 of nodes 4g..4g+3: 64-B store segments, the 16 x 16 tile is 1 KiB
+// contiguous.  Per 32-node chunk a wave issues 32 NTW MFMAs (1024 NTW cycles) against 4 + NTW 16-B global loads and
+// 8 + 8 NTW LDS reads per lane: the kernel is MFMA-bound as long as the next chunk (prefetched into registers during the
+// MFMAs) arrives in time.  Tiles that share operator rows run on one XCD (xcd_item): per XCD the resident workgroups stream
+// a few operator row tiles and all column tiles in lockstep through its L2.
+template <int NTW>
 __global__ __launch_bounds__(256) void gso_gemm_kernel(GsoGemmArgs a) {
     extern __shared__ float stgcn_smem[];
+    constexpr int SL = 2 * NTW, LDX = SL * 16 + 4;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wm = w & 1, wn = w >> 1;
     const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
     const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
     const int n0 = rt * kGtBM, N = a.N, NP = a.NP;
-    const long slab0 = (long)ct * kGtSL;
+    const long slab0 = (long)ct * SL;
     float* const Ms = stgcn_smem;                         // [2][128][LDM]
     float* const Xs = stgcn_smem + 2 * kGtBM * kGtLDM;    // [2][32][LDX]
 
-    f32x4 pm[4], px[4];
+    f32x4 pm[4], px[NTW];
     auto fetch = [&](int kb) {
         const int k0 = kb * kGtBK;
 #pragma unroll
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void gso_gemm_kernel(GsoGemmArgs a) {
             pm[i] = ld4(a.M + (size_t)(n0 + row) * NP + k0 + c4 * 4);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NTW; ++i) {   // 32 nodes x SL slabs x 4 float4 = 128 SL = 256 NTW float4
             const int f = tid + 256 * i, c4 = f & 3, ml = (f >> 2) & 31, sl = f >> 7;   // 128 threads read 2 KiB of one slab
             const int m = k0 + ml;
             const long slab = slab0 + sl;
@@ -74,24 +79,24 @@ __global__ __launch_bounds__(256) void gso_gemm_kernel(GsoGemmArgs a) {
     };
     auto stage = [&](int buf) {
         float* ms = Ms + buf * kGtBM * kGtLDM;
-        float* xs = Xs + buf * kGtBK * kGtLDX;
+        float* xs = Xs + buf * kGtBK * LDX;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
             st4(ms + row * kGtLDM + c4 * 4, pm[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NTW; ++i) {
             const int f = tid + 256 * i, c4 = f & 3, ml = (f >> 2) & 31, sl = f >> 7;
-            st4(xs + ml * kGtLDX + sl * 16 + c4 * 4, px[i]);
+            st4(xs + ml * LDX + sl * 16 + c4 * 4, px[i]);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4();
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = zero4();
 
     const int nkb = (N + kGtBK - 1) / kGtBK;   // operator columns >= N are zero padding
     fetch(0);
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void gso_gemm_kernel(GsoGemmArgs a) {
         const int buf = kb & 1;
         if (kb + 1 < nkb) fetch(kb + 1);
         const float* ms = Ms + buf * kGtBM * kGtLDM + (wm * 64 + l15) * kGtLDM + 4 * g;
-        const float* xs = Xs + buf * kGtBK * kGtLDX + 4 * g * kGtLDX + wn * 64 + l15;
+        const float* xs = Xs + buf * kGtBK * LDX + 4 * g * LDX + wn * NTW * 16 + l15;
 #pragma unroll
         for (int kc = 0; kc < kGtBK / 16; ++kc) {
             f32x4 af[4];
@@ -109,23 +114,23 @@ __global__ __launch_bounds__(256) void gso_gemm_kernel(GsoGemmArgs a) {
             for (int mt = 0; mt < 4; ++mt) af[mt] = ld4(ms + mt * 16 * kGtLDM + kc * 16);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float bf[4];
+                float bf[NTW];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) bf[nt] = xs[(kc * 16 + s) * kGtLDX + nt * 16];
+                for (int nt = 0; nt < NTW; ++nt) bf[nt] = xs[(kc * 16 + s) * LDX + nt * 16];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma4(af[mt][s], bf[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mfma4(af[mt][s], bf[nt], acc[mt][nt]);
             }
         }
         if (kb + 1 < nkb) stage(buf ^ 1);   // the other buffer was last read before the barrier that ended step kb - 1
         __syncthreads();
     }
 
-    // epilogue: acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][slab slab0 + wn*4 + nt][channel l15]
+    // epilogue: acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][slab slab0 + wn*NTW + nt][channel l15]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const long slab = slab0 + wn * 4 + nt;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const long slab = slab0 + wn * NTW + nt;
         if (slab >= a.slabs) continue;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -329,18 +334,20 @@ __device__ __forceinline__ void bf16_split4(f32x4 v, u32x2& hi, u32x2& lo) {
 }
 
 // dense zero-padded bf16 planes of the operator (T = 0) or of its transpose (T = 1): hi[h][i], lo[h][i]
-__global__ __launch_bounds__(256) void gso_bf16_kernel(const float* L, int N, int NP, int T, unsigned short* hi, unsigned short* lo) {
+// (LD >= NP: leading dimension of the planes in bf16 elements, see gc_plane_ld)
+__global__ __launch_bounds__(256) void gso_bf16_kernel(const float* L, int N, int NP, int LD, int T, unsigned short* hi, unsigned short* lo) {
     const long e = (long)blockIdx.x * kThreads + (long)threadIdx.x;
     if (e >= (long)NP * NP) return;
     const int h = (int)(e / NP), i = (int)(e - (long)h * NP);
     const float v = (h < N && i < N) ? (T ? L[(size_t)i * N + h] : L[(size_t)h * N + i]) : 0.f;
     const unsigned hh = bf16_rne(v);
-    hi[e] = (unsigned short)hh;
-    lo[e] = (unsigned short)bf16_rne(v - bf16_to_f32(hh));
+    const size_t o = (size_t)h * LD + i;
+    hi[o] = (unsigned short)hh;
+    lo[o] = (unsigned short)bf16_rne(v - bf16_to_f32(hh));
 }
 
 // X [slabs][N][16] fp32 -> operand form (hi, lo) [CP][NP]; grid = (ceil(NP / 256), slabs), 256 nodes of one slab per workgroup
-__global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, int N, int NP, float* Oh, float* Ol) {
+__global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, int N, int NP, int LD, float* Oh, float* Ol) {
     extern __shared__ float stgcn_smem[];   // [256][17]
     const int tid = threadIdx.x, m0 = (int)blockIdx.x * 256;
     const long slab = blockIdx.y;
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, in
             for (int j = 0; j < 4; ++j) v[j] = stgcn_smem[(4 * q + j) * 17 + c];
             u32x2 hi, lo;
             bf16_split4(v, hi, lo);
-            const size_t o = (((size_t)slab * 16 + c) * NP + m) >> 1;   // float units (2 bf16 each)
+            const size_t o = (((size_t)slab * 16 + c) * LD + m) >> 1;   // float units (2 bf16 each)
             *reinterpret_cast<u32x2*>(Oh + o) = hi;
             *reinterpret_cast<u32x2*>(Ol + o) = lo;
         }
@@ -379,7 +386,7 @@ struct GsoGemmBfArgs {
     const float* Z2;
     float* out;
     float alpha, b1, b2;
-    int N, NP, row_tiles, col_tiles;
+    int N, NP, LD, row_tiles, col_tiles;   // LD: leading dimension of all 16-bit planes (bf16 elements, gc_plane_ld)
     long slabs;
 };
 
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
     const int wm = w & 1, wn = w >> 1;
     const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
     const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
-    const int n0 = rt * 128, c0 = ct * 128, N = a.N, NP = a.NP, NPH = NP >> 1;   // NPH: floats per 16-bit row
+    const int n0 = rt * 128, c0 = ct * 128, N = a.N, NPH = a.LD >> 1;   // NPH: floats per 16-bit row
 
     // Register ring: D chunks in flight (chunk c lives in set c % D).  One 64-deep chunk is only 512 (bf16) / 1536 (bf16x3)
     // MFMA cycles per wave, far less than an L2 / HBM round trip, so a one-deep prefetch (as in the fp32 kernel, whose chunk
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
             if (a.Oh) {   // operand form of the result (zeros in the node / column padding)
                 u32x2 hi, lo;
                 bf16_split4(v, hi, lo);
-                const size_t o = ((size_t)col * NP + nb) >> 1;
+                const size_t o = ((size_t)col * a.LD + nb) >> 1;
                 *reinterpret_cast<u32x2*>(a.Oh + o) = hi;
                 *reinterpret_cast<u32x2*>(a.Ol + o) = lo;
             }

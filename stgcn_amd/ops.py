@@ -153,6 +153,14 @@ def set_gc_tiled_min_nodes(n: int) -> int:
     return prev
 
 
+def set_gc_ld_pad(pad: int) -> int:
+    """Row padding (bf16 elements, multiple of 8) of the 16-bit planes of the tiled graph conv (``stgcn_set_gc_ld_pad``);
+    returns the previous value.  Operators and plans made under one setting must be used under the same setting."""
+    prev = int(_lib.lib().dll.stgcn_set_gc_ld_pad(int(pad)))
+    _plan_cache.clear()
+    return prev
+
+
 GC_PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 

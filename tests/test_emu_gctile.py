@@ -173,7 +173,33 @@ def test_bf16_operator_products_track_fp32(tiled_everywhere, precision, gct, Ks,
             assert _rms(a - b) <= 0.15 * _rms(a)
 
 
-def test_bf16_gemm_equals_rounded_operand_product(tiled_everywhere, precision):
+@pytest.fixture
+def ld_pad():
+    prev = {}
+
+    def use(pad):
+        prev.setdefault("pad", ops.set_gc_ld_pad(pad))
+    try:
+        yield use
+    finally:
+        if "pad" in prev:
+            ops.set_gc_ld_pad(prev["pad"])
+
+
+def test_padded_planes_give_identical_results(tiled_everywhere, precision, ld_pad):
+    """stgcn_set_gc_ld_pad only moves rows apart: bf16x3 block output and gradients are bitwise those of the unpadded planes."""
+    args = _block_inputs("cheb_graph_conv", 4, 45, 2, 6)
+    precision("bf16x3")
+    ya, dxa, ga = _run(*args)
+    ld_pad(2176)
+    yb, dxb, gb = _run(*args)
+    assert np.array_equal(ya, yb) and np.array_equal(dxa, dxb)
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+
+
+@pytest.mark.parametrize("pad", [0, 72])
+def test_bf16_gemm_equals_rounded_operand_product(tiled_everywhere, precision, ld_pad, pad):
     """The bf16 kernel itself, exactly: X_1 = bf16(L) bf16(X_0) and X_2 = 2 bf16(L) bf16(X_1) - X_0 with fp32 accumulation,
     checked against numpy on the rounded operands (only the summation order differs)."""
     import ctypes as C
@@ -189,6 +215,8 @@ def test_bf16_gemm_equals_rounded_operand_product(tiled_everywhere, precision):
     desc = ops.make_desc(bcfg, B, T, training=False, need_dx=True)
     plan = ops.query_plan(desc)
     precision("bf16")
+    ld_pad(pad)
+    plan = ops.query_plan(desc)
     gp, _ = ops.gso_prepare(torch.from_numpy(gso), 3)
     pst = ops._param_struct(_lib.StblockParams, params_in_field_order(p, "st_blocks.0.", gct))
     x_cl = torch.from_numpy(np.ascontiguousarray(x_np.transpose(0, 2, 3, 1)))

@@ -52,3 +52,10 @@ def test_operator_stationary_graph_conv(per_cu):
 def test_head_tap_masked_kernels():
     # the row-tile kernels the output head used before the dense 32 x 256 tiles (tconv_fwd4_kernel) stay selectable
     run_subset({"STGCN_TCONV4": "0"}, ["tests/test_emu_head.py"], "head")
+
+
+@pytest.mark.parametrize("ntw", [4, 5])
+def test_tiled_gemm_column_extents(ntw):
+    # workgroup tiles of 128 / 160 GEMM columns of the tiled graph conv's fp32 operator GEMM (the emulator's residency
+    # heuristic always picks the 96-column tile); 150-node graph with 12 slabs: ragged tiles in both directions
+    run_subset({"STGCN_GEMM_NTW": str(ntw)}, ["tests/test_emu_gctile.py"], "stage_oracle and 150")

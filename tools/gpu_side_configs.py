@@ -37,7 +37,7 @@ def synthetic_operator(N, dev):
     return a.to(dev)
 
 
-def run(name, steps, precision="fp32"):
+def run(name, steps, precision="fp32", ldpad=None):
     from stgcn_amd import DropoutStream, _lib, models, ops
     from stgcn_amd.train import make_optimizer, train_step
     cfg = CONFIGS[name]
@@ -46,6 +46,8 @@ def run(name, steps, precision="fp32"):
     L = _lib.lib()
     assert L.backend == "hip-gfx950"
     ops.set_gc_precision(precision)          # operator products of the tiled graph conv (graphs beyond 512 nodes only)
+    if ldpad is not None:
+        ops.set_gc_ld_pad(ldpad)             # row padding of the 16-bit planes (tuning knob)
     torch.cuda.reset_peak_memory_stats()
     gso = synthetic_operator(N, dev)
     args = types.SimpleNamespace(Kt=KT, Ks=Ks, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True, droprate=0.5,
@@ -75,7 +77,7 @@ def run(name, steps, precision="fp32"):
     L.check(L.dll.stgcn_profile_collect(buf, len(buf)), "stgcn_profile_collect")
     L.dll.stgcn_profile_enable(0)
     prof = json.loads(buf.value.decode())
-    out = {"config": name, "N": N, "Ks": Ks, "batch": B, "dtype": "f32", "operator_products": precision if N > 512 else "fp32", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
+    out = {"config": name, "N": N, "Ks": Ks, "batch": B, "dtype": "f32", "operator_products": precision if N > 512 else "fp32", "ld_pad": ops.set_gc_ld_pad(-1), "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
            "windows_per_s": round(B * steps / el, 1), "final_loss": round(float(loss.item()), 5),
            "mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
            "per_kernel_ms_per_step": {k: round(v["total_ms"] / ksteps, 4) for k, v in sorted(prof.items())}}
@@ -103,7 +105,9 @@ if __name__ == "__main__":
     ap.add_argument("configs", nargs="+", choices=sorted(CONFIGS))
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--precision", nargs="+", default=["fp32"], choices=["fp32", "bf16x3", "bf16"])
+    ap.add_argument("--ldpad", nargs="+", type=int, default=[None], help="row padding(s) of the 16-bit planes to try (bf16 elements)")
     a = ap.parse_args()
     for c in a.configs:
-        for prec in (a.precision if CONFIGS[c]["N"] > 512 else ["fp32"]):
-            run(c, a.steps, prec)
+        for pad in a.ldpad:
+            for prec in (a.precision if CONFIGS[c]["N"] > 512 else ["fp32"]):
+                run(c, a.steps, prec, pad)
