@@ -238,7 +238,7 @@ class STConvBlock(nn.Module):
 
     def _operators(self, device):
         gso = self.gso
-        key = (gso.data_ptr(), gso._version, str(device))
+        key = (gso.data_ptr(), gso._version, str(device), ops.gc_layout_epoch())
         if self._gso_cache is None or self._gso_cache[0] != key:
             gp, gt = ops.gso_prepare(gso.to(device), ops.graph_terms(self.cfg))
             self._gso_cache = (key, gp, gt)

@@ -145,19 +145,30 @@ def gso_prepare(gso: torch.Tensor, terms: int) -> Tuple[torch.Tensor, torch.Tens
     return gp, gt
 
 
+_gc_layout_epoch = 0      # bumped whenever a knob changes operator / workspace layouts: modules re-prepare their cached operators
+
+
+def gc_layout_epoch() -> int:
+    return _gc_layout_epoch
+
+
 def set_gc_tiled_min_nodes(n: int) -> int:
     """Graphs with at least ``n`` nodes use the tiled graph conv (default 513); returns the previous threshold.  Operators
     (``gso_prepare``) and plans made under one setting must be used under the same setting (test / tuning knob)."""
+    global _gc_layout_epoch
     prev = int(_lib.lib().dll.stgcn_set_gc_tiled_min_nodes(int(n)))
     _plan_cache.clear()
+    _gc_layout_epoch += 1
     return prev
 
 
 def set_gc_ld_pad(pad: int) -> int:
     """Row padding (bf16 elements, multiple of 8) of the 16-bit planes of the tiled graph conv (``stgcn_set_gc_ld_pad``);
     returns the previous value.  Operators and plans made under one setting must be used under the same setting."""
+    global _gc_layout_epoch
     prev = int(_lib.lib().dll.stgcn_set_gc_ld_pad(int(pad)))
     _plan_cache.clear()
+    _gc_layout_epoch += 1
     return prev
 
 

@@ -137,7 +137,7 @@ def _block_inputs(gct, Ks, N, B, T):
 _rms = lambda a: float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
 _rel = lambda a, b: float(np.abs(a - b).max() / max(1e-30, np.abs(a).max()))
 
-SHAPES = [("cheb_graph_conv", 3, 45, 2, 6), ("cheb_graph_conv", 5, 130, 3, 5), ("graph_conv", 1, 45, 2, 6)]      # 130 nodes x 9 slabs: 2 x 2 ragged tiles
+SHAPES = [("cheb_graph_conv", 3, 45, 2, 6), ("cheb_graph_conv", 5, 130, 2, 5), ("graph_conv", 1, 45, 2, 6)]      # 130 nodes: 2 ragged row tiles
 
 
 @pytest.mark.parametrize("gct,Ks,N,B,T", SHAPES)
@@ -243,4 +243,31 @@ def test_layernorm_backward_on_big_slabs():
     bind_emulator()
     run_backward_case(32, (64, 16, 128), 3, 2, "cheb_graph_conv", "gtu", 516, 2, 5, True)      # (seeded; no ReLU input within 1e-6 of zero)
     from tests.test_emu_head import test_head_fwd_bwd as run_head_case
-    run_head_case(16, (128, 128), 2, 520, 3, 2, "glu", True)
+    run_head_case(16, (128, 128), 2, 520, 2, 2, "glu", True)
+
+
+def test_module_reprepares_operator_when_the_layout_knobs_change():
+    """STConvBlock caches its prepared operator; changing the tiled threshold / plane padding must invalidate that cache
+    (otherwise the kernels would read a fragment-ordered buffer as a dense matrix)."""
+    from tests.test_emu_model import _build
+    fx, model, x, _ = _build("tiny_cheb_f32")
+    model.eval()
+    with torch.no_grad():
+        a = model(x)
+        prev = ops.set_gc_tiled_min_nodes(1)
+        try:
+            b = model(x)
+            pad = ops.set_gc_ld_pad(64)
+            try:
+                prec = ops.set_gc_precision("bf16x3")
+                try:
+                    c = model(x)
+                finally:
+                    ops.set_gc_precision(prec)
+            finally:
+                ops.set_gc_ld_pad(pad)
+        finally:
+            ops.set_gc_tiled_min_nodes(prev)
+        d = model(x)
+    assert torch.equal(a, d)
+    assert (a - b).abs().max() < 2e-5 and (a - c).abs().max() < 2e-4
