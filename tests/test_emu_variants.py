@@ -31,7 +31,7 @@ def test_transposed_conv_wave_variants(waves):
     run_subset({"STGCN_BWD_DATA_WAVES": str(waves)}, [BWD], "17-2-6")
 
 
-@pytest.mark.parametrize("parts", ["1,1", pytest.param("2,3", marks=pytest.mark.full), "4,2"])
+@pytest.mark.parametrize("parts", [pytest.param("1,1", marks=pytest.mark.full), pytest.param("2,3", marks=pytest.mark.full), "4,2"])
 def test_graph_conv_slab_parts(parts):
     # workgroups per (b, t) slab of the graph conv, forward / backward (Chebyshev Ks = 3 and 5, Kipf, 300-node graph)
     run_subset({"STGCN_GC_PARTS": parts}, [FWD], "17-1-6 or 35-1-5 or 9-2-5" + (" or 300-6-12" if parts != "1,1" else ""))
