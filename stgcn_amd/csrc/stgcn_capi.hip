@@ -413,8 +413,15 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     g.row_tiles = cdiv(N, 128);
     g.col_tiles = (int)(gc_operand_cols(slabs) / 128);
     const dim3 grid((unsigned)(g.row_tiles * g.col_tiles));
-    if (g_gc_precision == 1) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1>), grid, dim3(256), gb_lds_floats(1) * sizeof(float), g);
-    else STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0>), grid, dim3(256), gb_lds_floats(0) * sizeof(float), g);
+    // depth of a pipeline step: 32 (more workgroups per CU) or 64 bf16 (half as many barriers); STGCN_GEMM_BF16_BK forces one
+    static const int force_bk = getenv("STGCN_GEMM_BF16_BK") ? atoi(getenv("STGCN_GEMM_BF16_BK")) : 0;
+    const int bk = force_bk == 32 || force_bk == 64 ? force_bk : kGbDefaultBK;
+    const int split = g_gc_precision == 1;
+    const size_t lds = gb_lds_floats(split, bk) * sizeof(float);
+    if (split && bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 64>), grid, dim3(256), lds, g);
+    else if (split) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 32>), grid, dim3(256), lds, g);
+    else if (bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0, 64>), grid, dim3(256), lds, g);
+    else STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0, 32>), grid, dim3(256), lds, g);
     return STGCN_OK;
 }
 

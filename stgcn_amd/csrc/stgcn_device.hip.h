@@ -42,6 +42,13 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4, gfx950): lane i of the wave copies its 16 bytes at g to
+// lds_base + 16 * i, where lds_base must be WAVE-UNIFORM (it travels in M0) -- the LDS image of one instruction is always the
+// 1 KiB lane-linear block, any permutation has to be applied to the per-lane source address.  Completion is counted in vmcnt;
+// __syncthreads() drains it before the barrier.
+__device__ __forceinline__ void glds16(const void* g, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
 __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;

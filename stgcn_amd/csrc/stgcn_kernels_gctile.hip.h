@@ -311,16 +311,18 @@ __global__ __launch_bounds__(256) void gso_dense_t_kernel(const float* L, int N,
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kGbBK = 64;                       // bf16 k values per pipeline step
-// LDS image of a staged plane: 128 rows of 128 B (64 bf16), NO padding; the 16-B chunk c of row r sits at chunk position
-// c ^ ((r >> 1) & 7).  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32 for the upper
-// half) over 64 banks (MI355X_MICROARCH.md, LDS): a fragment read takes rows l15 = 0-3,12-15 at chunk g and rows 4-11 at chunk
-// g+1 in ONE group, which collides 2-way for every padded row stride of the form 16 B x odd (r56: a third of the LDS-active
-// cycles were conflicts); with this XOR the 8 even and the 8 odd rows of a group each cover the 8 chunk positions of their
-// 128-B half of the bank row exactly once.  The staging stores (8 consecutive lanes = one row) stay conflict-free.
-constexpr int kGbLD = kGbBK / 2;                // LDS row stride in floats: 64 bf16 = 128 B
-constexpr int kGbPlane = 128 * kGbLD;           // floats per staged plane (128 rows)
-inline int gb_lds_floats(int split) { return 2 * (split ? 4 : 2) * kGbPlane; }   // 64 KB (bf16) / 128 KB (bf16x3)
+// LDS image of a staged plane: 128 rows of BK bf16 (BK = 64: 128-B rows, BK = 32: 64-B rows), NO padding; the 16-B chunk c of
+// row r sits at chunk position c ^ gb_swz<BK>(r).  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31} (+32 for the upper half) over 64 banks (MI355X_MICROARCH.md, LDS): a fragment read takes rows
+// l15 = 0-3,12-15 at chunk g and rows 4-11 at chunk g+1 in ONE group, which collides 2-way for every padded row stride of the
+// form 16 B x odd (r56: a third of the LDS-active cycles were conflicts).  BK = 64: with (r >> 1) & 7 the 8 even and the 8 odd
+// rows of a group each cover the 8 chunk positions of their 128-B half of the bank row exactly once.  BK = 32 (four rows per
+// 256-B bank row): the four rows of a group that share r mod 4 are r = q, q+12 at chunk g and q+4, q+8 at chunk g+1, and
+// (0, 3, 2, 1)[r >> 2] sends them to four different positions.  The lane-linear image a global -> LDS copy writes (8 or 16 whole
+// rows per wave instruction) is conflict-free by construction.
+template <int BK> __device__ __forceinline__ int gb_swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
+constexpr int kGbDefaultBK = 32;   // r61: equal on the 1280-workgroup launches, 7-16 % faster on the 768-workgroup ones
+inline int gb_lds_floats(int split, int bk) { return 2 * (split ? 4 : 2) * 128 * (bk / 2); }   // BK 64: 64 / 128 KB, BK 32: 32 / 64 KB
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {   // round-to-nearest-even, finite inputs
     const unsigned u = __builtin_bit_cast(unsigned, x);
@@ -396,47 +398,43 @@ struct GsoGemmBfArgs {
     long slabs;
 };
 
-// Same 128 x 128 workgroup tile, 2 x 2 waves of 64 x 64 and register-prefetched double buffering as gso_gemm_kernel;
-// per 64-deep step a wave issues 32 (bf16) or 96 (bf16x3) MFMAs of 16 cycles against 8 / 16 16-B loads per lane.
-template <int SPLIT>
+// Same 128 x 128 workgroup tile and 2 x 2 waves of 64 x 64 as gso_gemm_kernel; per BK-deep step a wave issues BK/2 (bf16) or
+// 3 BK/2 (bf16x3) MFMAs of 16 cycles.  BK = 32 halves the LDS footprint (32 / 64 KB): three (bf16) / two (bf16x3) workgroups
+// per CU instead of two / one, i.e. more independent waves to fill the copy / barrier / fragment-read gaps of each other.
+template <int SPLIT, int BK>
 __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
     extern __shared__ float stgcn_smem[];
     constexpr int NPL = SPLIT ? 2 : 1;              // planes per operand
-    constexpr int BUF = 2 * NPL * kGbPlane;         // floats per pipeline buffer: A planes then B planes
+    constexpr int LD = BK / 2;                      // floats per staged row
+    constexpr int PLANE = 128 * LD;                 // floats per staged plane (128 rows)
+    constexpr int BUF = 2 * NPL * PLANE;            // floats per pipeline buffer: A planes then B planes
+    constexpr int CPR = BK / 8;                     // 16-B chunks per row (8 / 4)
+    constexpr int RPI = 64 / CPR;                   // rows one wave instruction of the global -> LDS copy fills (8 / 16)
+    constexpr int NI = 128 / (4 * RPI);             // copy instructions per plane and wave (4 / 2)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wm = w & 1, wn = w >> 1;
     const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
     const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
     const int n0 = rt * 128, c0 = ct * 128, N = a.N, NPH = a.LD >> 1;   // NPH: floats per 16-bit row
 
-    // Register ring: D chunks in flight (chunk c lives in set c % D).  One 64-deep chunk is only 512 (bf16) / 1536 (bf16x3)
-    // MFMA cycles per wave, far less than an L2 / HBM round trip, so a one-deep prefetch (as in the fp32 kernel, whose chunk
-    // lasts 4096 cycles) leaves the wave waiting for its operands every step.
-    constexpr int D = SPLIT ? 2 : 3;
-    f32x4 pa[D][NPL][4], pb[D][NPL][4];
-    auto fetch = [&](int kb, f32x4 (&qa)[NPL][4], f32x4 (&qb)[NPL][4]) {
-        const int k0h = kb * (kGbBK / 2);   // float units
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, c8 = f & 7;   // 8 x 16 B per 64-k row
-            const size_t oa = (size_t)(n0 + row) * NPH + k0h + c8 * 4, ob = (size_t)(c0 + row) * NPH + k0h + c8 * 4;
-            qa[0][i] = ld4(a.Mh + oa);
-            qb[0][i] = ld4(a.Xh + ob);
-            if (SPLIT) {
-                qa[NPL - 1][i] = ld4(a.Ml + oa);
-                qb[NPL - 1][i] = ld4(a.Xl + ob);
-            }
-        }
-    };
-    auto stage = [&](int buf, const f32x4 (&qa)[NPL][4], const f32x4 (&qb)[NPL][4]) {
+    // Staging: direct global -> LDS copies (glds16), no VGPR round trip and no ds_write pass.  One instruction of a wave fills
+    // RPI rows = 1 KiB of the plane (lane-linear); the swizzle of the LDS image is applied to the per-lane SOURCE chunk: the
+    // lane whose slot is (row, position p) fetches chunk p ^ gb_swz(row) of that row.  Wave w, instruction i covers rows
+    // (w + 4 i) * RPI .. + RPI - 1 of every plane.
+    const int srow = lane / CPR, spos = lane % CPR;   // this lane's slot inside a block of RPI rows
+    auto issue = [&](int kb, int buf) {
+        const int k0h = kb * (BK / 2);   // float units
         float* base = stgcn_smem + buf * BUF;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, c8 = f & 7, o = row * kGbLD + ((c8 ^ ((row >> 1) & 7)) << 2);
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                st4(base + p * kGbPlane + o, qa[p][i]);
-                st4(base + (NPL + p) * kGbPlane + o, qb[p][i]);
+        for (int i = 0; i < NI; ++i) {
+            const int rb = (w + 4 * i) * RPI, row = rb + srow;
+            const int ch = (spos ^ gb_swz<BK>(row)) << 2;
+            const size_t oa = (size_t)(n0 + row) * NPH + k0h + ch, ob = (size_t)(c0 + row) * NPH + k0h + ch;
+            glds16(a.Mh + oa, base + rb * LD);
+            glds16(a.Xh + ob, base + NPL * PLANE + rb * LD);
+            if (SPLIT) {
+                glds16(a.Ml + oa, base + PLANE + rb * LD);
+                glds16(a.Xl + ob, base + (NPL + 1) * PLANE + rb * LD);
             }
         }
     };
@@ -447,51 +445,40 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4();
 
-    const int nkb = (N + kGbBK - 1) / kGbBK;   // k >= N: zero operator columns, zero operand padding
-    fetch(0, pa[0], pb[0]);
-    stage(0, pa[0], pb[0]);
+    const int nkb = (N + BK - 1) / BK;   // k >= N: zero operator columns, zero operand padding
+    issue(0, 0);
+    __syncthreads();   // (drains vmcnt: the copies of chunk 0 have landed)
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) issue(kb + 1, buf ^ 1);   // the other buffer was last read before the barrier that ended step kb - 1
+        const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * LD;
+        const float* Bs = stgcn_smem + buf * BUF + NPL * PLANE + (wn * 64 + l15) * LD;
+        const int sw = gb_swz<BK>(l15);   // tile rows start at multiples of 16: gb_swz(row) == gb_swz(l15)
 #pragma unroll
-    for (int c = 1; c < D; ++c)
-        if (c < nkb) fetch(c, pa[c], pb[c]);
-    __syncthreads();
-    for (int kb0 = 0; kb0 < nkb; kb0 += D) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 ah[4], al[4], bh[4], bl[4];
+            const int co = ((ks * 4 + g) ^ sw) << 2;   // swizzled position of chunk ks*4 + g (8 bf16) in the row
 #pragma unroll
-        for (int j = 0; j < D; ++j) {   // unrolled so that the ring sets are compile-time register names
-            const int kb = kb0 + j;
-            if (kb < nkb) {
-                const int buf = kb & 1;
-                if (kb + D < nkb) fetch(kb + D, pa[j], pb[j]);   // set j held chunk kb, staged one step ago
-                const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * kGbLD;
-                const float* Bs = stgcn_smem + buf * BUF + NPL * kGbPlane + (wn * 64 + l15) * kGbLD;
-                const int sw = (l15 >> 1) & 7;   // tile rows start at multiples of 16: (row >> 1) & 7 == (l15 >> 1) & 7
-#pragma unroll
-                for (int ks = 0; ks < kGbBK / 32; ++ks) {
-                    bf16x8 ah[4], al[4], bh[4], bl[4];
-                    const int co = ((ks * 4 + g) ^ sw) << 2;   // swizzled position of chunk ks*4 + g (8 bf16) in the row
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * kGbLD + co));
-                        bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * kGbLD + co));
-                        if (SPLIT) {
-                            al[t] = __builtin_bit_cast(bf16x8, ld4(As + kGbPlane + t * 16 * kGbLD + co));
-                            bl[t] = __builtin_bit_cast(bf16x8, ld4(Bs + kGbPlane + t * 16 * kGbLD + co));
-                        }
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) {
-                            if (SPLIT) {
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                            }
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        }
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * LD + co));
+                bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD + co));
+                if (SPLIT) {
+                    al[t] = __builtin_bit_cast(bf16x8, ld4(As + PLANE + t * 16 * LD + co));
+                    bl[t] = __builtin_bit_cast(bf16x8, ld4(Bs + PLANE + t * 16 * LD + co));
                 }
-                if (kb + 1 < nkb) stage(buf ^ 1, pa[(j + 1) % D], pb[(j + 1) % D]);   // chunk kb + 1, requested D - 1 steps ago
-                __syncthreads();
             }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (SPLIT) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                }
         }
+        __syncthreads();   // all waves done with `buf`; the copies into the other buffer have landed
     }
 
     // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*64 + nt*16 + l15]

@@ -163,6 +163,11 @@ static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, e
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
+// global_load_lds: lane i copies `size` bytes from its own global pointer to (wave-uniform LDS base) + size * i + offset
+static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned size, int off) {
+    memcpy(static_cast<char*>(lds_base) + (emu::g.threadIdx_.x % emu::kWave) * size + off, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)

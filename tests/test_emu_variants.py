@@ -62,3 +62,8 @@ def test_tiled_gemm_column_extents(ntw):
     # workgroup tiles of 128 / 160 GEMM columns of the tiled graph conv's fp32 operator GEMM (the emulator's residency
     # heuristic always picks the 96-column tile): 10 slabs = ragged column tiles for both, Chebyshev and Kipf
     run_subset({"STGCN_GEMM_NTW": str(ntw)}, ["tests/test_emu_gctile.py"], "stage_oracle and (21-2-7 or 35-1-5)")
+
+
+def test_bf16_gemm_64_deep_steps():
+    # the bf16 / bf16x3 operator GEMM with 64-deep pipeline steps (128-B LDS rows, 8-position swizzle); the default is 32
+    run_subset({"STGCN_GEMM_BF16_BK": "64"}, ["tests/test_emu_gctile.py"], "rounded or (bf16x3 and graph_conv)")
