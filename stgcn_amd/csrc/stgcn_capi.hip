@@ -128,6 +128,9 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (d->c1 != 16) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv channels c1 must be 16 (got %d)", d->c1);
     if (d->N > 32768) return fail(STGCN_ERR_UNSUPPORTED, "N=%d > 32768 nodes", d->N);
     if ((int64_t)d->B * d->T * d->N >= (1ll << 31) / 256) return fail(STGCN_ERR_UNSUPPORTED, "B*T*N too large for 32-bit row indexing");
+    if ((int64_t)d->B * (d->T - d->Kt + 1) > 65535)   // per-slab launches index the (b, t) slab with blockIdx.y
+        return fail(STGCN_ERR_UNSUPPORTED, "B*(T-Kt+1) = %lld (b, t) slabs exceed the 65535 rows of a launch grid: split the batch",
+                    (long long)d->B * (d->T - d->Kt + 1));
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
     if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
         return fail(STGCN_ERR_UNSUPPORTED, "c_in=%d: input channels must be a multiple of 4 unless Kt*c_in <= 16", d->c_in);
