@@ -24,9 +24,19 @@ def real_gso(key):
     return np.load(os.path.join(GOLDEN, "gso_real.npz"))[key]
 
 
+def synth_gso(n, seed):
+    """tests/golden/make_golden.py:synth_gso, restated: operators too large to store are regenerated from (n, seed)."""
+    rs = np.random.RandomState(seed)
+    a = rs.uniform(-1.0, 1.0, size=(n, n)) * (rs.uniform(size=(n, n)) < 0.5)
+    a = a / max(1.0, np.abs(np.linalg.eigvals(a)).max())
+    return a.astype(np.float32)
+
+
 def fixture_gso(name, fx):
     if "gso" in fx:
         return fx["gso"]
+    if name == "big600_ks4_f32":
+        return synth_gso(600, 7)
     return {"metrla_c2_f32": real_gso("metr_la.cheb_sym_norm_lap"),
             "pemsd7m_c1_f32": real_gso("pemsd7_m.sym_renorm_adj")}[name]
 

@@ -28,7 +28,8 @@ def _build(name):
     return fx, model, x, y
 
 
-@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32"])
+@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32",
+                                  pytest.param("big600_ks4_f32", marks=pytest.mark.full)])      # 600 nodes: tiled path, ~2 min emulated
 def test_model_matches_reference_golden(name):
     fx, model, x, y = _build(name)
     model.eval()
@@ -40,7 +41,8 @@ def test_model_matches_reference_golden(name):
         h.remove()
     assert out.shape == fx["eval.out"].shape
     for l, b in enumerate(blocks):
-        assert maxabs(b.numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"      # north-star bar: 1e-4 abs
+        if f"act.st_blocks.{l}" in fx:
+            assert maxabs(b.numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"      # north-star bar: 1e-4 abs
     assert maxabs(out.numpy(), fx["eval.out"]) <= 1e-4
 
     model.train()          # fixtures were generated with droprate 0 -> deterministic

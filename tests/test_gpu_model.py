@@ -32,7 +32,8 @@ def _model_from_fixture(name, droprate=None):
     return fx, cfg, model, x, y
 
 
-@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32", "metrla_c2_f32", "pemsd7m_c1_f32"])
+@pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32", "metrla_c2_f32", "pemsd7m_c1_f32",
+                                  "big600_ks4_f32"])      # 600 nodes: tiled graph conv + big-slab LayerNorm backward in the head
 def test_model_matches_reference_golden(name):
     fx, cfg, model, x, y = _model_from_fixture(name)
     model.eval()
@@ -43,8 +44,9 @@ def test_model_matches_reference_golden(name):
     for h in hooks:
         h.remove()
     for l, b in enumerate(blocks):
-        assert b.shape == fx[f"act.st_blocks.{l}"].shape
-        assert maxabs(b.cpu().numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"
+        if f"act.st_blocks.{l}" in fx:      # (block outputs are not stored for the 600-node fixture)
+            assert b.shape == fx[f"act.st_blocks.{l}"].shape
+            assert maxabs(b.cpu().numpy(), fx[f"act.st_blocks.{l}"]) <= 1e-4, f"block {l}"
     assert maxabs(out.cpu().numpy(), fx["eval.out"]) <= 1e-4
     model.train()
     model.zero_grad()

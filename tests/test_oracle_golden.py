@@ -8,7 +8,7 @@ from oracle import stgcn_oracle as orc
 from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture, maxabs
 
 CASES = ["tiny_cheb_f32", "tiny_cheb_f64", "tiny_gc_f32", "tiny_odd_f32", "tiny_ks1_f32", "tiny_ks5_f32",
-         "metrla_c2_f32", "pemsd7m_c1_f32"]
+         "metrla_c2_f32", "pemsd7m_c1_f32", "big600_ks4_f32"]
 
 
 def _setup(name):
@@ -38,7 +38,8 @@ def test_eval_forward_matches_reference(name):
     assert out.shape == fx["eval.out"].shape
     assert maxabs(out.numpy(), fx["eval.out"]) <= tol
     for l, b in enumerate(blocks):
-        assert maxabs(b.numpy(), fx[f"act.st_blocks.{l}"]) <= tol * 3
+        if f"act.st_blocks.{l}" in fx:      # (not stored for the 600-node fixture)
+            assert maxabs(b.numpy(), fx[f"act.st_blocks.{l}"]) <= tol * 3
 
 
 def test_sublayer_activations_match_reference():
