@@ -59,9 +59,13 @@ def block_flops(B, c_in, T, N, need_dx):
     F_L = (KS - 1) * 2 * N * N * B * T1 * c1
     F_W = 2 * B * T1 * N * KS * c1 * c1
     F_tc2 = 2 * B * T2 * N * KT * c1 * 2 * c2
-    return {"tconv_fwd.tc1": F_tc1 + F_al, "gconv_fwd": F_L + F_W, "tconv_fwd.tc2": F_tc2,
+    # one entry per kernel label a launch of this path can carry (fused kernels and the stage-per-launch kernels they replace);
+    # "_total" is the closed form of the whole block, independent of how the launches are cut
+    return {"tconv_fwd.tc1": F_tc1 + F_al, "gconv_fwd": F_L + F_W, "tconv_fwd.tc2": F_tc2, "tc2_ln_fwd": F_tc2,
             "tconv_bwd_data.tc2": F_tc2, "gconv_bwd": F_L + 2 * F_W, "align_gate_bwd": 2 * F_al,
-            "tconv_bwd_data.tc1": F_tc1 if need_dx else 0, "tconv_bwd_weight.tc1": F_tc1, "tconv_bwd_weight.tc2": F_tc2}
+            "tconv_bwd_data.tc1": F_tc1 if need_dx else 0, "tconv_bwd_weight.tc1": F_tc1, "tconv_bwd_weight.tc2": F_tc2,
+            "tc2_bwd": 2 * F_tc2, "tc1_bwd": (2 * F_tc1 if need_dx else F_tc1) + 2 * F_al,
+            "_total": (F_tc1 + F_al + F_L + F_W + F_tc2) + (F_tc1 if need_dx else 0) + F_tc1 + 2 * (F_al + F_W + F_tc2) + F_L}
 
 
 def stblock_flops_by_label(B, N):
@@ -262,6 +266,7 @@ def main():
         prof = json.loads(buf.value.decode())
         flops = stblock_flops_by_label(B_LOCAL, N)
         per_step = {k: v["total_ms"] / ksteps for k, v in prof.items()}
+        stblock_total = sum(v for k, v in flops.items() if k.startswith("_total"))
         mfma_kernels = {k: per_step[k] for k in flops if k in per_step and flops[k] > 0}
         dom = max(mfma_kernels, key=mfma_kernels.get)          # the single launch (kernel @ block) that costs most
         calls_per_step = prof[dom]["calls"] / ksteps
@@ -274,7 +279,10 @@ def main():
                            "traffic_source": traffic_src,
                            "avg_launch_us": round(dur_ms * 1e3, 2), "flops_per_launch": int(flops[dom] / calls_per_step),
                            "stblock_kernels_ms_per_step": round(tot_ms, 4), "all_kernels_ms_per_step": round(sum(per_step.values()), 4),
-                           "stblock_fwd_bwd_frac": round(sum(flops.values()) / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "stblock_fwd_bwd_frac": round(stblock_total / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "stblock_flops_per_step": int(stblock_total),
+                           "stblock_launches_per_step": int(round(sum(v["calls"] for k, v in prof.items()
+                                                                        if not k.startswith(("head.", "adamw", "prepack", "mse", "reduce"))) / ksteps)),
                            "per_kernel_us_per_step": {k: round(v * 1e3, 2) for k, v in sorted(per_step.items())}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(gso_np)

@@ -125,6 +125,10 @@ typedef struct stgcn_stblock_plan {
     int64_t ws_Gk;                    /* tiled_gc: [terms][rows1][c1] Clenshaw buffers of the graph-conv backward         */
     int64_t ws_XT;                    /* tiled_gc: two bf16 operand-form buffers (hi, lo planes of [CP][NP]) for the bf16 /
                                          bf16x3 operator products (stgcn_set_gc_precision)                                */
+    /* fused time-stepping kernels (stgcn_kernels_tstep.hip.h) */
+    int64_t fused_tc2_bwd;            /* 1: LayerNorm/dropout/gate backward + tmp_conv2 weight gradient + transposed conv run as ONE
+                                         launch per block; dZ2 stays on chip (ws_dZ2 is only written under stgcn_set_debug_stages)   */
+    int64_t ws_W2dense;               /* [KP2][2*c2] W_eff of tmp_conv2, row major (stationary A operand of that kernel)             */
 } stgcn_stblock_plan;
 
 int stgcn_version(void);
@@ -149,6 +153,10 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
  * Chebyshev recursion of layers.py:153-161 then runs on the activations, one GEMM launch per term
  * (stgcn_kernels_gctile.hip.h).                                                                                         */
 int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled);
+
+/* Test knob: 1 = the fused kernels also write the intermediates they normally keep on chip (dZ2 -> ws_dZ2) so that stage tests
+ * can compare them with the oracle.  Returns the previous value; other values only query.                                  */
+int stgcn_set_debug_stages(int32_t on);
 
 /* Tuning / test knob: graphs with at least n nodes use the tiled graph conv (default 513).  Returns the previous value;
  * n < 1 only queries.  Operators prepared under one setting must be used under the same setting.                        */

@@ -46,7 +46,7 @@ PLAN_FIELDS = ["T1", "T2", "rows1", "rows2", "NP", "y_floats", "saved_floats", "
                "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd", "sv_rowstat",
                "ws_W1p", "ws_W1d", "ws_b1", "ws_Wap", "ws_WaT", "ws_ba", "ws_W2p", "ws_W2d", "ws_b2", "ws_W1dense", "recompute_tc1", "ws_WaDense", "thin_tc1",
                "ws_rowstat_b", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats",
-               "tiled_gc", "ws_Gk", "ws_XT"]
+               "tiled_gc", "ws_Gk", "ws_XT", "fused_tc2_bwd", "ws_W2dense"]
 
 
 class StblockPlan(C.Structure):
@@ -124,6 +124,8 @@ class _Lib:
         d.stgcn_gso_layout.restype = C.c_int
         d.stgcn_set_gc_tiled_min_nodes.argtypes = [C.c_int32]
         d.stgcn_set_gc_tiled_min_nodes.restype = C.c_int
+        d.stgcn_set_debug_stages.argtypes = [C.c_int32]
+        d.stgcn_set_debug_stages.restype = C.c_int
         d.stgcn_set_gc_precision.argtypes = [C.c_int32]
         d.stgcn_set_gc_precision.restype = C.c_int
         d.stgcn_set_gc_ld_pad.argtypes = [C.c_int32]
@@ -195,4 +197,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
                     "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack",
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
-                    "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad"]
+                    "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages"]

@@ -232,6 +232,8 @@ bool pack_fill_block(PackList& L, const stgcn_stblock_desc* d, const stgcn_stblo
     ok &= L.add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
     if (pl.recompute_tc1)
         ok &= L.add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
+    if (pl.fused_tc2_bwd)
+        ok &= L.add(PK_TCONV_DENSE, v.KP2 * v.NC2, ws + pl.ws_W2dense, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
     return ok;
 }
 int launch_pack_list(const char* label, PackList& L, hipStream_t st) {
@@ -633,17 +635,20 @@ int launch_reduce_list(const char* label, ReduceList& L, hipStream_t st) {
 }
 void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived& v, const BwdGeom& bg, const float* part,
                        const stgcn_stblock_grads* G) {
+    // dW_eff partials wp[P][..][NC] (ps floats apart), db_eff partials bp[P][NC] (pb floats apart)
+    auto add_tconv_at = [&](const float* wp, const float* bp, int Pn, long ps, long pb, int NC, int Cin, int Cout, float* gw, float* gb, float* gaw,
+                            float* gab) {
+        // enumerate (k, i, o): src dW_eff[k*Cin + i][o] -> dst conv_w[o][i][k]
+        L.add(gw, wp, Pn, ps, d->Kt, Cin, NC, (long)Cin * NC, NC, 1, 1, d->Kt, (long)Cin * d->Kt);
+        L.add_flat(gb, bp, Pn, pb, NC);
+        if (Cin > Cout) {   // the residual branch is a live 1x1 conv: it shares tap Kt-1 of the P half
+            L.add(gaw, wp + (long)(d->Kt - 1) * Cin * NC, Pn, ps, 1, Cin, Cout, 0, NC, 1, 0, 1, Cin);   // aw[o][i] <- row i, col o
+            L.add_flat(gab, bp, Pn, pb, Cout);
+        }
+    };
     auto add_tconv = [&](const WgradGeom& w, int Cin, int Cout, float* gw, float* gb, float* gaw, float* gab) {
         const float* wp = part + w.off;
-        const float* bp = wp + (long)w.chunks * w.Mpad * w.NC;
-        const long ps = (long)w.Mpad * w.NC;
-        // enumerate (k, i, o): src dW_eff[k*Cin + i][o] -> dst conv_w[o][i][k]
-        L.add(gw, wp, w.chunks, ps, d->Kt, Cin, w.NC, (long)Cin * w.NC, w.NC, 1, 1, d->Kt, (long)Cin * d->Kt);
-        L.add_flat(gb, bp, w.chunks, w.NC, w.NC);
-        if (Cin > Cout) {   // the residual branch is a live 1x1 conv: it shares tap Kt-1 of the P half
-            L.add(gaw, wp + (long)(d->Kt - 1) * Cin * w.NC, w.chunks, ps, 1, Cin, Cout, 0, w.NC, 1, 0, 1, Cin);   // aw[o][i] <- row i, col o
-            L.add_flat(gab, bp, w.chunks, w.NC, Cout);
-        }
+        add_tconv_at(wp, wp + (long)w.chunks * w.Mpad * w.NC, w.chunks, (long)w.Mpad * w.NC, w.NC, w.NC, Cin, Cout, gw, gb, gaw, gab);
     };
     if (bg.thin) {   // dW_eff (16 padded rows) and db_eff sit behind dWa | dba in the per-workgroup partials
         const float* wp = part + bg.off_al + (long)d->c0 * 16 + 16;
@@ -652,7 +657,13 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
     } else {
         add_tconv(bg.w1, d->c_in, d->c0, G->tc1_w, G->tc1_b, G->tc1_aw, G->tc1_ab);
     }
-    add_tconv(bg.w2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw, G->tc2_ab);
+    if (bg.k1) {   // per-(window, node tile) partials of tc2_bwd_kernel: [Kt*16][NC2] then [NC2]
+        const float* wp = part + bg.off_k1;
+        add_tconv_at(wp, wp + (long)d->Kt * 16 * v.NC2, bg.k1_wgs, bg.k1_stride, bg.k1_stride, v.NC2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw,
+                     G->tc2_ab);
+    } else {
+        add_tconv(bg.w2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw, G->tc2_ab);
+    }
     if (d->c0 > d->c1) {
         // enumerate (i, j): src dWa[i][j] -> dst al_w[j][i]
         L.add(G->al_w, part + bg.off_al, bg.al_wgs, bg.al_stride, 1, d->c0, d->c1, 0, d->c1, 1, 0, 1, d->c0);
@@ -741,7 +752,10 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
     p->ws_W1dense = take(p->recompute_tc1 ? (int64_t)v.KP1 * v.NC1 : 0);
-    p->thin_tc1 = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms).thin;
+    const BwdGeom bgq = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
+    p->thin_tc1 = bgq.thin;
+    p->fused_tc2_bwd = bgq.k1;
+    p->ws_W2dense = take(bgq.k1 ? (int64_t)v.KP2 * v.NC2 : 0);
     p->ws_WaDense = take(p->thin_tc1 ? (int64_t)d->c0 * d->c1 : 0);
     p->ws_rowstat_b = take(2 * v.rows2 + 2 * v.slabs2);   // row partials, then the per-slab constants (big slabs only)
     p->ws_dZ2 = take(v.rows2 * v.NC2);
@@ -755,6 +769,12 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;
     return STGCN_OK;
+}
+
+int stgcn_set_debug_stages(int32_t on) {
+    const int prev = g_debug_stages;
+    if (on == 0 || on == 1) g_debug_stages = on;
+    return prev;
 }
 
 int stgcn_set_gc_tiled_min_nodes(int32_t n) {

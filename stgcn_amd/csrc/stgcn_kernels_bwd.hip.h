@@ -7,11 +7,28 @@
 //   (G, dZ2), (x, dZ1) --[tconv_bwd_weight]--> partial dW_eff/db_eff
 //   partials --[reduce_kernel]--> parameter gradients in the reference's layouts
 #pragma once
+#include <stdlib.h>
 #include "stgcn_device.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
 #include "stgcn_kernels_gctile.hip.h"
+#include "stgcn_kernels_tstep.hip.h"
 
 namespace stgcn {
+
+// ---- which fused kernels replace the stage-per-launch path (host side; plan, launchers and the gradient flush must agree) ----
+// STGCN_FUSE=<bit mask> (read once): 1 = tc2_bwd_kernel (LayerNorm/dropout/gate backward + tmp_conv2 weight gradient + transposed conv in
+// one launch).  Default: everything on; 0 reproduces the round-1 launch sequence (A/B runs, stage tests).
+enum FuseBit { FUSE_TC2_BWD = 1 };
+inline int fuse_mask() {
+    static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
+    return m;
+}
+// stage tests: also write the on-chip intermediates of the fused kernels (dZ2) to their round-1 workspace slots
+inline int g_debug_stages = 0;
+inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
+    return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && (c2 == 64 || c2 == 128) && Kt >= 2 && Kt <= 4 && T1 <= kTsMaxT &&
+           tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 64 * 1024;
+}
 
 // ---- which graph-conv implementation a block uses (host side; plan, launchers and stgcn_gso_prepare must agree) -------
 // Slab-resident kernels (gconv_fwd_kernel / gconv_bwd_kernel): up to 512 nodes and as many terms as the backward's LDS
@@ -56,6 +73,10 @@ struct BwdGeom {
     int gc_tiles_per_wg;     // tiled row pass: 16-row tiles per workgroup
     int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1 (+ 16*2*c0 + 2*c0 on the thin path)
     int thin;                // first layer handled by thin_tc1_bwd_kernel (Kt*c_in <= 16, c0 == 64)
+    int k1;                  // tmp_conv2 / LayerNorm backward fused into tc2_bwd_kernel (no dZ2, no w2 partials; ln_sg = B)
+    int node_tiles;          // ceil(N / 16)
+    int k1_wgs, k1_stride;   // workgroups (B * node_tiles) and floats per workgroup (Kt*16*NC2 + NC2) of its dW_eff2 | db_eff2 partials
+    long off_k1;
 };
 
 inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
@@ -91,6 +112,14 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     if (sg < 1) sg = 1;
     g.ln_spg = (int)((slabs2 + sg - 1) / sg);
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
+    g.k1 = tc2_bwd_fused_ok(c1, c2, Kt, T1, T2) ? 1 : 0;
+    g.node_tiles = (N + 15) / 16;
+    g.k1_wgs = B * g.node_tiles;
+    g.k1_stride = Kt * 16 * 2 * c2 + 2 * c2;
+    if (g.k1) {   // one LayerNorm-parameter partial per window
+        g.ln_spg = T2;
+        g.ln_sg = B;
+    }
     const long tiles1 = (rows1 + kTileRows - 1) / kTileRows;
     g.thin = (Kt * c_in <= 4 && c0 == 64 && c1 == 16) ? 1 : 0;   // thin_tc1_bwd_kernel keeps K <= 4 rows of W_eff in registers
     // grid-stride workgroups of align_gate_bwd (23.5 KB of LDS each: several per CU for latency hiding).  The thin
@@ -118,7 +147,8 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.w1 = wgrad_geom(rows1, Kt * c_in, 2 * c0, 0);
     g.w1.off = take(g.w1.floats);
     g.w2 = wgrad_geom(rows2, Kt * c1, 2 * c2, 0);
-    g.w2.off = take(g.w2.floats);
+    g.w2.off = take(g.k1 ? 0 : g.w2.floats);
+    g.off_k1 = take(g.k1 ? (long)g.k1_wgs * g.k1_stride : 0);
     g.total = o;
     return g;
 }

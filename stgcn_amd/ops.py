@@ -172,6 +172,12 @@ def set_gc_ld_pad(pad: int) -> int:
     return prev
 
 
+def set_debug_stages(on: bool) -> bool:
+    """Stage tests only: make the fused kernels also write the intermediates they keep on chip (dZ2 -> plan.ws_dZ2);
+    returns the previous setting (``stgcn_set_debug_stages``)."""
+    return bool(_lib.lib().dll.stgcn_set_debug_stages(1 if on else 0))
+
+
 GC_PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 

@@ -17,6 +17,7 @@ def bind_hip():
 def run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, dev="cuda:0", seed=99, offset=3, pdrop=0.5):
     """Returns dict of max errors (absolute for activations, relative-to-max for gradients)."""
     bind_hip()
+    ops.set_debug_stages(True)      # fused kernels also write the intermediates they keep on chip (dZ2)
     cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
     if gso is None:
         gso = nonsym_gso(N, 5)

@@ -23,6 +23,7 @@ CASES = [
 @pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T,training", CASES)
 def test_block_backward(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
     bind_emulator()
+    ops.set_debug_stages(True)      # fused kernels also write the intermediates they keep on chip (dZ2)
     cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
     gso = nonsym_gso(N, 5)
     rs = np.random.RandomState(11)
