@@ -892,6 +892,28 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     rc = launch_gconv_fwd(gc, st);
     if (rc) return rc;
 
+    if (tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N)) {
+        // ---- tmp_conv2 + GLU + LayerNorm([N, c2]) + dropout: one workgroup per (b, t2) slab ------------------------------------
+        Tc2LnFwdArgs f;
+        memset(&f, 0, sizeof(f));
+        f.G = saved + pl.sv_G; f.Wp = ws + pl.ws_W2p; f.bias = ws + pl.ws_b2; f.gamma = P->ln_w; f.beta = P->ln_b;
+        f.U = saved + pl.sv_U2; f.S = saved + pl.sv_S2; f.y = y; f.mean = saved + pl.sv_mean; f.rstd = saved + pl.sv_rstd;
+        f.T1 = v.T1; f.T2 = v.T2; f.N = d->N; f.NPR = (int)rup(d->N, 16); f.act = d->act; f.training = d->training && d->droprate > 0.f;
+        f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
+        f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;
+        const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N);
+        const dim3 grid((unsigned)v.slabs2), blk(512);
+        const bool small = d->N <= 224;   // 7 row tiles per wave
+#define STGCN_TC2LN(KT_)                                                                                  \
+        do {                                                                                              \
+            if (small) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7>), grid, blk, lds, f);  \
+            else STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14>), grid, blk, lds, f);       \
+        } while (0)
+        if (d->Kt == 2) STGCN_TC2LN(2); else if (d->Kt == 3) STGCN_TC2LN(3); else STGCN_TC2LN(4);
+#undef STGCN_TC2LN
+        return STGCN_OK;
+    }
+
     // ---- tmp_conv2 + GLU ---------------------------------------------------------------------------
     TconvFwdArgs t2;
     memset(&t2, 0, sizeof(t2));

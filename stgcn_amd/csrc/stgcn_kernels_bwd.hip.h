@@ -18,13 +18,17 @@ namespace stgcn {
 // ---- which fused kernels replace the stage-per-launch path (host side; plan, launchers and the gradient flush must agree) ----
 // STGCN_FUSE=<bit mask> (read once): 1 = tc2_bwd_kernel (LayerNorm/dropout/gate backward + tmp_conv2 weight gradient + transposed conv in
 // one launch).  Default: everything on; 0 reproduces the round-1 launch sequence (A/B runs, stage tests).
-enum FuseBit { FUSE_TC2_BWD = 1 };
+//                                  2 = tc2_ln_fwd_kernel (tmp_conv2 + gate + LayerNorm + dropout of one slab per workgroup).
+enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2 };
 inline int fuse_mask() {
     static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
     return m;
 }
 // stage tests: also write the on-chip intermediates of the fused kernels (dZ2) to their round-1 workspace slots
 inline int g_debug_stages = 0;
+inline bool tc2_ln_fwd_fused_ok(int c1, int c2, int Kt, int N) {
+    return (fuse_mask() & FUSE_TC2_LN_FWD) && c1 == 16 && c2 == 64 && Kt >= 2 && Kt <= 4 && N <= 448 && tc2_ln_fwd_lds_bytes(Kt, N) <= 150 * 1024;
+}
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
     return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && (c2 == 64 || c2 == 128) && Kt >= 2 && Kt <= 4 && T1 <= kTsMaxT &&
            tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 64 * 1024;

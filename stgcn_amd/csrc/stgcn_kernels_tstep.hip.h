@@ -50,59 +50,36 @@ struct Tc2BwdArgs {
 
 constexpr int kTsMaxT = 32;   // time steps of G kept in LDS (host falls back to the unfused kernels beyond)
 inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
-    return ((size_t)Kt * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 4 * 16 * 20 + 4 * (size_t)T2) * sizeof(float);
+    return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2) * sizeof(float);
 }
 
 template <int C2, int KT>
 __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
-    constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20;
+    constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20, RING = KT + 1, RED = 4 * 16 * LDG;
     extern __shared__ float stgcn_smem[];
-    float* const Zt = stgcn_smem;                      // [KT][16][LDZ]  ring of dZ2 tiles
-    float* const GT = Zt + KT * 16 * LDZ;              // [T1][16 ch][LDG]  G tiles, transposed (GT[t][i][row])
-    float* const red = GT + a.T1 * 16 * LDG;           // [4 waves][16 rows][LDG]
-    float* const cs = red + 4 * 16 * LDG;              // [T2][4]: c1, c2, mean, rstd
+    float* const Zt = stgcn_smem;                      // [KT + 1][16][LDZ]  ring of dZ2 tiles (one spare slot: the next tile is written
+                                                       //                    while slower waves still read the KT previous ones)
+    float* const GT = Zt + RING * 16 * LDZ;            // [T1][16 ch][LDG]  G tiles, transposed (GT[t][i][row])
+    float* const red = GT + a.T1 * 16 * LDG;           // [2][4 waves][16 rows][LDG]  transposed-conv partials of the 4 waves, double buffered
+    float* const cs = red + 2 * RED;                   // [T2][4]: c1, c2, mean, rstd
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int b = (int)blockIdx.x / a.node_tiles, nt = (int)blockIdx.x - b * a.node_tiles, n0 = nt * 16;
     const int N = a.N, T1 = a.T1, T2 = a.T2;
     const int r = tid >> 4, cq = tid & 15;             // elementwise phase: row r, float4 columns cq + 16*it
     const bool rv = n0 + r < N;
 
-    // ---- slab constants of this window's T2 slabs (wave w: slabs w, w + 4, ..) -------------------------------------
-    for (int t = w; t < T2; t += 4) {
-        const long slab = (long)b * T2 + t;
-        float x = 0.f, y = 0.f;
-        if (a.slabconst) {
-            const float2 c = a.slabconst[slab];
-            x = c.x; y = c.y;
-        } else {
-            const float2* rs = a.rowstat + slab * N;
-            for (int i = lane; i < N; i += 64) {
-                const float2 v = rs[i];
-                x += v.x;
-                y += v.y;
-            }
+    // one-step software prefetch of the streamed tiles (the first one is requested before anything else)
+    f32x4 dyn[IT], un[IT], sn[IT];
+    auto fetch = [&](int t2) {
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                x += __shfl_xor(x, m);
-                y += __shfl_xor(y, m);
-            }
-            const float inv = 1.0f / ((float)N * (float)C2);
-            x *= inv; y *= inv;
+        for (int it = 0; it < IT; ++it) {
+            const size_t e = (((size_t)b * T2 + t2) * N + n0 + r) * C2 + 4 * (cq + 16 * it);
+            dyn[it] = rv ? ld4(a.dy + e) : zero4();
+            un[it] = rv ? ld4(a.U + e) : zero4();
+            sn[it] = rv ? ld4(a.S + e) : zero4();
         }
-        if (lane == 0) {
-            cs[4 * t] = x;
-            cs[4 * t + 1] = y;
-            cs[4 * t + 2] = a.mean[slab];
-            cs[4 * t + 3] = a.rstd[slab];
-        }
-    }
-    // ---- all G tiles of this (window, node tile), transposed ------------------------------------------------------------
-    for (int idx = tid; idx < T1 * 64; idx += 256) {
-        const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
-        const f32x4 v = n0 + rr < N ? ld4(a.G + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
-    }
+    };
+    if (T2 > 0) fetch(0);
     // ---- stationary weights of the transposed conv: wave w contracts o in [w*NC/4, (w+1)*NC/4) of every tap ----------------
     f32x4 Wr[KT][QW];
 #pragma unroll
@@ -115,6 +92,49 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
         gam[it] = rv ? ld4(a.gamma + (size_t)(n0 + r) * C2 + 4 * (cq + 16 * it)) : zero4();
         dgam[it] = zero4(); dbet[it] = zero4(); dbu[it] = zero4(); dbq[it] = zero4();
     }
+    // ---- slab constants of this window's T2 slabs: 32 lanes per slab, 8 slabs at a time ------------------------------------
+    {
+        const int grp = tid >> 5, l32 = tid & 31;
+        for (int t0 = 0; t0 < T2; t0 += 8) {   // uniform trip count
+            const int t = t0 + grp;
+            const long slab = (long)b * T2 + (t < T2 ? t : 0);
+            float x = 0.f, y = 0.f;
+            if (t < T2) {
+                if (a.slabconst) {
+                    if (l32 == 0) {
+                        const float2 c = a.slabconst[slab];
+                        x = c.x; y = c.y;
+                    }
+                } else {
+                    const float2* rs = a.rowstat + slab * N;
+                    for (int i = l32; i < N; i += 32) {
+                        const float2 v = rs[i];
+                        x += v.x;
+                        y += v.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                x += __shfl_xor(x, m);
+                y += __shfl_xor(y, m);
+            }
+            if (t < T2 && l32 == 0) {
+                const float inv = a.slabconst ? 1.0f : 1.0f / ((float)N * (float)C2);
+                cs[4 * t] = x * inv;
+                cs[4 * t + 1] = y * inv;
+                cs[4 * t + 2] = a.mean[slab];
+                cs[4 * t + 3] = a.rstd[slab];
+            }
+        }
+    }
+    // ---- all G tiles of this (window, node tile), transposed ------------------------------------------------------------
+    for (int idx = tid; idx < T1 * 64; idx += 256) {
+        const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
+        const f32x4 v = n0 + rr < N ? ld4(a.G + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
+    }
     f32x4 accw[KT][NTW];
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -122,24 +142,18 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
         for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     const int n4 = (N * C2) >> 2;
-
-    // one-step software prefetch of the streamed tiles
-    f32x4 dyn[IT], un[IT], sn[IT];
-    auto fetch = [&](int t2) {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const size_t e = (((size_t)b * T2 + t2) * N + n0 + r) * C2 + 4 * (cq + 16 * it);
-            dyn[it] = rv ? ld4(a.dy + e) : zero4();
-            un[it] = rv ? ld4(a.U + e) : zero4();
-            sn[it] = rv ? ld4(a.S + e) : zero4();
-        }
+    // dYg[t] = relu'(G[t]) * (sum of the 4 waves' partial tiles), thread (row r, channel cq)
+    auto finish = [&](int t) {
+        const float* rd = red + (t & 1) * RED;
+        float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
+        if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
+        if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
     };
-    if (T2 > 0) fetch(0);
     __syncthreads();
 
     for (int t1 = 0; t1 < T1; ++t1) {
         const bool step = t1 < T2;                      // uniform: a new dZ2 tile this step
-        float* const Zs = Zt + (t1 % KT) * 16 * LDZ;
+        float* const Zs = Zt + (t1 % RING) * 16 * LDZ;
         if (step) {
             const float c1 = cs[4 * t1], c2 = cs[4 * t1 + 1], mean = cs[4 * t1 + 2], rstd = cs[4 * t1 + 3];
 #pragma unroll
@@ -179,8 +193,9 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 st4(Zs + r * LDZ + C2 + 4 * c4, dq);
             }
         }
-        __syncthreads();   // dZ2 tile of this step visible; `red` of the previous step consumed
+        __syncthreads();   // ONE barrier per step: this step's dZ2 tile and the previous step's partial tiles are visible
         if (t1 + 1 < T2) fetch(t1 + 1);
+        if (t1 > 0) finish(t1 - 1);
         if (step) {
             // weight gradient: A[m = i][k = row] = G[t1 + tap][row][i] (transposed tiles: one 16-byte read), B[k = row][n = o] = dZ2
             f32x4 bz[NTW];
@@ -198,30 +213,25 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
                     for (int j = 0; j < NTW; ++j) accw[k][j] = mfma4(af[s], bz[j][s], accw[k][j]);
             }
         }
-        // transposed conv for output step t1: taps with 0 <= t1 - tap < T2
-        f32x4 accd = zero4();
+        // transposed conv for output step t1: taps with 0 <= t1 - tap < T2 (two accumulators: independent MFMA chains)
+        f32x4 accd[2] = {zero4(), zero4()};
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const int ts = t1 - k;
             if (ts >= 0 && ts < T2) {   // uniform
-                const float* zr = Zt + (ts % KT) * 16 * LDZ + l15 * LDZ + w * (NC / 4) + 4 * g;
+                const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + w * (NC / 4) + 4 * g;
 #pragma unroll
                 for (int q = 0; q < QW; ++q) {
                     const f32x4 z = ld4(zr + q * 16);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) accd = mfma4(Wr[k][q][s], z[s], accd);
+                    for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
                 }
             }
         }
-        st4(red + (w * 16 + l15) * LDG + 4 * g, accd);   // D[m = i = 4g + r][n = row = l15]
-        __syncthreads();
-        {
-            const int i = cq;   // thread (row r, channel i)
-            float v = (red[(0 * 16 + r) * LDG + i] + red[(1 * 16 + r) * LDG + i]) + (red[(2 * 16 + r) * LDG + i] + red[(3 * 16 + r) * LDG + i]);
-            if (!(GT[(t1 * 16 + i) * LDG + r] > 0.f)) v = 0.f;
-            if (rv) a.dYg[(((size_t)b * T1 + t1) * N + n0 + r) * 16 + i] = v;
-        }
+        st4(red + (t1 & 1) * RED + (w * 16 + l15) * LDG + 4 * g, accd[0] + accd[1]);   // D[m = i = 4g + r][n = row = l15]
     }
+    __syncthreads();
+    finish(T1 - 1);
 
     // ---- per-workgroup partials ---------------------------------------------------------------------------------------------
     float* part = a.part + (size_t)blockIdx.x * (KT * 16 * NC + NC);
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
     }
     // db_eff2[o] = sum over the 16 rows (threads with equal cq: lanes 16 apart, then the 4 waves through LDS)
     __syncthreads();   // `red` reads of the last step done
-    float* bred = red;   // [4 waves][NC] (NC <= 256: fits the 1280 floats of `red`)
+    float* bred = red;   // [4 waves][NC] (NC <= 256: fits the 2 x 1280 floats of `red`)
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
 #pragma unroll
@@ -257,6 +267,152 @@ __global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
     }
     __syncthreads();
     if (tid < NC) part[(size_t)KT * 16 * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
+}
+
+// ================================================================================================
+// F3+F4 fused: tmp_conv2 + GLU/GTU + LayerNorm([N, c2]) + Dropout of ONE (b, t2) slab per workgroup (layers.py:254-256).
+// LayerNorm normalises over all N * c2 values of a slab, so the slab is the natural owner: the conv output never goes to
+// memory before it is normalised (the stage-per-launch path wrote U2, S2 and row partials, then re-read U2, S2 in ln_norm_kernel).
+//   Z^T[o][row] = W_eff2^T[o][K] im2col(G)^T[K][row]     A = the packed weights (PK_TCONV_FWD fragments are A fragments of the
+//                                                        transposed product), stationary in registers; B = G rows from LDS
+//   D leaves a lane with 4 consecutive channels of one row, and with wave w owning o-tiles w and w + c2/16 the P and Q halves of a
+//   channel meet in the same lane: bias, sigmoid, gate, the two-pass slab statistics (values stay in registers), the affine map,
+//   the Philox mask and the 16-byte U2 / S2 / y stores all run on registers -- no LDS round trip of the accumulators.
+// grid = B * T2 workgroups of 512 threads (8 waves: wave = (pair p = wave & 3, half = wave >> 2); the halves take alternate
+// 16-row tiles).  Template: C2 = 64 (p owns channels 16p..16p+15), KT taps, NTI row tiles per wave (N <= 32 * NTI).
+// ================================================================================================
+struct Tc2LnFwdArgs {
+    const float* G;        // [B][T1][N][16]
+    const float* Wp;       // packed W_eff2 (PK_TCONV_FWD): K = Kt*16 (KCH = Kt chunks), NC = 2*C2 columns
+    const float* bias;     // b_eff2 [2*C2]
+    const float* gamma;    // [N][C2]
+    const float* beta;
+    float* U;              // [B*T2*N][C2]
+    float* S;
+    float* y;              // [B*T2*N][C2]
+    float* mean;           // [B*T2]
+    float* rstd;
+    int T1, T2, N, NPR, act, training;   // NPR = roundup16(N)
+    float eps, keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+    const uint64_t* offset_dev;
+};
+constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
+inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 32) * sizeof(float); }
+
+template <int C2, int KT, int NTI>
+__global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
+    static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
+    constexpr int NC = 2 * C2, MT = C2 / 16;
+    extern __shared__ float stgcn_smem[];
+    float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]
+    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [32]
+    const int tid = threadIdx.x, wv = tid >> 6, p = wv & (MT - 1), hf = wv >> 2, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const long slab = blockIdx.x;
+    const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N, NPR = a.NPR, ntiles = NPR >> 4;
+
+    // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)
+    f32x4 wP[KT], wQ[KT];
+#pragma unroll
+    for (int kc = 0; kc < KT; ++kc) {
+        wP[kc] = ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4);
+        wQ[kc] = ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4);
+    }
+    // stage the KT input slabs G[b][t2 + tap] (zero rows beyond N)
+    const float* Gb = a.G + ((size_t)b * a.T1 + t2) * N * 16;
+    for (int idx = tid; idx < KT * NPR * 4; idx += 512) {
+        const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
+        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ld4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
+    }
+    const int c = 16 * p + 4 * g;   // this lane's 4 channels
+    const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C2 + c);
+    __syncthreads();
+
+    f32x4 accP[NTI], accQ[NTI];
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+        accP[j] = zero4();
+        accQ[j] = zero4();
+    }
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+        const int nt = hf + 2 * j;
+        if (nt < ntiles) {   // uniform per wave
+#pragma unroll
+            for (int kc = 0; kc < KT; ++kc) {
+                const f32x4 bf = ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g);   // B[k = 4g + s][n = row]
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    accP[j] = mfma4(wP[kc][s], bf[s], accP[j]);
+                    accQ[j] = mfma4(wQ[kc][s], bf[s], accQ[j]);
+                }
+            }
+        }
+    }
+    // gate: U = P + b, S = sigmoid(Q + b), h = act(U) * S (kept in accP); pass 1 of the slab statistics
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+        const int row = (hf + 2 * j) * 16 + l15;
+        if (row < N) {
+            f32x4 u, sg, h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = accP[j][i] + bp[i];
+                sg[i] = sigmoid_f(accQ[j][i] + bq[i]);
+                h[i] = gate_fwd(u[i], sg[i], a.act);
+            }
+            const size_t o = ((size_t)slab * N + row) * C2 + c;
+            st4(a.U + o, u);
+            st4(a.S + o, sg);
+            accP[j] = h;
+            sum += (h[0] + h[1]) + (h[2] + h[3]);
+        }
+    }
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        __syncthreads();   // protect red from its previous use
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    };
+    const float cnt = (float)N * (float)C2;
+    const float mean = block_sum(sum) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+        const int row = (hf + 2 * j) * 16 + l15;
+        if (row < N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m2 += (accP[j][i] - mean) * (accP[j][i] - mean);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(m2) / cnt + a.eps);
+    if (tid == 0) {
+        a.mean[slab] = mean;
+        a.rstd[slab] = rstd;
+    }
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+    const uint64_t n4 = ((uint64_t)N * C2) >> 2;
+#pragma unroll
+    for (int j = 0; j < NTI; ++j) {
+        const int row = (hf + 2 * j) * 16 + l15;
+        if (row < N) {
+            const size_t e = (size_t)row * C2 + c;
+            const f32x4 ga = ld4(a.gamma + e), be = ld4(a.beta + e);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (accP[j][i] - mean) * rstd * ga[i] + be[i];
+            if (a.training) {
+                const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (e >> 2), a.seed, off, a.thresh, a.keep_scale);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] *= k[i];
+            }
+            st4(a.y + (size_t)slab * N * C2 + e, o);
+        }
+    }
 }
 
 }  // namespace stgcn

@@ -88,5 +88,6 @@ def test_two_rank_graphed_step_equals_one_big_batch(tmp_path):
     for k in range(6):
         train_step(model, opt, *_windows(series, k * BG, BG))
     torch.cuda.synchronize()
-    worst = max(float((got[k] - v.cpu()).abs().max()) for k, v in model.state_dict().items())
-    assert worst <= 2e-5, worst
+    errs = {k: float((got[k] - v.cpu()).abs().max()) for k, v in model.state_dict().items()}
+    worst = max(errs.values())
+    assert worst <= 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
