@@ -62,6 +62,9 @@ typedef struct stgcn_stblock_desc {
     int64_t x_bstride;
     const int64_t* x_index_dev;
     int64_t x_index_stride;
+    int32_t dy_rowstats_ready; /* backward: 1 = the kernel that produced `dy` already wrote this block's LayerNorm-backward row partials
+                                  (stgcn_ln_hook handed to that producer's backward call); the block skips its own pass over dy          */
+    int32_t reserved2;
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -190,6 +193,30 @@ int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_p
                            const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
                            const uint64_t* offset_dev, void* stream);
 
+/* ---- LayerNorm-backward row partials in the PRODUCER of dy.  The backward of `Dropout(LayerNorm(h))` (layers.py:255-256) needs the
+ *      per-slab means of g = mask * dy * gamma and g * xhat before it can touch a single element; the per-row sums they are built
+ *      from can be formed by whichever kernel produces dy (the next module's input gradient) while the row is still on chip.
+ *      stgcn_stblock_ln_hook describes the LayerNorm of a block's forward call (same desc / params / saved / ws / seed / offset as that
+ *      call); hand it to the backward call of the module that consumed the block's output (..._backward_hook below) and set
+ *      desc.dy_rowstats_ready = 1 in the block's own backward call.  A NULL hook reproduces stgcn_*_backward.                     */
+typedef struct stgcn_ln_hook {
+    float* rowstat;            /* [B*T2*N][2] destination (inside the block's ws)                                     */
+    const float *U, *S;        /* [B*T2*N][c2] saved gate inputs of tmp_conv2                                         */
+    const float *gamma;        /* tc2_ln.weight (N, c2)                                                               */
+    const float *mean, *rstd;  /* [B*T2]                                                                              */
+    int32_t N, C, act, training;
+    float droprate;
+    int32_t pad_;
+    uint64_t seed, offset;
+    const uint64_t* offset_dev;
+} stgcn_ln_hook;
+int stgcn_stblock_ln_hook(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* saved, float* ws, uint64_t seed,
+                          uint64_t offset, const uint64_t* offset_dev, stgcn_ln_hook* hook);
+int stgcn_stblock_backward_hook(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
+                                const float* gso_t_pad, const float* dy, const float* saved, float* ws,
+                                const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
+                                const uint64_t* offset_dev, const stgcn_ln_hook* dx_hook, void* stream);
+
 /* out[e] = 0 or 1/(1-p): the keep-scale the forward applies to element e of y (n multiple of 4).     */
 int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                        void* stream);
@@ -242,6 +269,10 @@ int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock
 int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                             const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
                             void* stream);
+/* as above; dx_hook (nullable): LayerNorm of the module that produced x -- its backward row partials are written while dx is formed */
+int stgcn_outblock_backward_hook(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
+                                 const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
+                                 const stgcn_ln_hook* dx_hook, void* stream);
 
 /* ---- Whole-model weight pack: the per-call pack launches of all ST blocks and of the head in ONE launch at the start of a
  *      training / inference step (the parameters only change in optimizer.step(), main.py:169).  Every forward whose desc

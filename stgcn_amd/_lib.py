@@ -27,7 +27,14 @@ class StblockDesc(C.Structure):
                 ("act", C.c_int32), ("graph_conv", C.c_int32), ("training", C.c_int32),
                 ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32),
                 ("prepacked", C.c_int32), ("defer_reduce", C.c_int32),
-                ("x_bstride", C.c_int64), ("x_index_dev", C.c_void_p), ("x_index_stride", C.c_int64)]
+                ("x_bstride", C.c_int64), ("x_index_dev", C.c_void_p), ("x_index_stride", C.c_int64),
+                ("dy_rowstats_ready", C.c_int32), ("reserved2", C.c_int32)]
+
+
+class LnHook(C.Structure):            # stgcn_ln_hook
+    _fields_ = [("rowstat", C.c_void_p), ("U", C.c_void_p), ("S", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("N", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float), ("pad_", C.c_int32),
+                ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p)]
 
 
 PARAM_FIELDS = ["tc1_w", "tc1_b", "tc1_aw", "tc1_ab", "al_w", "al_b", "gc_w", "gc_b",
@@ -135,6 +142,15 @@ class _Lib:
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
                                              C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        d.stgcn_stblock_backward_hook.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
+                                                  C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(LnHook), C.c_void_p]
+        d.stgcn_stblock_ln_hook.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                            C.c_void_p, C.POINTER(LnHook)]
+        d.stgcn_outblock_backward_hook.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.POINTER(OutblockGrads), C.c_void_p, C.POINTER(LnHook), C.c_void_p]
+        for f in ("stgcn_stblock_backward_hook", "stgcn_stblock_ln_hook", "stgcn_outblock_backward_hook"):
+            getattr(d, f).restype = C.c_int
         d.stgcn_dropout_mask.argtypes = [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_outblock_plan_query.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockPlan)]
         d.stgcn_outblock_forward.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -197,4 +213,5 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_stblock_forward", "stgcn_stblock_backward", "stgcn_dropout_mask", "stgcn_profile_enable",
                     "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack",
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
-                    "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages"]
+                    "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
+                    "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook"]

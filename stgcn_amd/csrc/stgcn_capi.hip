@@ -676,6 +676,16 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
     L.add_flat(G->ln_w, part + bg.off_ln_g, bg.ln_sg, n, n);
     L.add_flat(G->ln_b, part + bg.off_ln_b, bg.ln_sg, n, n);
 }
+LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
+    LnRowstatOut o;
+    memset(&o, 0, sizeof(o));
+    if (!h || !h->rowstat) return o;
+    o.rowstat = reinterpret_cast<float2*>(h->rowstat); o.U = h->U; o.S = h->S; o.gamma = h->gamma; o.mean = h->mean; o.rstd = h->rstd;
+    o.N = h->N; o.C = h->C; o.act = h->act; o.training = h->training && h->droprate > 0.f;
+    o.keep_scale = 1.0f / (1.0f - h->droprate); o.thresh = drop_thresh(h->droprate); o.seed = h->seed; o.offset = h->offset;
+    o.offset_dev = h->offset_dev;
+    return o;
+}
 }  // namespace
 
 extern "C" {
@@ -847,6 +857,20 @@ int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uin
     if (n == 0) return STGCN_OK;
     STGCN_LAUNCH("dropout_mask", (hipStream_t)stream, dropout_mask_kernel, dim3(cdiv(n / 4, kThreads)), dim3(kThreads), 0, out,
                  (long)(n / 4), seed, offset, offset_dev, drop_thresh(droprate), 1.0f / (1.0f - droprate));
+    return STGCN_OK;
+}
+
+int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* saved, float* ws, uint64_t seed, uint64_t offset,
+                          const uint64_t* offset_dev, stgcn_ln_hook* h) {
+    stgcn_stblock_plan pl;
+    int rc = stgcn_stblock_plan_query(d, &pl);
+    if (rc) return rc;
+    if (!P || !P->ln_w || !saved || !ws || !h) return fail(STGCN_ERR_INVALID, "stgcn_stblock_ln_hook: NULL argument");
+    memset(h, 0, sizeof(*h));
+    h->rowstat = ws + pl.ws_rowstat_b; h->U = saved + pl.sv_U2; h->S = saved + pl.sv_S2; h->gamma = P->ln_w;
+    h->mean = saved + pl.sv_mean; h->rstd = saved + pl.sv_rstd;
+    h->N = d->N; h->C = d->c2; h->act = d->act; h->training = d->training; h->droprate = d->droprate;
+    h->seed = seed; h->offset = offset; h->offset_dev = offset_dev;
     return STGCN_OK;
 }
 

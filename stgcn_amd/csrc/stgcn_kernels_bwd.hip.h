@@ -19,7 +19,8 @@ namespace stgcn {
 // STGCN_FUSE=<bit mask> (read once): 1 = tc2_bwd_kernel (LayerNorm/dropout/gate backward + tmp_conv2 weight gradient + transposed conv in
 // one launch).  Default: everything on; 0 reproduces the round-1 launch sequence (A/B runs, stage tests).
 //                                  2 = tc2_ln_fwd_kernel (tmp_conv2 + gate + LayerNorm + dropout of one slab per workgroup).
-enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2 };
+//                                  4 = LayerNorm-backward row partials in the epilogue of the kernel that produces dy (stgcn_ln_hook).
+enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4 };
 inline int fuse_mask() {
     static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
     return m;
@@ -30,7 +31,7 @@ inline bool tc2_ln_fwd_fused_ok(int c1, int c2, int Kt, int N) {
     return (fuse_mask() & FUSE_TC2_LN_FWD) && c1 == 16 && c2 == 64 && Kt >= 2 && Kt <= 4 && N <= 448 && tc2_ln_fwd_lds_bytes(Kt, N) <= 150 * 1024;
 }
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
-    return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && (c2 == 64 || c2 == 128) && Kt >= 2 && Kt <= 4 && T1 <= kTsMaxT &&
+    return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && ((c2 == 64 && Kt >= 2 && Kt <= 4) || (c2 == 128 && Kt == 3)) && T1 <= kTsMaxT &&
            tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 64 * 1024;
 }
 

@@ -822,6 +822,49 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, 
     STGCN_PHASE(a.Wap ? 1 : 7, 7);
 }
 
+
+// ================================================================================================
+// LayerNorm-backward row partials in the epilogue of the kernel that PRODUCES the gradient dy of a LayerNorm output
+// (SURVEY.md 8a row a6): the slab constants c1 = mean(g), c2 = mean(g * xhat), g = dropout_mask * dy * gamma, need all N rows
+// of a (b, t) slab, so the consumer (tc2_bwd_kernel / ln_gate_bwd_kernel) takes per-ROW sums; forming them where dy is still
+// on chip saves the ln_bwd_rowstats_kernel launch and its re-read of dy.
+// ================================================================================================
+struct LnRowstatOut {
+    float2* rowstat;      // [slabs*N] (sum g, sum g*xhat) per row; null = epilogue disabled
+    const float* U;       // [slabs*N][C] saved gate inputs of the layer in front of the LayerNorm
+    const float* S;
+    const float* gamma;   // [N][C]
+    const float* mean;    // [slabs]
+    const float* rstd;
+    int N, C, act, training;
+    float keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+    const uint64_t* offset_dev;
+};
+// contribution of 4 consecutive channels (c .. c+3) of row (slab, node): returns (sum g, sum g*xhat) of those 4
+__device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, f32x4 dy, long slab, int node, int c) {
+    const size_t e = ((size_t)slab * o.N + node) * o.C + c;
+    const f32x4 u = ld4(o.U + e), s = ld4(o.S + e), ga = ld4(o.gamma + (size_t)node * o.C + c);
+    const float mean = o.mean[slab], rstd = o.rstd[slab];
+    if (o.training) {
+        const uint64_t off = o.offset + (o.offset_dev ? *o.offset_dev : 0);
+        const f32x4 k = dropout_scale4((uint64_t)slab * (((uint64_t)o.N * o.C) >> 2) + (((uint64_t)node * o.C + c) >> 2), o.seed, off, o.thresh,
+                                       o.keep_scale);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xh = (gate_fwd(u[i], s[i], o.act) - mean) * rstd;
+        const float gg = dy[i] * ga[i];
+        s1 += gg;
+        s2 += gg * xh;
+    }
+    return make_float2(s1, s2);
+}
+
 // ================================================================================================
 // F1 (v4, wide outputs / few rows: the output head): row tile of 16*TM rows x NC = 256 columns, 8 waves (wave w owns
 // n-tiles w and w + 8), the whole im2col tile in LDS, and the weight fragments STREAMED in rounds of KC chunks through two
@@ -837,6 +880,7 @@ struct Tconv4Args {
     TconvFwdArgs f;     // ts, Wp, bias, KCH, Cout (NC = 2*Cout), act, U, S, rowstat (gated) -- H, align fields unused
     float* out;         // PLAIN: destination tensor (B, outT, N, outC)
     int outT, outC;
+    LnRowstatOut rs;    // PLAIN: LayerNorm-backward row partials of the layer whose output `out` is the gradient of (rs.rowstat != null)
 };
 
 template <int TM, int KC, bool PLAIN>
@@ -910,9 +954,18 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = (tid + it * THREADS) / Q4;
-            if (row0 + row < a.ts.rows) {
-                const RowCoord c = row_advance(a.ts, c0, row);     // (b, t = 0, n) of the dZ row
-                st4(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, ld4(Zt + row * LDZ + 4 * q));
+            const bool rin = row0 + row < a.ts.rows;
+            const RowCoord c = row_advance(a.ts, c0, rin ? row : 0);     // (b, t = 0, n) of the dZ row
+            const f32x4 v = ld4(Zt + row * LDZ + 4 * q);
+            if (rin) st4(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
+            if (aa.rs.rowstat) {   // uniform; the outC / 4 lanes holding one output row are consecutive and aligned
+                const long slab = (long)c.b * aa.outT + tap;
+                float2 p = rin ? ln_rowstat4(aa.rs, v, slab, c.n, ci) : make_float2(0.f, 0.f);
+                for (int m = aa.outC >> 3; m >= 1; m >>= 1) {
+                    p.x += __shfl_xor(p.x, m);
+                    p.y += __shfl_xor(p.y, m);
+                }
+                if (rin && ci == 0) aa.rs.rowstat[slab * a.ts.N + c.n] = p;
             }
         }
     } else {

@@ -108,6 +108,7 @@ struct FcBwdArgs {
     long rows;
     int c0, c1, KCH;      // KCH = c1 / 16
     float grad_scale;     // keep_scale when dropout was active, else 1
+    LnRowstatOut rs;      // row partials of the head's LayerNorm backward (dyln is its output gradient); rs.rowstat == null: off
 };
 
 template <int WM, int NT>
@@ -151,16 +152,44 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
         pre_mma<WM, NT, 8>(acc, At, lda, 0, a.KCH, w);
+        if (a.rs.rowstat && c0 == c1) {
+            // dyln through the LDS tile: 16-byte row-major stores, and the LayerNorm-backward row partials while the row is on chip
+            __syncthreads();   // every wave is done reading At
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = (wave + 4 * j) * 16 + l15;
+            for (int j = 0; j < NT; ++j) {
+                const int col = (wave + 4 * j) * 16 + l15;
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long R = row0 + i * 16 + 4 * g + r;
-                    if (R < a.rows && col < c0) a.dyln[(size_t)R * c0 + col] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) At[(i * 16 + 4 * g + r) * lda + col] = acc[i][j][r];
+            }
+            __syncthreads();
+            for (int row = rsub; row < TR; row += kThreads / c4n) {   // c4n lanes (half a wave for c0 = 128) hold one row
+                const long R = row0 + row;
+                const bool rin = R < a.rows;
+                const f32x4 v = ld4(At + row * lda + 4 * c4);
+                if (rin) st4(a.dyln + (size_t)R * c0 + 4 * c4, v);
+                const long slab = rin ? R / a.rs.N : 0;
+                const int node = rin ? (int)(R - slab * a.rs.N) : 0;
+                float2 p = rin ? ln_rowstat4(a.rs, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);
+                for (int m = c4n >> 1; m >= 1; m >>= 1) {
+                    p.x += __shfl_xor(p.x, m);
+                    p.y += __shfl_xor(p.y, m);
                 }
+                if (rin && c4 == 0) a.rs.rowstat[R] = p;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (wave + 4 * j) * 16 + l15;
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long R = row0 + i * 16 + 4 * g + r;
+                        if (R < a.rows && col < c0) a.dyln[(size_t)R * c0 + col] = acc[i][j][r];
+                    }
+            }
         }
     }
     __syncthreads();

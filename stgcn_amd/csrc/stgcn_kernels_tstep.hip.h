@@ -12,6 +12,7 @@
 //                    D leaves a lane with 4 consecutive channels of one row = a 16-byte store.
 // Reference arithmetic: hazdzz/STGCN model/layers.py:87-120 (TemporalConvLayer), :246/255-256 (LayerNorm, Dropout).
 #pragma once
+#include <type_traits>
 #include "stgcn_device.hip.h"
 
 namespace stgcn {
@@ -37,7 +38,6 @@ struct Tc2BwdArgs {
     const float* G;           // [B][T1][N][16]  tmp_conv2 input (relu output, also the relu mask)
     const float* Wd;          // [Kt*16][2*C2]   dense W_eff of tmp_conv2 (PK_TCONV_DENSE)
     float* dYg;               // [B][T1][N][16]
-    float* dZ;                // optional [B*T2*N][2*C2]  (stage tests only)
     float* part;              // [wgs][Kt*16*NC + NC]  dW_eff2 | db_eff2 partials
     float* dgam_part;         // [B][N*C2]
     float* dbet_part;
@@ -53,220 +53,256 @@ inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
     return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2) * sizeof(float);
 }
 
-template <int C2, int KT>
-__global__ __launch_bounds__(256) void tc2_bwd_kernel(Tc2BwdArgs a) {
+// Wave specialisation: a workgroup is 8 waves = 4 "E" waves + 4 "M" waves, one of each per SIMD.
+//     E waves (VALU / memory): E(t) = dy, U, S tiles (prefetched two steps ahead) -> dZ2 tile t into ring slot t % (KT + 1), plus the
+//                              LayerNorm-parameter and bias partials;
+//     M waves (matrix cores) : F(t - 1) = dYg[t - 1] from the 4 partial tiles of the previous step;
+//                              M(t) = weight-gradient MFMAs of tile t + transposed-conv MFMAs for output step t -> `red[t & 1]`.
+//   iteration t:  barrier | E waves: E(t + 1)  ||  M waves: F(t - 1), M(t)
+// The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
+// walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
+// spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
+template <int C2, int KT, bool TRAINING, int ACT>
+__global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20, RING = KT + 1, RED = 4 * 16 * LDG;
     extern __shared__ float stgcn_smem[];
-    float* const Zt = stgcn_smem;                      // [KT + 1][16][LDZ]  ring of dZ2 tiles (one spare slot: the next tile is written
-                                                       //                    while slower waves still read the KT previous ones)
+    float* const Zt = stgcn_smem;                      // [KT + 1][16][LDZ]  ring of dZ2 tiles
     float* const GT = Zt + RING * 16 * LDZ;            // [T1][16 ch][LDG]  G tiles, transposed (GT[t][i][row])
-    float* const red = GT + a.T1 * 16 * LDG;           // [2][4 waves][16 rows][LDG]  transposed-conv partials of the 4 waves, double buffered
+    float* const red = GT + a.T1 * 16 * LDG;           // [2][4 waves][16 rows][LDG]  transposed-conv partials of the 4 M waves, double buffered
     float* const cs = red + 2 * RED;                   // [T2][4]: c1, c2, mean, rstd
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const bool roleE = threadIdx.x < 256;              // wave-uniform
+    const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int b = (int)blockIdx.x / a.node_tiles, nt = (int)blockIdx.x - b * a.node_tiles, n0 = nt * 16;
     const int N = a.N, T1 = a.T1, T2 = a.T2;
-    const int r = tid >> 4, cq = tid & 15;             // elementwise phase: row r, float4 columns cq + 16*it
+    const int r = tid >> 4, cq = tid & 15;             // row r, float4 column cq (+ 16 it) of the 16-row tile
     const bool rv = n0 + r < N;
+    const int rc = rv ? n0 + r : N - 1;                // clamped row: rows beyond N read a valid address and are masked to zero
+    float* const part = a.part + (size_t)blockIdx.x * (KT * 16 * NC + NC);
+    STGCN_PHASE(8, 0);
 
-    // one-step software prefetch of the streamed tiles (the first one is requested before anything else)
-    f32x4 dyn[IT], un[IT], sn[IT];
-    auto fetch = [&](int t2) {
+    if (roleE) {
+        // =========================================== E waves ===========================================================
+        struct Tile { f32x4 dy[IT], u[IT], s[IT]; };
+        auto fetch = [&](int t2, Tile& t) {
+            const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                t.dy[it] = ld4(a.dy + e0 + 64 * it);
+                t.u[it] = ld4(a.U + e0 + 64 * it);
+                t.s[it] = ld4(a.S + e0 + 64 * it);
+                if (!rv) { t.dy[it] = zero4(); t.s[it] = zero4(); }   // s = 0 makes every product of the gate backward vanish
+            }
+        };
+        Tile p0, p1;
+        fetch(0, p0);
+        fetch(1, p1);
+        f32x4 gam[IT], dgam[IT], dbet[IT], dbu[IT], dbq[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const size_t e = (((size_t)b * T2 + t2) * N + n0 + r) * C2 + 4 * (cq + 16 * it);
-            dyn[it] = rv ? ld4(a.dy + e) : zero4();
-            un[it] = rv ? ld4(a.U + e) : zero4();
-            sn[it] = rv ? ld4(a.S + e) : zero4();
+            gam[it] = ld4(a.gamma + (size_t)rc * C2 + 4 * (cq + 16 * it));
+            dgam[it] = zero4(); dbet[it] = zero4(); dbu[it] = zero4(); dbq[it] = zero4();
         }
-    };
-    if (T2 > 0) fetch(0);
-    // ---- stationary weights of the transposed conv: wave w contracts o in [w*NC/4, (w+1)*NC/4) of every tap ----------------
-    f32x4 Wr[KT][QW];
-#pragma unroll
-    for (int k = 0; k < KT; ++k)
-#pragma unroll
-        for (int q = 0; q < QW; ++q) Wr[k][q] = ld4(a.Wd + (size_t)(k * 16 + l15) * NC + w * (NC / 4) + q * 16 + 4 * g);
-    f32x4 gam[IT], dgam[IT], dbet[IT], dbu[IT], dbq[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        gam[it] = rv ? ld4(a.gamma + (size_t)(n0 + r) * C2 + 4 * (cq + 16 * it)) : zero4();
-        dgam[it] = zero4(); dbet[it] = zero4(); dbu[it] = zero4(); dbq[it] = zero4();
-    }
-    // ---- slab constants of this window's T2 slabs: 32 lanes per slab, 8 slabs at a time ------------------------------------
-    {
-        const int grp = tid >> 5, l32 = tid & 31;
-        for (int t0 = 0; t0 < T2; t0 += 8) {   // uniform trip count
-            const int t = t0 + grp;
-            const long slab = (long)b * T2 + (t < T2 ? t : 0);
-            float x = 0.f, y = 0.f;
-            if (t < T2) {
+        // slab constants of this window's T2 slabs: 32 lanes per slab, 8 slabs at a time, 8 independent loads per lane in flight
+        {
+            const int grp = tid >> 5, l32 = tid & 31;
+            for (int t0 = 0; t0 < T2; t0 += 8) {   // uniform trip count
+                const int t = t0 + grp;
+                const long slab = (long)b * T2 + (t < T2 ? t : 0);
+                float x = 0.f, y = 0.f;
                 if (a.slabconst) {
-                    if (l32 == 0) {
+                    if (t < T2 && l32 == 0) {
                         const float2 c = a.slabconst[slab];
                         x = c.x; y = c.y;
                     }
                 } else {
                     const float2* rs = a.rowstat + slab * N;
-                    for (int i = l32; i < N; i += 32) {
-                        const float2 v = rs[i];
-                        x += v.x;
-                        y += v.y;
+                    for (int i0 = 0; i0 < N; i0 += 256) {
+                        float2 v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int i = i0 + l32 + 32 * j;
+                            v[j] = (t < T2 && i < N) ? rs[i] : make_float2(0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            x += v[j].x;
+                            y += v[j].y;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) {
-                x += __shfl_xor(x, m);
-                y += __shfl_xor(y, m);
-            }
-            if (t < T2 && l32 == 0) {
-                const float inv = a.slabconst ? 1.0f : 1.0f / ((float)N * (float)C2);
-                cs[4 * t] = x * inv;
-                cs[4 * t + 1] = y * inv;
-                cs[4 * t + 2] = a.mean[slab];
-                cs[4 * t + 3] = a.rstd[slab];
+                for (int m = 16; m >= 1; m >>= 1) {
+                    x += __shfl_xor(x, m);
+                    y += __shfl_xor(y, m);
+                }
+                if (t < T2 && l32 == 0) {
+                    const float inv = a.slabconst ? 1.0f : 1.0f / ((float)N * (float)C2);
+                    cs[4 * t] = x * inv;
+                    cs[4 * t + 1] = y * inv;
+                    cs[4 * t + 2] = a.mean[slab];
+                    cs[4 * t + 3] = a.rstd[slab];
+                }
             }
         }
-    }
-    // ---- all G tiles of this (window, node tile), transposed ------------------------------------------------------------
-    for (int idx = tid; idx < T1 * 64; idx += 256) {
-        const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
-        const f32x4 v = n0 + rr < N ? ld4(a.G + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
-    }
-    f32x4 accw[KT][NTW];
-#pragma unroll
-    for (int k = 0; k < KT; ++k)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
-    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-    const int n4 = (N * C2) >> 2;
-    // dYg[t] = relu'(G[t]) * (sum of the 4 waves' partial tiles), thread (row r, channel cq)
-    auto finish = [&](int t) {
-        const float* rd = red + (t & 1) * RED;
-        float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
-        if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
-        if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
-    };
-    __syncthreads();
-
-    for (int t1 = 0; t1 < T1; ++t1) {
-        const bool step = t1 < T2;                      // uniform: a new dZ2 tile this step
-        float* const Zs = Zt + (t1 % RING) * 16 * LDZ;
-        if (step) {
-            const float c1 = cs[4 * t1], c2 = cs[4 * t1 + 1], mean = cs[4 * t1 + 2], rstd = cs[4 * t1 + 3];
+        const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+        const uint64_t n4 = ((uint64_t)N * C2) >> 2, q0 = (((uint64_t)rc * C2) >> 2) + cq;
+        // E(t): branch free (rows beyond N carry s = 0, dy = 0: every product vanishes)
+        auto E = [&](int t, const Tile& tl) {
+            float* const Zs = Zt + (t % RING) * 16 * LDZ;
+            const float c1 = cs[4 * t], c2 = cs[4 * t + 1], mean = cs[4 * t + 2], rstd = cs[4 * t + 3];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                f32x4 dy = dyn[it];
-                const f32x4 u = un[it], s = sn[it];
+                f32x4 dy = tl.dy[it];
+                const f32x4 u = tl.u[it], s = tl.s[it];
                 const int c4 = cq + 16 * it;
-                if (a.training) {
-                    const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t1) * n4 + (((uint64_t)(n0 + r) * C2) >> 2) + c4, a.seed, off, a.thresh,
-                                                   a.keep_scale);
+                if constexpr (TRAINING) {
+                    const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dy[i] *= k[i];
                 }
-                f32x4 du = zero4(), dq = zero4();
-                if (rv) {
+                f32x4 du, dq;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float xh = (gate_fwd(u[i], s[i], a.act) - mean) * rstd;
-                        const float gg = dy[i] * gam[it][i];
-                        const float dh = rstd * (gg - c1 - xh * c2);
-                        dgam[it][i] += dy[i] * xh;
-                        dbet[it][i] += dy[i];
-                        float du_, dq_;
-                        gate_bwd(dh, u[i], s[i], a.act, du_, dq_);
-                        du[i] = du_;
-                        dq[i] = dq_;
-                    }
-                    dbu[it] += du;
-                    dbq[it] += dq;
-                    if (a.dZ) {
-                        float* z = a.dZ + (((size_t)b * T2 + t1) * N + n0 + r) * NC + 4 * c4;
-                        st4(z, du);
-                        st4(z + C2, dq);
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (gate_fwd(u[i], s[i], ACT) - mean) * rstd;   // ACT is a compile-time constant: no tanhf call / branch for GLU
+                    const float gg = dy[i] * gam[it][i];
+                    const float dh = rstd * (gg - c1 - xh * c2);
+                    dgam[it][i] += dy[i] * xh;
+                    dbet[it][i] += dy[i];
+                    float du_, dq_;
+                    gate_bwd(dh, u[i], s[i], ACT, du_, dq_);
+                    du[i] = du_;
+                    dq[i] = dq_;
                 }
+                dbu[it] += du;
+                dbq[it] += dq;
                 st4(Zs + r * LDZ + 4 * c4, du);
                 st4(Zs + r * LDZ + C2 + 4 * c4, dq);
             }
-        }
-        __syncthreads();   // ONE barrier per step: this step's dZ2 tile and the previous step's partial tiles are visible
-        if (t1 + 1 < T2) fetch(t1 + 1);
-        if (t1 > 0) finish(t1 - 1);
-        if (step) {
-            // weight gradient: A[m = i][k = row] = G[t1 + tap][row][i] (transposed tiles: one 16-byte read), B[k = row][n = o] = dZ2
-            f32x4 bz[NTW];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) bz[j][s] = Zs[(4 * g + s) * LDZ + (w * NTW + j) * 16 + l15];
-            }
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const f32x4 af = ld4(GT + ((t1 + k) * 16 + l15) * LDG + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) accw[k][j] = mfma4(af[s], bz[j][s], accw[k][j]);
+        };
+        __syncthreads();   // (A) cs complete (written by E waves), GT complete (written by M waves)
+        STGCN_PHASE(8, 1);
+        E(0, p0);
+        p0 = p1;
+        fetch(2, p1);
+        for (int t1 = 0; t1 < T1; ++t1) {
+            __syncthreads();   // (B) tile t1 visible to the M waves
+            if (t1 + 1 < T2) {
+                E(t1 + 1, p0);
+                p0 = p1;
+                fetch(t1 + 3, p1);
             }
         }
-        // transposed conv for output step t1: taps with 0 <= t1 - tap < T2 (two accumulators: independent MFMA chains)
-        f32x4 accd[2] = {zero4(), zero4()};
+        STGCN_PHASE(8, 4);
+        __syncthreads();       // (C) last partial tiles visible
+        if (rv) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const int ts = t1 - k;
-            if (ts >= 0 && ts < T2) {   // uniform
-                const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + w * (NC / 4) + 4 * g;
+            for (int it = 0; it < IT; ++it) {
+                const size_t o = (size_t)b * N * C2 + (size_t)(n0 + r) * C2 + 4 * (cq + 16 * it);
+                st4(a.dgam_part + o, dgam[it]);
+                st4(a.dbet_part + o, dbet[it]);
+            }
+        }
+        __syncthreads();       // (D) `red` free: it becomes the bias-reduction buffer
+        // db_eff2[o] = sum over the 16 rows (threads with equal cq: lanes 16 apart, then the 4 waves through LDS)
+        float* bred = red;     // [4 waves][NC] (NC <= 256: fits the 2 x 1280 floats of `red`)
 #pragma unroll
-                for (int q = 0; q < QW; ++q) {
-                    const f32x4 z = ld4(zr + q * 16);
+        for (int it = 0; it < IT; ++it) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
+            for (int i = 0; i < 4; ++i) {
+                float x = dbu[it][i], y = dbq[it][i];
+                x += __shfl_xor(x, 16); y += __shfl_xor(y, 16);
+                x += __shfl_xor(x, 32); y += __shfl_xor(y, 32);
+                if (g == 0) {
+                    bred[w * NC + 4 * (l15 + 16 * it) + i] = x;
+                    bred[w * NC + C2 + 4 * (l15 + 16 * it) + i] = y;
                 }
             }
         }
-        st4(red + (t1 & 1) * RED + (w * 16 + l15) * LDG + 4 * g, accd[0] + accd[1]);   // D[m = i = 4g + r][n = row = l15]
-    }
-    __syncthreads();
-    finish(T1 - 1);
-
-    // ---- per-workgroup partials ---------------------------------------------------------------------------------------------
-    float* part = a.part + (size_t)blockIdx.x * (KT * 16 * NC + NC);
+        __syncthreads();       // (E)
+        if (tid < NC) part[(size_t)KT * 16 * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
+        STGCN_PHASE(8, 6);
+    } else {
+        // =========================================== M waves ===========================================================
+        // stationary weights of the transposed conv: wave w contracts o in [w*NC/4, (w+1)*NC/4) of every tap
+        f32x4 Wr[KT][QW];
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
+        for (int k = 0; k < KT; ++k)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+            for (int q = 0; q < QW; ++q) Wr[k][q] = ld4(a.Wd + (size_t)(k * 16 + l15) * NC + w * (NC / 4) + q * 16 + 4 * g);
+        // all G tiles of this (window, node tile), transposed
+        for (int idx = tid; idx < T1 * 64; idx += 256) {
+            const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
+            const f32x4 v = n0 + rr < N ? ld4(a.G + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) part[(size_t)(k * 16 + 4 * g + rr) * NC + (w * NTW + j) * 16 + l15] = accw[k][j][rr];
-    if (rv) {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const size_t o = (size_t)b * N * C2 + (size_t)(n0 + r) * C2 + 4 * (cq + 16 * it);
-            st4(a.dgam_part + o, dgam[it]);
-            st4(a.dbet_part + o, dbet[it]);
+            for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
         }
-    }
-    // db_eff2[o] = sum over the 16 rows (threads with equal cq: lanes 16 apart, then the 4 waves through LDS)
-    __syncthreads();   // `red` reads of the last step done
-    float* bred = red;   // [4 waves][NC] (NC <= 256: fits the 2 x 1280 floats of `red`)
+        f32x4 accw[KT][NTW];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
+        for (int k = 0; k < KT; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float x = dbu[it][i], y = dbq[it][i];
-            x += __shfl_xor(x, 16); y += __shfl_xor(y, 16);
-            x += __shfl_xor(x, 32); y += __shfl_xor(y, 32);
-            if (g == 0) {
-                bred[w * NC + 4 * (l15 + 16 * it) + i] = x;
-                bred[w * NC + C2 + 4 * (l15 + 16 * it) + i] = y;
+            for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
+        __syncthreads();   // (A)
+        for (int t1 = 0; t1 < T1; ++t1) {
+            __syncthreads();   // (B) dZ2 tile t1 and the partial tiles of step t1 - 1 are visible
+            if (t1 > 0) {      // F(t1 - 1): dYg = relu'(G) * (sum of the 4 waves' partial tiles), thread (row r, channel cq)
+                const int t = t1 - 1;
+                const float* rd = red + (t & 1) * RED;
+                float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
+                if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
+                if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
             }
+            if (t1 < T2) {     // weight gradient of tile t1: A[m = i][k = row] = G[t1 + tap][row][i] (one 16-byte read), B[k = row][n = o] = dZ2
+                const float* const Zs = Zt + (t1 % RING) * 16 * LDZ;
+                f32x4 bz[NTW];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) bz[j][s] = Zs[(4 * g + s) * LDZ + (w * NTW + j) * 16 + l15];
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const f32x4 af = ld4(GT + ((t1 + k) * 16 + l15) * LDG + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) accw[k][j] = mfma4(af[s], bz[j][s], accw[k][j]);
+                }
+            }
+            // transposed conv for output step t1: taps with 0 <= t1 - tap < T2; two independent MFMA chains
+            f32x4 accd[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int ts = t1 - k;
+                if (ts >= 0 && ts < T2) {   // uniform
+                    const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + w * (NC / 4) + 4 * g;
+#pragma unroll
+                    for (int q = 0; q < QW; ++q) {
+                        const f32x4 z = ld4(zr + q * 16);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
+                    }
+                }
+            }
+            st4(red + (t1 & 1) * RED + (w * 16 + l15) * LDG + 4 * g, accd[0] + accd[1]);   // D[m = i = 4g + r][n = row = l15]
         }
+        __syncthreads();       // (C)
+        {
+            const int t = T1 - 1;
+            const float* rd = red + (t & 1) * RED;
+            float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
+            if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
+            if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
+        }
+        STGCN_PHASE(8, 5);
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) part[(size_t)(k * 16 + 4 * g + rr) * NC + (w * NTW + j) * 16 + l15] = accw[k][j][rr];
+        __syncthreads();       // (D)
+        __syncthreads();       // (E)
     }
-    __syncthreads();
-    if (tid < NC) part[(size_t)KT * 16 * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
 }
 
 // ================================================================================================
@@ -312,6 +348,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     const long slab = blockIdx.x;
     const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N, NPR = a.NPR, ntiles = NPR >> 4;
 
+    STGCN_PHASE(9, 0);
     // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)
     f32x4 wP[KT], wQ[KT];
 #pragma unroll
@@ -328,91 +365,122 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     const int c = 16 * p + 4 * g;   // this lane's 4 channels
     const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C2 + c);
     __syncthreads();
+    STGCN_PHASE(9, 1);
 
-    f32x4 accP[NTI], accQ[NTI];
+    unsigned kbits2 = 0;
+    // LayerNorm parameters of this lane's elements: requested now, consumed after the statistics (in flight during the MFMA phase)
+    f32x4 ga[NTI], be[NTI];
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        accP[j] = zero4();
-        accQ[j] = zero4();
+        const int row = (hf + 2 * j) * 16 + l15, rcl = row < N ? row : N - 1;
+        ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
+        be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
     }
+    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+    const uint64_t n4 = ((uint64_t)N * C2) >> 2;
+    // Per row tile: MFMAs, then the gate (U = P + b, S = sigmoid(Q + b), h = act(U) * S, kept in hh) and the keep bits of the dropout mask.
+    // The two waves of a SIMD (hf = 0 / 1) fall into anti-phase: one issues MFMAs while the other runs the VALU work of its previous tile.
+    f32x4 hh[NTI];
+    unsigned kbits = 0;
+    float sum = 0.f, cnt_l = 0.f;
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int nt = hf + 2 * j;
+        const int nt = hf + 2 * j, row = nt * 16 + l15;
+        hh[j] = zero4();
         if (nt < ntiles) {   // uniform per wave
+            f32x4 accP = zero4(), accQ = zero4();
 #pragma unroll
             for (int kc = 0; kc < KT; ++kc) {
                 const f32x4 bf = ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g);   // B[k = 4g + s][n = row]
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    accP[j] = mfma4(wP[kc][s], bf[s], accP[j]);
-                    accQ[j] = mfma4(wQ[kc][s], bf[s], accQ[j]);
+                    accP = mfma4(wP[kc][s], bf[s], accP);
+                    accQ = mfma4(wQ[kc][s], bf[s], accQ);
                 }
             }
-        }
-    }
-    // gate: U = P + b, S = sigmoid(Q + b), h = act(U) * S (kept in accP); pass 1 of the slab statistics
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + 2 * j) * 16 + l15;
-        if (row < N) {
-            f32x4 u, sg, h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u[i] = accP[j][i] + bp[i];
-                sg[i] = sigmoid_f(accQ[j][i] + bq[i]);
-                h[i] = gate_fwd(u[i], sg[i], a.act);
+            if (a.training) {
+                const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (((size_t)(row < N ? row : 0) * C2 + c) >> 2), a.seed, off, a.thresh, 1.0f);
+                kbits |= ((k[0] > 0.f ? 1u : 0u) | (k[1] > 0.f ? 2u : 0u) | (k[2] > 0.f ? 4u : 0u) | (k[3] > 0.f ? 8u : 0u)) << (4 * (j & 7));
             }
-            const size_t o = ((size_t)slab * N + row) * C2 + c;
-            st4(a.U + o, u);
-            st4(a.S + o, sg);
-            accP[j] = h;
-            sum += (h[0] + h[1]) + (h[2] + h[3]);
+            if (row < N) {
+                f32x4 u, sg, h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u[i] = accP[i] + bp[i];
+                    sg[i] = sigmoid_f(accQ[i] + bq[i]);
+                    h[i] = gate_fwd(u[i], sg[i], a.act);
+                }
+                const size_t o = ((size_t)slab * N + row) * C2 + c;
+                st4(a.U + o, u);
+                st4(a.S + o, sg);
+                hh[j] = h;
+                sum += (h[0] + h[1]) + (h[2] + h[3]);
+                cnt_l += 4.f;
+            }
+        }
+        if ((j & 7) == 7 && j + 1 < NTI) {   // (NTI = 14: the keep bits of the first 8 tiles move to the upper word)
+            kbits2 = kbits;
+            kbits = 0;
         }
     }
-    auto block_sum = [&](float v) {
+    STGCN_PHASE(9, 3);
+    // slab statistics with ONE barrier: per-wave (count, mean, M2) about the wave's own mean, merged exactly (Chan et al.)
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        __syncthreads();   // protect red from its previous use
-        if (lane == 0) red[wv] = v;
-        __syncthreads();
-        return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-    };
-    const float cnt = (float)N * (float)C2;
-    const float mean = block_sum(sum) / cnt;
+    for (int m = 32; m >= 1; m >>= 1) {
+        sum += __shfl_xor(sum, m);
+        cnt_l += __shfl_xor(cnt_l, m);
+    }
+    const float mean_w = cnt_l > 0.f ? sum / cnt_l : 0.f;
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
         const int row = (hf + 2 * j) * 16 + l15;
         if (row < N) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m2 += (accP[j][i] - mean) * (accP[j][i] - mean);
+            for (int i = 0; i < 4; ++i) m2 += (hh[j][i] - mean_w) * (hh[j][i] - mean_w);
         }
     }
-    const float rstd = 1.0f / sqrtf(block_sum(m2) / cnt + a.eps);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) m2 += __shfl_xor(m2, m);
+    if (lane == 0) {
+        red[3 * wv] = cnt_l;
+        red[3 * wv + 1] = mean_w;
+        red[3 * wv + 2] = m2;
+    }
+    __syncthreads();
+    float nn = 0.f, mean = 0.f, M2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float nw = red[3 * k], mw = red[3 * k + 1], qw = red[3 * k + 2];
+        if (nw > 0.f) {
+            const float d = mw - mean, nt2 = nn + nw;
+            mean += d * (nw / nt2);
+            M2 += qw + d * d * (nn * nw / nt2);
+            nn = nt2;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(M2 / nn + a.eps);
     if (tid == 0) {
         a.mean[slab] = mean;
         a.rstd[slab] = rstd;
     }
-    const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-    const uint64_t n4 = ((uint64_t)N * C2) >> 2;
+    STGCN_PHASE(9, 4);
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
         const int row = (hf + 2 * j) * 16 + l15;
         if (row < N) {
             const size_t e = (size_t)row * C2 + c;
-            const f32x4 ga = ld4(a.gamma + e), be = ld4(a.beta + e);
+            const unsigned kb = ((NTI > 8 && j < 8) ? kbits2 : kbits) >> (4 * (j & 7));
             f32x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (accP[j][i] - mean) * rstd * ga[i] + be[i];
-            if (a.training) {
-                const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (e >> 2), a.seed, off, a.thresh, a.keep_scale);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] *= k[i];
+            for (int i = 0; i < 4; ++i) {
+                o[i] = (hh[j][i] - mean) * rstd * ga[j][i] + be[j][i];
+                if (a.training) o[i] = ((kb >> i) & 1u) ? o[i] * a.keep_scale : 0.f;
             }
             st4(a.y + (size_t)slab * N * C2 + e, o);
         }
     }
+    STGCN_PHASE(9, 5);
 }
 
 }  // namespace stgcn

@@ -322,6 +322,30 @@ class WorkspaceCache:
         return b
 
 
+class LnHookState:
+    """LayerNorm of one ST-block forward call, offered to whichever fused operator consumes that block's output: the consumer's
+    backward forms the block's LayerNorm-backward row partials while its input gradient is still on chip (``stgcn_ln_hook``) and marks
+    the state ready; the block's own backward then skips its pass over dy -- if the gradient it receives is the very buffer the
+    consumer wrote (``dx_ptr``), i.e. nothing else contributed to it."""
+    __slots__ = ("hook", "keep", "ready", "dx_ptr")
+
+    def __init__(self, hook, keep):
+        self.hook, self.keep, self.ready, self.dx_ptr = hook, keep, False, None
+
+
+_ln_hooks: "Dict[int, LnHookState]" = {}      # key: data_ptr of a block output (channels-last storage)
+
+
+def _offer_ln_hook(y: torch.Tensor, state: LnHookState) -> None:
+    if len(_ln_hooks) > 64:                   # outputs nobody consumed through a fused operator (e.g. a block used on its own)
+        _ln_hooks.clear()
+    _ln_hooks[y.data_ptr()] = state
+
+
+def _take_ln_hook(x_cl: torch.Tensor) -> Optional[LnHookState]:
+    return _ln_hooks.pop(x_cl.data_ptr(), None)
+
+
 def _param_struct(cls, tensors):
     s = cls()
     for name, t in zip(PARAM_FIELDS, tensors):
@@ -355,6 +379,14 @@ class _STBlockFn(torch.autograd.Function):
         L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_pad.data_ptr(), y.data_ptr(),
                                             saved.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev), _stream_of(x_cl)),
                 "stgcn_stblock_forward")
+        ctx.in_hook = _take_ln_hook(x_cl) if need_dx else None          # LayerNorm of the module that produced x (if it was a fused block)
+        ctx.own_hook = None
+        if any(p is not None and p.requires_grad for p in params):       # (a later backward is possible)
+            hk = _lib.LnHook()
+            L.check(L.dll.stgcn_stblock_ln_hook(C.byref(desc), C.byref(pst), saved.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev),
+                                                C.byref(hk)), "stgcn_stblock_ln_hook")
+            ctx.own_hook = LnHookState(hk, (saved, ws, ps, offset_dev))
+            _offer_ln_hook(y, ctx.own_hook)
         ctx.save_for_backward(x_cl, saved, gso_t_pad, *[p for p in params if p is not None])
         ctx.param_present = [p is not None for p in params]
         ctx.cfg, ctx.training, ctx.seed, ctx.offset, ctx.wsc, ctx.ws = cfg, training, seed, offset, wsc, ws
@@ -375,8 +407,11 @@ class _STBlockFn(torch.autograd.Function):
         sink = _sink
         desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None, x_bstride=ctx.x_window[0], x_index=ctx.x_window[1],
                          x_index_stride=ctx.x_window[2])
-        plan = query_plan(desc)
         dy = dy.contiguous()
+        own = ctx.own_hook
+        if own is not None and own.ready and own.dx_ptr == dy.data_ptr():
+            desc.dy_rowstats_ready = 1       # the consumer of y wrote this block's LayerNorm-backward row partials with its dx
+        plan = query_plan(desc)
         dev = x_cl.device
         c0, c1, c2 = cfg.channels
         # which parameters the forward actually used (reference leaves .grad None for the others)
@@ -395,11 +430,14 @@ class _STBlockFn(torch.autograd.Function):
         ws = ctx.ws
         pst = _param_struct(StblockParams, [None if p is None else p.detach() for p in params])
         gst = _param_struct(StblockGrads, grads)
-        L.check(L.dll.stgcn_stblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(),
-                                             saved.data_ptr(), ws.data_ptr(), C.byref(gst),
-                                             None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _optr(ctx.offset_dev),
-                                             _stream_of(x_cl)),
+        ih = ctx.in_hook if dx is not None else None
+        L.check(L.dll.stgcn_stblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(),
+                                                  saved.data_ptr(), ws.data_ptr(), C.byref(gst),
+                                                  None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _optr(ctx.offset_dev),
+                                                  None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
                 "stgcn_stblock_backward")
+        if ih is not None:
+            ih.ready, ih.dx_ptr = True, dx.data_ptr()
         if sink is not None:
             sink.blocks.append((desc, gst, ws, (grads, params)))
             grads = [None] * len(grads)
@@ -541,6 +579,7 @@ class _OutBlockFn(torch.autograd.Function):
         pst = _head_struct(OutblockParams, ps)
         L.check(L.dll.stgcn_outblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), out.data_ptr(), saved.data_ptr(), ws.data_ptr(),
                                              seed, offset, _optr(offset_dev), _stream_of(x_cl)), "stgcn_outblock_forward")
+        ctx.in_hook = _take_ln_hook(x_cl) if need_dx else None
         ctx.save_for_backward(x_cl, saved, *[p for p in params if p is not None])
         ctx.param_present = [p is not None for p in params]
         ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
@@ -572,9 +611,13 @@ class _OutBlockFn(torch.autograd.Function):
         dx = torch.empty_like(x_cl) if ctx.need_dx else None
         pst = _head_struct(OutblockParams, [None if p is None else p.detach() for p in params])
         gst = _head_struct(OutblockGrads, grads)
-        L.check(L.dll.stgcn_outblock_backward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
-                                              ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(), _stream_of(x_cl)),
+        ih = ctx.in_hook if dx is not None else None
+        L.check(L.dll.stgcn_outblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
+                                                   ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
+                                                   None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
                 "stgcn_outblock_backward")
+        if ih is not None:
+            ih.ready, ih.dx_ptr = True, dx.data_ptr()
         if sink is not None:
             sink.head = (desc, gst, ctx.ws, (grads, params))
             grads = [None] * len(grads)

@@ -173,6 +173,7 @@ static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned s
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 
 template <typename T>
 static inline T emu_shfl_from(T v, int src_lane) {

@@ -22,7 +22,8 @@ from tests.helpers import real_gso  # noqa: E402
 
 L = _lib.lib()
 dev = "cuda:0"
-NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd", 7: "tconv_fwd(tc2, v3)"}
+NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd", 7: "tconv_fwd(tc2, v3)",
+         8: "tc2_bwd", 9: "tc2_ln_fwd", 10: "tc1_bwd"}
 
 
 def run_block(c_in, T):
@@ -101,5 +102,5 @@ KIDS = [int(k) for k in os.environ.get("STGCN_PHASE_KIDS", "1,2,3,4,6").split(",
 for kid in KIDS:
     report(kid, "blk1", go1)
 for kid in KIDS:
-    if kid in (1, 3, 4, 6, 7):
+    if kid in (1, 3, 4, 6, 7, 8, 9):
         report(kid, "blk0", go0)
