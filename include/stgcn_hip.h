@@ -132,6 +132,8 @@ typedef struct stgcn_stblock_plan {
     int64_t fused_tc2_bwd;            /* 1: LayerNorm/dropout/gate backward + tmp_conv2 weight gradient + transposed conv run as ONE
                                          launch per block; dZ2 stays on chip (ws_dZ2 is only written under stgcn_set_debug_stages)   */
     int64_t ws_W2dense;               /* [KP2][2*c2] W_eff of tmp_conv2, row major (stationary A operand of that kernel)             */
+    int64_t fused_tc1_bwd;            /* 1: Align + gate backward + tmp_conv1 weight gradient + transposed conv run as ONE launch (needs
+                                         need_dx); dZ1 stays on chip (ws_dZ1 is only written under stgcn_set_debug_stages)           */
 } stgcn_stblock_plan;
 
 int stgcn_version(void);

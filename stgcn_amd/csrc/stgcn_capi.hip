@@ -230,8 +230,11 @@ bool pack_fill_block(PackList& L, const stgcn_stblock_desc* d, const stgcn_stblo
     ok &= L.add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
                 d->Kt * v.NC2 / 16);
     ok &= L.add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
-    if (pl.recompute_tc1)
+    const bool k3s = tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) && (d->Kt * d->c_in > 4);
+    if (pl.recompute_tc1 || k3s)
         ok &= L.add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
+    if (k3s && !pl.thin_tc1)
+        ok &= L.add(PK_ALIGN_DENSE, d->c0 * d->c1, ws + pl.ws_WaDense, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, 0);
     if (pl.fused_tc2_bwd)
         ok &= L.add(PK_TCONV_DENSE, v.KP2 * v.NC2, ws + pl.ws_W2dense, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
     return ok;
@@ -650,7 +653,11 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
         const float* wp = part + w.off;
         add_tconv_at(wp, wp + (long)w.chunks * w.Mpad * w.NC, w.chunks, (long)w.Mpad * w.NC, w.NC, w.NC, Cin, Cout, gw, gb, gaw, gab);
     };
-    if (bg.thin) {   // dW_eff (16 padded rows) and db_eff sit behind dWa | dba in the per-workgroup partials
+    if (bg.k3) {     // per-workgroup partials of tc1_bwd_kernel: dW_eff1 [Kt*c_in][NC1] | db_eff1 [NC1] | dWa [c0][c1] | dba [c1]
+        const float* wp = part + bg.off_k3;
+        add_tconv_at(wp, wp + (long)d->Kt * d->c_in * v.NC1, bg.k3_wgs, bg.k3_stride, bg.k3_stride, v.NC1, d->c_in, d->c0, G->tc1_w, G->tc1_b, G->tc1_aw,
+                     G->tc1_ab);
+    } else if (bg.thin) {   // dW_eff (16 padded rows) and db_eff sit behind dWa | dba in the per-workgroup partials
         const float* wp = part + bg.off_al + (long)d->c0 * 16 + 16;
         L.add(G->tc1_w, wp, bg.al_wgs, bg.al_stride, d->Kt, d->c_in, v.NC1, (long)d->c_in * v.NC1, v.NC1, 1, 1, d->Kt, (long)d->c_in * d->Kt);
         L.add_flat(G->tc1_b, wp + 16 * v.NC1, bg.al_wgs, bg.al_stride, v.NC1);
@@ -664,7 +671,11 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
     } else {
         add_tconv(bg.w2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw, G->tc2_ab);
     }
-    if (d->c0 > d->c1) {
+    if (bg.k3 && d->c0 > d->c1) {
+        const float* ap = part + bg.off_k3 + (long)d->Kt * d->c_in * v.NC1 + v.NC1;
+        L.add(G->al_w, ap, bg.k3_wgs, bg.k3_stride, 1, d->c0, d->c1, 0, d->c1, 1, 0, 1, d->c0);
+        L.add_flat(G->al_b, ap + (long)d->c0 * d->c1, bg.k3_wgs, bg.k3_stride, d->c1);
+    } else if (d->c0 > d->c1) {
         // enumerate (i, j): src dWa[i][j] -> dst al_w[j][i]
         L.add(G->al_w, part + bg.off_al, bg.al_wgs, bg.al_stride, 1, d->c0, d->c1, 0, d->c1, 1, 0, 1, d->c0);
         L.add_flat(G->al_b, part + bg.off_al + (long)d->c0 * d->c1, bg.al_wgs, bg.al_stride, d->c1);
@@ -761,12 +772,14 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2p = take((int64_t)v.NC2 * v.KP2);
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
-    p->ws_W1dense = take(p->recompute_tc1 ? (int64_t)v.KP1 * v.NC1 : 0);
-    const BwdGeom bgq = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
+    const bool k3s = tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) && (d->Kt * d->c_in > 4);
+    p->ws_W1dense = take((p->recompute_tc1 || k3s) ? (int64_t)v.KP1 * v.NC1 : 0);
+    const BwdGeom bgq = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
     p->thin_tc1 = bgq.thin;
     p->fused_tc2_bwd = bgq.k1;
     p->ws_W2dense = take(bgq.k1 ? (int64_t)v.KP2 * v.NC2 : 0);
-    p->ws_WaDense = take(p->thin_tc1 ? (int64_t)d->c0 * d->c1 : 0);
+    p->ws_WaDense = take((p->thin_tc1 || k3s) ? (int64_t)d->c0 * d->c1 : 0);
+    p->fused_tc1_bwd = bgq.k3;
     p->ws_rowstat_b = take(2 * v.rows2 + 2 * v.slabs2);   // row partials, then the per-slab constants (big slabs only)
     p->ws_dZ2 = take(v.rows2 * v.NC2);
     p->ws_dYg = take(v.rows1 * d->c1);
@@ -775,7 +788,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->tiled_gc = v.tiled;
     p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
     p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
-    p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms);
+    p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;
     return STGCN_OK;

@@ -20,7 +20,8 @@ namespace stgcn {
 // one launch).  Default: everything on; 0 reproduces the round-1 launch sequence (A/B runs, stage tests).
 //                                  2 = tc2_ln_fwd_kernel (tmp_conv2 + gate + LayerNorm + dropout of one slab per workgroup).
 //                                  4 = LayerNorm-backward row partials in the epilogue of the kernel that produces dy (stgcn_ln_hook).
-enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4 };
+//                                  8 = tc1_bwd_kernel (Align + gate backward + tmp_conv1 weight gradient + transposed conv in one launch).
+enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4, FUSE_TC1_BWD = 8 };
 inline int fuse_mask() {
     static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
     return m;
@@ -29,6 +30,19 @@ inline int fuse_mask() {
 inline int g_debug_stages = 0;
 inline bool tc2_ln_fwd_fused_ok(int c1, int c2, int Kt, int N) {
     return (fuse_mask() & FUSE_TC2_LN_FWD) && c1 == 16 && c2 == 64 && Kt >= 2 && Kt <= 4 && N <= 448 && tc2_ln_fwd_lds_bytes(Kt, N) <= 150 * 1024;
+}
+// shapes tc1_bwd_kernel covers (whether a call uses it also depends on need_dx: the kernel always forms the input gradient)
+inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
+    return (fuse_mask() & FUSE_TC1_BWD) && c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64) &&
+           tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
+}
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
 }
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
     return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && ((c2 == 64 && Kt >= 2 && Kt <= 4) || (c2 == 128 && Kt == 3)) && T1 <= kTsMaxT &&
@@ -82,6 +96,9 @@ struct BwdGeom {
     int node_tiles;          // ceil(N / 16)
     int k1_wgs, k1_stride;   // workgroups (B * node_tiles) and floats per workgroup (Kt*16*NC2 + NC2) of its dW_eff2 | db_eff2 partials
     long off_k1;
+    int k3;                  // tmp_conv1 / Align backward fused into tc1_bwd_kernel (needs need_dx): no dZ1, no w1 / align partials
+    int k3_wb, k3_wgs, k3_stride;   // windows per workgroup, workgroups (node_tiles * ceil(B / wb)), floats per workgroup
+    long off_k3;
 };
 
 inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
@@ -105,7 +122,7 @@ inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
     return g;
 }
 
-inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms) {
+inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms, int need_dx) {
     BwdGeom g;
     const int T1 = T - Kt + 1, T2 = T1 - Kt + 1;
     const long rows1 = (long)B * T1 * N, rows2 = (long)B * T2 * N, slabs1 = (long)B * T1, slabs2 = (long)B * T2;
@@ -154,11 +171,18 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.w2 = wgrad_geom(rows2, Kt * c1, 2 * c2, 0);
     g.w2.off = take(g.k1 ? 0 : g.w2.floats);
     g.off_k1 = take(g.k1 ? (long)g.k1_wgs * g.k1_stride : 0);
+    g.k3 = (need_dx && !g.thin && tc1_bwd_shape_ok(c_in, c0, c1, Kt)) ? 1 : 0;
+    g.k3_wb = (int)(((long)B * g.node_tiles + device_cus() - 1) / device_cus());   // ~one workgroup per CU, each walking wb windows
+    if (g.k3_wb < 1) g.k3_wb = 1;
+    if (g.k3_wb > B) g.k3_wb = B;
+    g.k3_wgs = g.node_tiles * ((B + g.k3_wb - 1) / g.k3_wb);
+    g.k3_stride = tc1_bwd_part_floats(c0, c_in, Kt);
+    g.off_k3 = take(g.k3 ? (long)g.k3_wgs * g.k3_stride : 0);
     g.total = o;
     return g;
 }
-inline int64_t bwd_partial_floats(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms) {
-    return bwd_geom(B, T, N, c_in, c0, c1, c2, Kt, terms).total;
+inline int64_t bwd_partial_floats(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms, int need_dx) {
+    return bwd_geom(B, T, N, c_in, c0, c1, c2, Kt, terms, need_dx).total;
 }
 
 // ================================================================================================

@@ -14,6 +14,7 @@
 #pragma once
 #include <type_traits>
 #include "stgcn_device.hip.h"
+#include "stgcn_kernels_fwd.hip.h"
 
 namespace stgcn {
 
@@ -302,6 +303,304 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 for (int rr = 0; rr < 4; ++rr) part[(size_t)(k * 16 + 4 * g + rr) * NC + (w * NTW + j) * 16 + l15] = accw[k][j][rr];
         __syncthreads();       // (D)
         __syncthreads();       // (E)
+    }
+}
+
+// ================================================================================================
+// K3: backward of  tmp_conv1 -> Align(c0 -> c1)  (layers.py:252, :223) for `wb` windows x one 16-node tile per workgroup:
+//     per tile t1:  dA -> dH = dA Wa^T -> gate backward with the saved U1, S1 -> dZ1 tile (LDS ring only)
+//     dW_eff1 += im2col(x)^T dZ1, db_eff1 += sum dZ1, dWa += H^T dA, dba += sum dA              (per-workgroup partials)
+//     dx[t] = sum_tap dZ1[t - tap] W_eff1[tap]^T  (+ the LayerNorm-backward row partials of the layer that produced x, stgcn_ln_hook)
+// replaces align_gate_bwd + tconv_bwd_weight.tc1 + tconv_bwd_data.tc1 (+ ln_bwd_rowstats of the previous block): dZ1, the largest
+// tensor of the backward pass, never leaves the chip and x / U1 / S1 are read once.
+// 12 waves: 4 E waves (VALU: tile production, dx stores, hook epilogue) | 4 Mw waves (weight-gradient MFMAs, 24 accumulator tiles each)
+// | 4 Md waves (transposed conv, the whole W_eff1 slice of their 16 input channels stationary in registers), one barrier per step.
+// grid = node_tiles * ceil(B / wb); a workgroup walks its windows one after the other and keeps accumulating (few, large partials).
+// Template: C0 = 64 (NC = 128), CIN in {16, 32, 64}, KT taps.
+// ================================================================================================
+struct Tc1BwdArgs {
+    const float* dA;          // [B][T1][N][16]
+    const float* U;           // [B][T1][N][C0]   saved gate inputs of tmp_conv1
+    const float* S;
+    const float* x;           // [B][T][N][CIN]
+    const float* WaD;         // [C0][16] dense Align map (PK_ALIGN_DENSE)
+    const float* Wd;          // [KT*CIN][NC] dense W_eff1 (PK_TCONV_DENSE)
+    float* dx;                // [B][T][N][CIN]
+    float* part;              // [wgs][KT*CIN*NC + NC + C0*16 + 16]  dW_eff1 | db_eff1 | dWa | dba
+    LnRowstatOut rs;          // hook: row partials of the LayerNorm in front of x (rs.rowstat == null: none)
+    int B, T, T1, N, node_tiles, wb;
+};
+inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt) {
+    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + 3 * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4) + 16 * C0) * sizeof(float);
+}
+inline int tc1_bwd_part_floats(int C0, int CIN, int Kt) { return Kt * CIN * 2 * C0 + 2 * C0 + C0 * 16 + 16; }
+
+template <int C0, int CIN, int KT, int ACT>
+__global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
+    static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    constexpr int NC = 2 * C0, LDZ = NC + 4, RING = KT + 1, LDX = 20, LDH = C0 + 4, LDO = CIN + 4, MI = CIN / 16, QD = NC / 16;
+    extern __shared__ float stgcn_smem[];
+    float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
+    float* const XT = Zt + RING * 16 * LDZ;            // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row])
+    float* const dAt = XT + RING * CIN * LDX;          // [3][16][16]       dA tiles
+    float* const Ht = dAt + 3 * 16 * 16;               // [2][16][LDH]      H = act(U) * S tiles
+    float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
+    float* const WaL = Xo + 2 * 16 * LDO;              // [16 j][C0]        Align map, transposed: WaL[j][i] = Wa[i][j]
+    const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
+    const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int nt = (int)blockIdx.x % a.node_tiles, bg = (int)blockIdx.x / a.node_tiles, n0 = nt * 16;
+    const int N = a.N, T = a.T, T1 = a.T1;
+    const int b_lo = bg * a.wb, b_hi = (b_lo + a.wb < a.B) ? b_lo + a.wb : a.B;
+    const int r = tid >> 4, cq = tid & 15;             // E role: row r, float4 column cq
+    const bool rv = n0 + r < N;
+    const int rc = rv ? n0 + r : N - 1;
+    float* const part = a.part + (size_t)blockIdx.x * (KT * CIN * NC + NC + C0 * 16 + 16);
+    STGCN_PHASE(10, 0);
+
+    if (role == 0) {
+        // =========================================== E waves ===========================================================
+        {   // Wa[i][j] (dense, row major) -> WaL[j][i]: thread tid moves Wa[tid >> 2][4 (tid & 3) .. + 3]  (visible after barrier (A))
+            const f32x4 v = ld4(a.WaD + (size_t)tid * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) WaL[(4 * (tid & 3) + e) * C0 + (tid >> 2)] = v[e];
+        }
+        f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
+        struct Tile { f32x4 u, s; };
+        for (int b = b_lo; b < b_hi; ++b) {
+            auto fetch = [&](int t1, Tile& t) {
+                const size_t e0 = (((size_t)b * T1 + (t1 < T1 ? t1 : T1 - 1)) * N + rc) * C0 + 4 * cq;
+                t.u = ld4(a.U + e0);
+                t.s = ld4(a.S + e0);
+                if (!rv) t.s = zero4();
+            };
+            // x tile xt (< T) -> registers ; transposed into the ring by put_x
+            auto get_x = [&](int xt) {
+                f32x4 v = zero4();
+                if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
+                return v;
+            };
+            auto put_x = [&](int xt, f32x4 v) {
+                if (cq < CIN / 4) {
+                    float* d = XT + (size_t)(xt % RING) * CIN * LDX + (4 * cq) * LDX + r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e * LDX] = v[e];
+                }
+            };
+            // dA tile t1 -> dAt[t1 % 3] (threads 0..63: row tid >> 2, quad tid & 3), column sums into dba
+            auto get_dA = [&](int t1) {
+                f32x4 v = zero4();
+                if (tid < 64 && t1 < T1 && n0 + (tid >> 2) < N) v = ld4(a.dA + (((size_t)b * T1 + t1) * N + n0 + (tid >> 2)) * 16 + 4 * (tid & 3));
+                return v;
+            };
+            auto put_dA = [&](int t1, f32x4 v) {
+                if (tid < 64) {
+                    st4(dAt + (t1 % 3) * 256 + (tid >> 2) * 16 + 4 * (tid & 3), v);
+                    dba += v;
+                }
+            };
+            // E(t): dH = dA Wa^T (K = 16 on the VALU), gate backward, dZ1 tile -> ring, H tile
+            auto E = [&](int t, const Tile& tl) {
+                const float* da = dAt + (t % 3) * 256 + r * 16;
+                f32x4 dh = zero4();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 d4 = ld4(da + 4 * q);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x4 wv = ld4(WaL + (4 * q + jj) * C0 + 4 * cq);   // Wa[4cq .. 4cq+3][j]: one broadcast 16-byte read per row group
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dh[e] += d4[jj] * wv[e];
+                    }
+                }
+                f32x4 du, dq, h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float du_, dq_;
+                    gate_bwd(dh[i], tl.u[i], tl.s[i], ACT, du_, dq_);
+                    du[i] = du_;
+                    dq[i] = dq_;
+                    h[i] = gate_fwd(tl.u[i], tl.s[i], ACT);
+                }
+                dbu += du;
+                dbq += dq;
+                float* const Zs = Zt + (t % RING) * 16 * LDZ + r * LDZ;
+                st4(Zs + 4 * cq, du);
+                st4(Zs + C0 + 4 * cq, dq);
+                st4(Ht + (t & 1) * 16 * LDH + r * LDH + 4 * cq, h);
+            };
+            // finish output step t: dx tile from LDS -> global (16-byte rows) + hook row partials
+            auto F = [&](int t) {
+                if (cq < CIN / 4) {
+                    const f32x4 v = ld4(Xo + (t & 1) * 16 * LDO + r * LDO + 4 * cq);
+                    if (rv) st4(a.dx + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
+                    if (a.rs.rowstat) {   // uniform
+                        const long slab = (long)b * T + t;
+                        float2 p = rv ? ln_rowstat4(a.rs, v, slab, n0 + r, 4 * cq) : make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int m = CIN / 8; m >= 1; m >>= 1) {
+                            p.x += __shfl_xor(p.x, m);
+                            p.y += __shfl_xor(p.y, m);
+                        }
+                        if (rv && cq == 0) a.rs.rowstat[slab * N + n0 + r] = p;
+                    }
+                } else if (a.rs.rowstat) {   // keep the shuffles of partially used waves convergent (CIN < 64)
+                    float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int m = CIN / 8; m >= 1; m >>= 1) {
+                        p.x += __shfl_xor(p.x, m);
+                        p.y += __shfl_xor(p.y, m);
+                    }
+                }
+            };
+            Tile p0, p1;
+            fetch(0, p0);
+            fetch(1, p1);
+            f32x4 da_n = get_dA(0);
+            f32x4 xs[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) xs[k] = get_x(k);
+            put_dA(0, da_n);
+            da_n = get_dA(1);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) put_x(k, xs[k]);
+            f32x4 x_n = get_x(KT);
+            __syncthreads();   // (A) dA tile 0 visible to every E thread; previous window fully consumed
+            E(0, p0);
+            p0 = p1;
+            fetch(2, p1);
+            put_dA(1, da_n);
+            da_n = get_dA(2);
+            for (int i = 0; i < T; ++i) {
+                __syncthreads();   // (B) tile i (dZ1, H, x, dA) visible to the M waves; dx tile i - 1 visible to the E waves
+                if (i > 0) F(i - 1);
+                if (i + 1 < T1) {
+                    E(i + 1, p0);
+                    p0 = p1;
+                    fetch(i + 3, p1);
+                    put_dA(i + 2, da_n);
+                    da_n = get_dA(i + 3);
+                }
+                put_x(i + KT, x_n);      // (tiles beyond T are zero: nothing reads them)
+                x_n = get_x(i + KT + 1);
+            }
+            __syncthreads();       // (C) last dx tile visible
+            F(T - 1);
+        }
+        STGCN_PHASE(10, 4);
+        // ---- partials of the E role: db_eff1 (16 rows -> lanes 16 apart -> 4 waves through LDS), dba (wave 0) ----------------
+        __syncthreads();           // (D) every role is done with the LDS tiles: Zt becomes the reduction buffer
+        float* bred = Zt;          // [4 waves][NC]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = dbu[i], y = dbq[i];
+            x += __shfl_xor(x, 16); y += __shfl_xor(y, 16);
+            x += __shfl_xor(x, 32); y += __shfl_xor(y, 32);
+            if (g == 0) {
+                bred[w * NC + 4 * l15 + i] = x;
+                bred[w * NC + C0 + 4 * l15 + i] = y;
+            }
+        }
+        {   // dba[j]: threads 0..63 hold (row tid >> 2, quad tid & 3): lanes with equal quad are 4 apart
+            f32x4 v = dba;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x = v[i];
+                x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+                v[i] = x;
+            }
+            if (tid < 4) st4(part + (size_t)KT * CIN * NC + NC + C0 * 16 + 4 * tid, v);
+        }
+        __syncthreads();           // (E)
+        if (tid < NC) part[(size_t)KT * CIN * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
+        STGCN_PHASE(10, 6);
+    } else if (role == 1) {
+        // =========================================== Mw waves: weight gradients ==========================================
+        f32x4 accw[KT * MI][2], acca = zero4();
+#pragma unroll
+        for (int m = 0; m < KT * MI; ++m) {
+            accw[m][0] = zero4();
+            accw[m][1] = zero4();
+        }
+        for (int b = b_lo; b < b_hi; ++b) {
+            __syncthreads();   // (A)
+            for (int i = 0; i < T; ++i) {
+                __syncthreads();   // (B)
+                if (i < T1) {
+                    const float* const Zs = Zt + (i % RING) * 16 * LDZ;
+                    f32x4 bz[2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bz[0][s] = Zs[(4 * g + s) * LDZ + (2 * w) * 16 + l15];
+                        bz[1][s] = Zs[(4 * g + s) * LDZ + (2 * w + 1) * 16 + l15];
+                    }
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const float* xt = XT + (size_t)((i + k) % RING) * CIN * LDX + l15 * LDX + 4 * g;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const f32x4 af = ld4(xt + mi * 16 * LDX);   // A[m = ch][k = row]
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                accw[k * MI + mi][0] = mfma4(af[s], bz[0][s], accw[k * MI + mi][0]);
+                                accw[k * MI + mi][1] = mfma4(af[s], bz[1][s], accw[k * MI + mi][1]);
+                            }
+                        }
+                    }
+                    // dWa[i0 = 16w + ..][j] += H^T dA : A[m = ch][k = row] = Ht[row][16w + l15], B[k = row][n = j] = dA[row][j]
+                    const float* hh = Ht + (i & 1) * 16 * LDH + (4 * g) * LDH + 16 * w + l15;
+                    const float* dd = dAt + (i % 3) * 256 + (4 * g) * 16 + l15;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acca = mfma4(hh[s * LDH], dd[s * 16], acca);
+                }
+            }
+            __syncthreads();       // (C)
+        }
+        STGCN_PHASE(10, 5);
+#pragma unroll
+        for (int m = 0; m < KT * MI; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) part[(size_t)(m * 16 + 4 * g + rr) * NC + (2 * w + j) * 16 + l15] = accw[m][j][rr];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) part[(size_t)KT * CIN * NC + NC + (16 * w + 4 * g + rr) * 16 + l15] = acca[rr];
+        __syncthreads();           // (D)
+        __syncthreads();           // (E)
+    } else {
+        // =========================================== Md waves: transposed conv ===========================================
+        // wave w < MI owns input channels 16w .. 16w+15: A[m = ci][k = o] = W_eff1[(tap, ci)][o], the whole K = KT * NC in registers
+        f32x4 Wr[KT][QD];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int q = 0; q < QD; ++q)
+                Wr[k][q] = w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4();
+        for (int b = b_lo; b < b_hi; ++b) {
+            __syncthreads();   // (A)
+            for (int i = 0; i < T; ++i) {
+                __syncthreads();   // (B)
+                if (w < MI) {
+                    f32x4 accd[2] = {zero4(), zero4()};
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const int ts = i - k;
+                        if (ts >= 0 && ts < T1) {   // uniform
+                            const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + 4 * g;
+#pragma unroll
+                            for (int q = 0; q < QD; ++q) {
+                                const f32x4 z = ld4(zr + 16 * q);   // B[k = o][n = row]
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
+                            }
+                        }
+                    }
+                    st4(Xo + (i & 1) * 16 * LDO + l15 * LDO + 16 * w + 4 * g, accd[0] + accd[1]);   // D[m = ci = 16w + 4g + r][n = row]
+                }
+            }
+            __syncthreads();       // (C)
+        }
+        __syncthreads();           // (D)
+        __syncthreads();           // (E)
     }
 }
 

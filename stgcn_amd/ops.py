@@ -333,17 +333,26 @@ class LnHookState:
         self.hook, self.keep, self.ready, self.dx_ptr = hook, keep, False, None
 
 
-_ln_hooks: "Dict[int, LnHookState]" = {}      # key: data_ptr of a block output (channels-last storage)
+_ln_hooks: "Dict[int, tuple]" = {}      # data_ptr of a block output -> (state, the output tensor itself)
 
 
 def _offer_ln_hook(y: torch.Tensor, state: LnHookState) -> None:
-    if len(_ln_hooks) > 64:                   # outputs nobody consumed through a fused operator (e.g. a block used on its own)
-        _ln_hooks.clear()
-    _ln_hooks[y.data_ptr()] = state
+    # The entry holds a strong reference to y: while it exists the allocator cannot hand y's address to another tensor, so a later
+    # input with this data_ptr IS (a view of) y.  Entries leave when a consumer takes them; outputs nobody consumed through a fused
+    # operator (a block used on its own) are evicted oldest-first, so at most 8 outputs are pinned.
+    while len(_ln_hooks) >= 8:
+        _ln_hooks.pop(next(iter(_ln_hooks)))
+    _ln_hooks[y.data_ptr()] = (state, y)
 
 
 def _take_ln_hook(x_cl: torch.Tensor) -> Optional[LnHookState]:
-    return _ln_hooks.pop(x_cl.data_ptr(), None)
+    e = _ln_hooks.pop(x_cl.data_ptr(), None)
+    if e is None:
+        return None
+    state, y = e
+    if tuple(y.shape) != tuple(x_cl.shape) or y.stride() != x_cl.stride():      # not the whole output (a slice / other view of it)
+        return None
+    return state
 
 
 def _param_struct(cls, tensors):
