@@ -7,10 +7,10 @@ Reference map (hazdzz/STGCN, model/layers.py):
     Align :7-23 | CausalConv2d :40-57 | TemporalConvLayer :59-120 | ChebGraphConv :122-172 |
     GraphConv :174-206 | GraphConvLayer :208-231 | STConvBlock :233-258 | OutputBlock :260-284
 
-The sub-layer modules own the parameters (that is what fixes the checkpoint keys).  Their own
-``forward`` methods are plain tensor expressions kept for API completeness; neither the ST blocks nor the
-output head call them -- ``STConvBlock.forward`` / ``OutputBlock.forward`` hand the parameter pointers to
-``stgcn_stblock_forward`` / ``stgcn_outblock_forward``.
+The sub-layer modules only OWN parameters (that is what fixes the checkpoint keys and the initialisation
+order); they have no arithmetic of their own: ``STConvBlock.forward`` / ``OutputBlock.forward`` hand the
+parameter pointers to ``stgcn_stblock_forward`` / ``stgcn_outblock_forward``, and calling a sub-layer directly
+raises -- there is no eager / ATen path in this package.
 """
 from __future__ import annotations
 
@@ -18,10 +18,14 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 import torch.nn.init as init
 
 from . import ops
+
+
+def _no_eager(name):
+    raise NotImplementedError(f"stgcn_amd.layers.{name} only owns parameters: its arithmetic runs inside the fused HIP operators "
+                              f"(STConvBlock / OutputBlock); there is no eager PyTorch path")
 
 
 class DropoutStream:
@@ -81,11 +85,7 @@ class Align(nn.Module):
         self.align_conv = nn.Conv2d(in_channels=c_in, out_channels=c_out, kernel_size=(1, 1))
 
     def forward(self, x):
-        if self.c_in > self.c_out:
-            return self.align_conv(x)
-        if self.c_in < self.c_out:
-            return F.pad(x, (0, 0, 0, 0, 0, self.c_out - self.c_in))
-        return x
+        _no_eager("Align")
 
 
 class CausalConv2d(nn.Conv2d):
@@ -103,9 +103,7 @@ class CausalConv2d(nn.Conv2d):
         super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=0, dilation=dilation, groups=groups, bias=bias)
 
     def forward(self, input):
-        if self._left is not None:
-            input = F.pad(input, (self._left[1], 0, self._left[0], 0))
-        return super().forward(input)
+        _no_eager("CausalConv2d")
 
 
 class TemporalConvLayer(nn.Module):
@@ -124,18 +122,7 @@ class TemporalConvLayer(nn.Module):
         self.act_func = act_func
 
     def forward(self, x):
-        x_in = self.align(x)[:, :, self.Kt - 1:, :]
-        z = self.causal_conv(x)
-        if self.act_func in ("glu", "gtu"):
-            p, q = z[:, :self.c_out], z[:, -self.c_out:]
-            if self.act_func == "glu":
-                return (p + x_in) * torch.sigmoid(q)
-            return torch.tanh(p + x_in) * torch.sigmoid(q)
-        if self.act_func == "relu":
-            return torch.relu(z + x_in)
-        if self.act_func == "silu":
-            return F.silu(z + x_in)
-        raise NotImplementedError(f"ERROR: The activation function {self.act_func} is not implemented.")
+        _no_eager("TemporalConvLayer")
 
 
 def _init_graph_weight(weight, bias):
@@ -161,16 +148,7 @@ class ChebGraphConv(nn.Module):
         _init_graph_weight(self.weight, self.bias)
 
     def forward(self, x):
-        x = x.permute(0, 2, 3, 1)
-        if self.Ks - 1 < 0:
-            raise ValueError(f"ERROR: the graph convolution kernel size Ks has to be a positive integer, but received {self.Ks}.")
-        terms = [x]
-        if self.Ks >= 2:
-            terms.append(torch.einsum("hi,btij->bthj", self.gso, x))
-        for k in range(2, self.Ks):
-            terms.append(2 * torch.einsum("hi,btij->bthj", self.gso, terms[k - 1]) - terms[k - 2])
-        out = torch.einsum("btkhi,kij->bthj", torch.stack(terms, dim=2), self.weight)
-        return out + self.bias if self.bias is not None else out
+        _no_eager("ChebGraphConv")
 
 
 class GraphConv(nn.Module):
@@ -187,9 +165,7 @@ class GraphConv(nn.Module):
         _init_graph_weight(self.weight, self.bias)
 
     def forward(self, x):
-        x = x.permute(0, 2, 3, 1)
-        out = torch.einsum("bthi,ij->bthj", torch.einsum("hi,btij->bthj", self.gso, x), self.weight)
-        return out + self.bias if self.bias is not None else out
+        _no_eager("GraphConv")
 
 
 class GraphConvLayer(nn.Module):
@@ -208,9 +184,7 @@ class GraphConvLayer(nn.Module):
             self.graph_conv = GraphConv(c_out, c_out, gso, bias)
 
     def forward(self, x):
-        x_in = self.align(x)
-        conv = self.cheb_graph_conv if self.graph_conv_type == "cheb_graph_conv" else self.graph_conv
-        return conv(x_in).permute(0, 3, 1, 2) + x_in
+        _no_eager("GraphConvLayer")
 
 
 class STConvBlock(nn.Module):
@@ -265,8 +239,8 @@ class STConvBlock(nn.Module):
 
 class OutputBlock(nn.Module):
     """'TNFF' head (layers.py:260-284) as one fused HIP operator (fwd) + one (bwd) for the reference's
-    channel plan ([128, 128] -> 1).  Other channel plans are outside what the kernels cover and run the same
-    arithmetic as composed PyTorch-ROCm ops (``_forward_composed``)."""
+    channel plan ([128, 128] -> 1, which main.py:84-92 hard-wires).  Other channel plans are outside what the kernels cover:
+    ``forward`` raises NotImplementedError (there is no eager fallback)."""
 
     def __init__(self, Ko, last_block_channel, channels, end_channel, n_vertex, act_func, bias, droprate):
         super().__init__()
@@ -286,17 +260,10 @@ class OutputBlock(nn.Module):
         return [t.causal_conv.weight, t.causal_conv.bias, t.align.align_conv.weight, t.align.align_conv.bias,
                 self.tc1_ln.weight, self.tc1_ln.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias]
 
-    def _forward_composed(self, x):
-        x = self.tmp_conv1(x)
-        x = self.tc1_ln(x.permute(0, 2, 3, 1))
-        x = self.fc1(x)
-        x = self.relu(x)
-        x = self.dropout(x)
-        return self.fc2(x).permute(0, 3, 1, 2)
-
     def forward(self, x):
         if not ops.head_supported(self.cfg):
-            return self._forward_composed(x)
+            raise NotImplementedError(f"OutputBlock channel plan {self.cfg.channels} -> {self.cfg.end_channel} (c_in {self.cfg.c_in}) is not "
+                                      f"covered by the fused head kernels (supported: [64|128, 128] -> 1)")
         training = self.training and self.cfg.droprate > 0.0
         counter = DropoutStream.counter if training else None
         if counter is not None:

@@ -236,6 +236,10 @@ class GradSink:
         self.by_ptr = {p.data_ptr(): g for p, g in grads.items()}
         self.blocks = []          # (desc, grads struct, ws tensor, keep-alive)
         self.head = None
+        self.owners = []          # WorkspaceCache objects whose buffers hold partials of this (unflushed) step
+
+    def holds(self, wsc) -> bool:
+        return any(o is wsc for o in self.owners)
 
     def grad_for(self, p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return None if p is None else self.by_ptr.get(p.data_ptr())
@@ -252,6 +256,9 @@ class GradSink:
         L.check(L.dll.stgcn_grad_flush(len(self.blocks), arr, hd, hg, hws, opt_table, n_opt, None if hyper is None else C.byref(hyper), stream),
                 "stgcn_grad_flush")
         self.blocks, self.head = [], None
+        for o in self.owners:
+            o.pending_sink = None
+        self.owners = []
 
 
 _sink: Optional[GradSink] = None
@@ -306,6 +313,7 @@ class WorkspaceCache:
     def __init__(self):
         self.bufs: Dict[int, torch.Tensor] = {}
         self.prepacked = False      # one-shot: set by prepack_modules, consumed by the next forward of the owning module
+        self.pending_sink = None    # GradSink holding deferred gradient partials of this module that have not been flushed yet
 
     @property
     def buf(self) -> Optional[torch.Tensor]:
@@ -316,6 +324,11 @@ class WorkspaceCache:
         return p
 
     def get(self, n_floats: int, device) -> torch.Tensor:
+        if self.pending_sink is not None and self.pending_sink.holds(self):
+            # a second forward of the same module (gradient accumulation, a module applied twice) would overwrite the deferred
+            # partials of the first call: silent wrong gradients.  The caller must flush the sink between the two uses.
+            raise RuntimeError("this module's gradient partials are still waiting in an active GradSink: call sink.flush() before the module "
+                               "runs again (one forward/backward per module per flush)")
         b = self.bufs.get(_chain)
         if b is None or b.numel() < n_floats or b.device != device:
             b = self.bufs[_chain] = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
@@ -449,6 +462,8 @@ class _STBlockFn(torch.autograd.Function):
             ih.ready, ih.dx_ptr = True, dx.data_ptr()
         if sink is not None:
             sink.blocks.append((desc, gst, ws, (grads, params)))
+            sink.owners.append(ctx.wsc)
+            ctx.wsc.pending_sink = sink
             grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, None, None, *grads)
 
@@ -592,7 +607,7 @@ class _OutBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x_cl, saved, *[p for p in params if p is not None])
         ctx.param_present = [p is not None for p in params]
         ctx.param_needs_grad = [p is not None and p.requires_grad for p in params]
-        ctx.cfg, ctx.training, ctx.ws, ctx.need_dx = cfg, training, ws, need_dx
+        ctx.cfg, ctx.training, ctx.ws, ctx.need_dx, ctx.wsc = cfg, training, ws, need_dx, wsc
         return out
 
     @staticmethod
@@ -629,6 +644,8 @@ class _OutBlockFn(torch.autograd.Function):
             ih.ready, ih.dx_ptr = True, dx.data_ptr()
         if sink is not None:
             sink.head = (desc, gst, ctx.ws, (grads, params))
+            sink.owners.append(ctx.wsc)
+            ctx.wsc.pending_sink = sink
             grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, *grads)
 

@@ -24,6 +24,7 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.capturable = capturable
         self._dev = {}     # per group: (step tensor, lr tensor) on the device (capturable mode)
+        self.trainer_owns_step = False   # a trainer advances the device step count itself (stgcn_prepack counters): step() must not
 
     def sync_lr(self):
         for gi, group in enumerate(self.param_groups):
@@ -75,6 +76,27 @@ class AdamW(torch.optim.Optimizer):
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
         sink.flush(table, hyper, stream)
 
+    def state_dict(self):
+        """torch's state_dict plus the step counts, which capturable mode keeps in device tensors outside ``state`` (without them a
+        resumed run would restart the bias correction at t = 1: a ~10x too large first update)."""
+        sd = super().state_dict()
+        for gi, g in enumerate(sd["param_groups"]):
+            if gi in self._dev:
+                g["_step"] = int(self._dev[gi][0].item())
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for gi, group in enumerate(self.param_groups):
+            if self.capturable and "_step" in group:
+                live = [p for p in group["params"]]
+                if live and live[0].is_cuda:
+                    dev = live[0].device
+                    if gi not in self._dev:
+                        self._dev[gi] = (torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), float(group["lr"]), device=dev))
+                    self._dev[gi][0].fill_(int(group["_step"]))
+                    self._dev[gi][1].fill_(float(group["lr"]))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -99,7 +121,8 @@ class AdamW(torch.optim.Optimizer):
                 if gi not in self._dev:
                     self._dev[gi] = (torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), float(group["lr"]), device=dev))
                 step_t, lr_t = self._dev[gi]
-                step_t.add_(1)
+                if not self.trainer_owns_step:
+                    step_t.add_(1)
                 step_dev, lr_dev = step_t.data_ptr(), lr_t.data_ptr()
                 step = 0
             else:

@@ -45,6 +45,9 @@ def init_distributed(backend: Optional[str] = None):
                 dist.init_process_group(backend=backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:      # every data-parallel rank draws its own dropout masks (the shards are different windows of one global batch)
+        from .layers import DropoutStream
+        DropoutStream.manual_seed(DropoutStream.seed + rank)
     return rank, local_rank, world
 
 
@@ -95,6 +98,20 @@ def fwd_loss_bwd(model, x, y):
     return loss[0]
 
 
+def fused_tail_supported(model, live_params) -> bool:
+    """The fused step tail (``GradSink`` / ``stgcn_grad_flush``) writes the gradient of every parameter OWNED BY A FUSED OPERATOR
+    (``STConvBlock``, a supported ``OutputBlock``) and nothing else.  A live parameter outside of them (the two ``nn.Linear`` of the
+    Ko == 0 head, models.py:46-51, or any user module around the model) gets its gradient from autograd, which would ACCUMULATE
+    into the never-zeroed arena view installed as ``.grad``: such models take the plain step (zero_grad / backward / step)."""
+    from . import ops
+    from .layers import OutputBlock, STConvBlock
+    owned = set()
+    for m in model.modules():
+        if isinstance(m, STConvBlock) or (isinstance(m, OutputBlock) and ops.head_supported(m.cfg)):
+            owned.update(id(p) for p in m.parameters())
+    return all(id(p) in owned for p in live_params)
+
+
 class GradArena:
     """One flat fp32 buffer holding the gradient of every live parameter (those the model actually uses: the reference
     leaves ``.grad`` None for the 10 idle align convs) in ``model.parameters()`` order, with one view
@@ -125,6 +142,9 @@ def fused_train_step(model, optimizer, x, y, arena: GradArena, world: int = 1, a
     ``all_reduce(arena.flat)`` -> AdamW (world > 1; the 1/world of the gradient mean rides on the loss gradient).
     ``param.grad`` are the arena views (overwritten every step, never accumulated)."""
     from . import ops
+    if not fused_tail_supported(model, arena.params):
+        raise RuntimeError("fused_train_step: the model has live parameters outside the fused operators (see fused_tail_supported); "
+                           "use train_step")
     arena.install()
     with ops.grad_sink_scope(arena.sink):
         y_pred = model(x).reshape(len(x), -1)
@@ -143,12 +163,46 @@ def fused_train_step(model, optimizer, x, y, arena: GradArena, world: int = 1, a
 def train_step(model, optimizer, x, y, allreduce: Optional[FlatGradAllReduce] = None):
     """zero_grad -> forward -> MSELoss -> backward -> [all-reduce] -> optimizer.step (main.py:165-169).
     Returns the loss tensor (no host sync: the reference's per-step .item() at main.py:170 is deferred)."""
+    from .layers import DropoutStream
     optimizer.zero_grad(set_to_none=True)
     loss = fwd_loss_bwd(model, x, y)
     if allreduce is not None:
         allreduce()
     optimizer.step()
+    DropoutStream.advance()      # (device-counter mode only: eager mode consumes a fresh host offset per forward)
     return loss.detach()
+
+
+def tail_step(model, optimizer, x, y, world: int = 1, rank: int = 0):
+    """The partial last minibatch of an epoch (the reference iterates with ``DataLoader(drop_last=False)``, main.py:126-131, so its
+    last step sees n < batch_size windows).  ``x`` / ``y`` are the GLOBAL tail batch (n windows, the same tensors on every rank);
+    rank r takes a contiguous share of ceil(n / world) windows -- possibly none -- and weights its loss gradient by n_local / n, so
+    the SUM all-reduce of the gradients is exactly the gradient of the mean loss over the n windows (``weight by local count``,
+    SURVEY.md section 8e).  Eager launches: a captured step has a fixed batch shape.  Returns the global mean loss (tensor)."""
+    from . import ops
+    n = len(x)
+    per = (n + world - 1) // world
+    lo, hi = min(rank * per, n), min(rank * per + per, n)
+    optimizer.zero_grad(set_to_none=True)
+    dev = x.device
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    if hi > lo:
+        pred = model(x[lo:hi]).reshape(hi - lo, -1)
+        loss, dpred = ops.mse_loss_and_grad(pred, y[lo:hi].contiguous(), grad_scale=(hi - lo) / n)
+        pred.backward(dpred)
+        loss_sum = loss * ((hi - lo) / n)
+    if world > 1:
+        params = [p for p in model.parameters() if p.requires_grad]
+        live = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], device=dev)
+        dist.all_reduce(live, op=dist.ReduceOp.MAX)          # a rank with an empty share has no gradients at all
+        keep = [p for p, l in zip(params, live.tolist()) if l > 0]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in keep])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for p, g in zip(keep, flat.split([p.numel() for p in keep])):
+            p.grad = g.view_as(p).clone()
+        dist.all_reduce(loss_sum, op=dist.ReduceOp.SUM)
+    optimizer.step()
+    return loss_sum[0].detach()
 
 
 def chained_fwd_bwd(model, x, y, chains: int, streams=None):
@@ -228,6 +282,7 @@ class GraphedTrainStep:
         if fused is None:
             fused = os.environ.get("STGCN_FUSED_STEP", "1") != "0"
         # fused step tail (GradArena / GradSink): one-launch loss, one launch for all gradient reductions + AdamW
+        # (decided for good after the first plain step has shown which parameters are live: fused_tail_supported)
         self.fused = bool(fused) and self.chains == 1 and hasattr(optimizer, "flush_with")
         self.arena: Optional[GradArena] = None
         self.streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(self.chains - 1)]
@@ -240,7 +295,11 @@ class GraphedTrainStep:
             from . import ops
             B, N = len(x_example), series.shape[1]
             assert series.is_cuda and series.dtype == torch.float32 and series.is_contiguous() and B > 1
-            num = series.shape[0] - n_his - n_pred + 1                  # windows the series holds (dataloader.py:34-35)
+            num = series.shape[0] - n_his - n_pred                      # windows as the reference counts them (dataloader.py:36)
+            # whole global minibatches only: the reference's DataLoader(drop_last=False) also yields the partial tail batch
+            # (main.py:126-131); a captured step has a fixed batch shape, so the tail (< B * world windows per epoch) is left to
+            # the eager path (``train.tail_step``).  The constructor itself runs `warmup` + 1 REAL optimizer steps (capture needs
+            # warmed-up allocator state): the window position after construction is (warmup + 1) * B * world.
             usable = num // (B * world) * (B * world)
             assert usable > 0, "series shorter than one global minibatch of windows"
             self.x = torch.as_strided(series, (B, 1, n_his, N), (N, n_his * N, N, 1))           # window b = rows [b, b + n_his)
@@ -259,8 +318,12 @@ class GraphedTrainStep:
         self.fold = False       # step counters advanced by the weight-pack launch instead of two tiny launches of their own
         with torch.cuda.stream(side):
             for i in range(max(warmup, 2 if self.fused else 1)):
+                if self.fused and i > 0 and self.arena is None:
+                    live = [p for p in model.parameters() if p.grad is not None]      # the first (plain) step showed them
+                    if not fused_tail_supported(model, live):
+                        self.fused = False
                 if self.fused and i > 0:
-                    if self.arena is None:    # the first (unfused) step showed which parameters receive gradients
+                    if self.arena is None:
                         self.arena = GradArena([p for p in model.parameters() if p.grad is not None])
                         if world == 1:
                             self._try_fold_counters(dev)     # (is itself one fused training step)
@@ -307,6 +370,28 @@ class GraphedTrainStep:
         self(x_example, y_example)
         torch.cuda.synchronize(dev)
 
+    def close(self):
+        """Undo the process-global state a captured step leaves behind (device dropout counter, step counters on the model's pack
+        launch, input-index bindings) so that later EAGER steps on the same model behave like clean eager steps."""
+        from . import ops
+        from .layers import DropoutStream
+        if getattr(self.model, "_step_counters", None) is not None:
+            self.model._step_counters = None
+        if self.series is not None:
+            ops.unbind_input_index(self.x)
+            ops.unbind_input_index(self.y)
+        if DropoutStream.counter is self.counter:
+            DropoutStream.disable_device_counter()
+        if hasattr(self.opt, "trainer_owns_step"):
+            self.opt.trainer_owns_step = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _fwd_bwd(self):
         if self.chains > 1:
             return chained_fwd_bwd(self.model, self.x, self.y, self.chains, self.streams)
@@ -340,6 +425,7 @@ class GraphedTrainStep:
             self.model._step_counters.append(self._index_bump)
         c0, s0 = int(DropoutStream.counter.item()), int(step_t.item())
         self.fold = True
+        self.opt.trainer_owns_step = True       # the pack launch counts the steps: AdamW.step() must not count them again
         self._eager_fused_once()
         if int(DropoutStream.counter.item()) != c0 + DropoutStream.SITE_STRIDE or int(step_t.item()) != s0 + 1:
             self.model._step_counters = None          # the pack launch did not run: advance them the explicit way
@@ -348,6 +434,7 @@ class GraphedTrainStep:
             if i0 is not None:
                 self._index_bump[0].fill_((i0 + self._index_bump[1]) % self._index_bump[2])
             self.fold = False
+            self.opt.trainer_owns_step = False
 
     def _eager_fused_once(self):
         from .layers import DropoutStream

@@ -82,3 +82,36 @@ def test_two_ranks_equal_one_big_batch(tmp_path):
     assert n_live == 28        # 38 tensors, 10 unused align convs never get a gradient
     for k, v in model.state_dict().items():
         assert (got["params"][k] - v).abs().max() <= 2e-6, k
+
+
+def _tail_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from stgcn_amd.train import init_distributed, make_optimizer, tail_step
+    torch.set_num_threads(1)
+    init_distributed("gloo")
+    model = _make()
+    x, y = _data(B=3)                       # the partial last batch: 3 windows for 2 ranks -> shares of 2 and 1
+    opt = make_optimizer(model)
+    loss = tail_step(model, opt, x, y, world=world, rank=rank)
+    if rank == 0:
+        torch.save({"loss": float(loss), "params": {k: v.clone() for k, v in model.state_dict().items()}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tail_batch_weighted_by_local_count(tmp_path):
+    """main.py:126-131 keeps the partial last batch: 2 ranks x (2 + 1 windows), loss gradients weighted by the local count and SUM
+    all-reduced == one process stepping on the 3 windows."""
+    out = str(tmp_path / "t0.pt")
+    mp.spawn(_tail_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    from stgcn_amd.train import make_optimizer, tail_step
+    model = _make()
+    x, y = _data(B=3)
+    opt = make_optimizer(model)
+    loss = tail_step(model, opt, x, y)
+    assert abs(got["loss"] - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+    for k, v in model.state_dict().items():
+        # (AdamW divides every gradient element by its own magnitude: an element whose gradient nearly cancels turns the different
+        #  summation order of the two-rank run into a few 1e-6 of the lr = 1e-3 step)
+        assert (got["params"][k] - v).abs().max() <= 1e-5, k
