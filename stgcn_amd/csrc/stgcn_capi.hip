@@ -295,6 +295,7 @@ int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st
     }
     return STGCN_OK;
 }
+#ifdef STGCN_EXPERIMENTS
 // v3 kernels (time-complete tiles: one workgroup = 16 nodes x all time steps of one window, weights of the whole K in registers)
 template <int WAVES, int NT, int KCW>
 int launch_tconv_fwd3(const char* label, const TconvFwdArgs& a, hipStream_t st) {
@@ -305,6 +306,7 @@ int launch_tconv_fwd3(const char* label, const TconvFwdArgs& a, hipStream_t st) 
     STGCN_LAUNCH(label, st, (tconv_fwd3_kernel<WAVES, NT, KCW, MG>), dim3((unsigned)(B * node_tiles)), dim3(WAVES * 64), lds, a, node_tiles);
     return STGCN_OK;
 }
+#endif
 // v4: 32-row x 256-column tiles with streamed, double-buffered weight rounds (the output head; see tconv_fwd4_kernel)
 inline bool tconv4_ok(const TconvFwdArgs& a) {
     static const int off = getenv("STGCN_TCONV4") ? atoi(getenv("STGCN_TCONV4")) == 0 : 0;   // A/B knob
@@ -325,6 +327,7 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
         aa.f = a;
         return launch_tconv_fwd4<false>(label, aa, st);
     }
+#ifdef STGCN_EXPERIMENTS
     static const int ver = getenv("STGCN_TCONV_V") ? atoi(getenv("STGCN_TCONV_V")) : 1;   // 1: row tiles (fastest at C2); 3: time-complete tiles (opt-in)
     if (ver == 3 && (a.ts.C & 15) == 0 && a.KCH * 16 == a.ts.taps * a.ts.C && a.c1 == 16 * (a.Wap ? 1 : a.c1 / 16) &&
         tconv3_lds_bytes(a.ts.Tsrc, a.ts.C, 2 * a.Cout, 2) <= 64 * 1024) {
@@ -333,6 +336,7 @@ int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
         if (a.Cout == 128 && a.KCH <= 4) return launch_tconv_fwd3<8, 2, 4>(label, a, st);
         if (a.Cout == 128 && a.KCH <= 16) return launch_tconv_fwd3<8, 2, 16>(label, a, st);
     }
+#endif
     return a.Cout == 64 ? launch_tconv_fwd_nt<2>(label, a, st) : launch_tconv_fwd_nt<4>(label, a, st);
 }
 
@@ -511,6 +515,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     const int HT = a.NP / 16;
     int pf = (HT + 3) / 4, pb = 1;
     gc_parts_override(pf, pb);
+#ifdef STGCN_EXPERIMENTS
     {   // operator-stationary variant: the wave's operator fragments in registers, several slabs per workgroup
         static const int per_cu = getenv("STGCN_GC_REG") ? atoi(getenv("STGCN_GC_REG")) : 0;   // opt-in (measured equal / slower at C2 and at bs 128): workgroups per CU
         const int off = per_cu <= 0;
@@ -538,6 +543,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
             return STGCN_OK;
         }
     }
+#endif
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
@@ -589,19 +595,19 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
 
 template <int MTW>
 int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
-    const dim3 grid(w.chunks, w.mchunks), blk(kThreads * kWgradGroups);
-    const bool vec = (a.ts.C & 3) == 0;   // 16-byte im2col loads
-    if (a.NC == 128) {
-        if (vec) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, true>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
-        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, false>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
-    } else {
-        if (vec) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, true>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
-        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, false>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
-    }
+    const dim3 grid(w.chunks, w.mchunks), blk(kThreads * kWgradGroups);   // (16-byte im2col loads: c_in % 4 == 0, checked by the caller)
+    if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, true>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
+    else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, true>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
     return STGCN_OK;
 }
 int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     if (a.NC != 128 && a.NC != 256) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient with %d output channels", a.NC);
+    if ((a.ts.C & 3) != 0) {   // scalar im2col loads: check_desc only admits such inputs with Kt*c_in <= 16, i.e. ONE m-tile
+        if (w.MTW != 1) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient: c_in=%d needs Kt*c_in <= 16", a.ts.C);
+        if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<1, 2, false>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 2), a);
+        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<1, 4, false>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 4), a);
+        return STGCN_OK;
+    }
     switch (w.MTW) {
         case 1: return launch_bwd_weight_n<1>(label, a, w, st);
         case 2: return launch_bwd_weight_n<2>(label, a, w, st);

@@ -639,6 +639,7 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
 
 inline int tconv2_lds_floats(int kp, int nc, int rows) { return rows * ((kp > nc ? kp : nc) + 4); }
 
+#ifdef STGCN_EXPERIMENTS   // round-1 experiment variants (never launched by the default build): -DSTGCN_EXPERIMENTS + STGCN_TCONV_V=3
 // ================================================================================================
 // F1 (v3, "time-complete tiles"): one workgroup owns 16 consecutive nodes of one window b for ALL time steps.
 // The input tile X[b, 0..Tsrc-1, n0..n0+15, :] (Tsrc*16 rows of C floats) is read from HBM exactly once into LDS; the
@@ -822,6 +823,8 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, 
     STGCN_PHASE(a.Wap ? 1 : 7, 7);
 }
 
+
+#endif  // STGCN_EXPERIMENTS
 
 // ================================================================================================
 // LayerNorm-backward row partials in the epilogue of the kernel that PRODUCES the gradient dy of a LayerNorm output
@@ -1164,6 +1167,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     STGCN_PHASE(4, 15);
 }
 
+#ifdef STGCN_EXPERIMENTS   // operator-stationary graph conv (opt-in, STGCN_GC_REG=<workgroups per CU>)
 // ================================================================================================
 // F2 (operator-stationary variant): the fragments of T_1 .. T_{Ks-1} a wave needs for ITS node tile (KCH chunks per term,
 // 1 KiB each: 26 KiB for the 207-node graph, Ks = 3) are loaded into registers ONCE and the workgroup then walks `spw`
@@ -1274,6 +1278,8 @@ __global__ __launch_bounds__(256) void gconv_fwd_reg_kernel(GconvFwdArgs a, int 
         if (slab + 1 < s1) commit(XTn);
     }
 }
+
+#endif  // STGCN_EXPERIMENTS
 
 // ================================================================================================
 // F4: LayerNorm over the joint [N, C] axes of each (b, t) slab (biased variance, eps 1e-12,

@@ -34,7 +34,9 @@ pmc)
         ( cd /tmp && export TMPDIR=/tmp && STGCN_LAUNCH_LOG=$OUT/launch_$C.log timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_${TAG}_$C -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_$C.log 2>&1; echo "pmc $C exit $?" )
         python tools/rocpd_pmc_summary.py /tmp/pmc_${TAG}_$C/pmc_results.db > $OUT/pmc_$C.md 2>&1
     done
-    python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.md $OUT/pmc_WRITE_SIZE.md $OUT/launch_FETCH_SIZE.log > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic.json ;;
+    python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE/pmc_results.db /tmp/pmc_${TAG}_WRITE_SIZE/pmc_results.db $OUT/launch_FETCH_SIZE.log $OUT/launch_WRITE_SIZE.log > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
+    python -c "import sqlite3,sys; db=sqlite3.connect('/tmp/pmc_${TAG}_FETCH_SIZE/pmc_results.db'); print([d[1] for d in db.execute('pragma table_info(counters_collection)')])" > $OUT/pmc_schema.txt 2>&1
+    head -c 1200 $OUT/pmc_traffic.json; cat $OUT/pmc_traffic.err | tail -3 ;;
 side)
     timeout 900 python tools/gpu_side_configs.py ${SIDE_ARGS:-} > $OUT/side_configs.jsonl 2> $OUT/side_configs.err; echo "side exit $?"; cat $OUT/side_configs.jsonl ;;
 *)  # anything else: a script path relative to the repo
