@@ -130,7 +130,8 @@ def test_resident_series_step_equals_explicit_batches():
     from stgcn_amd.train import GraphedTrainStep, make_optimizer, train_step
     n_his, n_pred, B, N = 12, 3, 8, 207
     g = torch.Generator().manual_seed(6)
-    series = torch.randn(5 * B + n_his + n_pred - 1, N, generator=g).to(DEV)         # 5 minibatches of windows, then it wraps
+    series = torch.randn(5 * B + n_his + n_pred, N, generator=g).to(DEV)    # 5 minibatches of windows (num = rows - n_his - n_pred,
+                                                                            # script/dataloader.py:36), then it wraps
 
     def windows(s):
         x = torch.stack([series[s + b:s + b + n_his] for b in range(B)]).unsqueeze(1).contiguous()
