@@ -29,7 +29,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [cxx, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
            "-Wno-unused-value", "-Wno-vla-cxx-extension",
            os.path.join(CSRC, "stgcn_capi.hip"), os.path.join(EMU, "emu_runtime.cpp"), "-o", OUT]
     subprocess.run(cmd, check=True)

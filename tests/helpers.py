@@ -38,6 +38,8 @@ def fixture_gso(name, fx):
     if name == "big600_ks4_f32":
         return synth_gso(600, 7)
     return {"metrla_c2_f32": real_gso("metr_la.cheb_sym_norm_lap"),
+            "metrla_c2_b32_f32": real_gso("metr_la.cheb_sym_norm_lap"),          # BASELINE.json configs[1] at its stated batch size
+            "pemsbay_c3_b64_f32": real_gso("pems_bay.cheb_sym_norm_lap"),        # configs[2] at its stated batch size
             "pemsd7m_c1_f32": real_gso("pemsd7_m.sym_renorm_adj")}[name]
 
 

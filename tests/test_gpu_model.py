@@ -33,7 +33,8 @@ def _model_from_fixture(name, droprate=None):
 
 
 @pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32", "metrla_c2_f32", "pemsd7m_c1_f32",
-                                  "big600_ks4_f32"])      # 600 nodes: tiled graph conv + big-slab LayerNorm backward in the head
+                                  "big600_ks4_f32",      # 600 nodes: tiled graph conv + big-slab LayerNorm backward in the head
+                                  "metrla_c2_b32_f32", "pemsbay_c3_b64_f32"])   # the stated batch sizes of configs[1] / configs[2]
 def test_model_matches_reference_golden(name):
     fx, cfg, model, x, y = _model_from_fixture(name)
     model.eval()

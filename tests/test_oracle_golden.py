@@ -8,7 +8,7 @@ from oracle import stgcn_oracle as orc
 from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture, maxabs
 
 CASES = ["tiny_cheb_f32", "tiny_cheb_f64", "tiny_gc_f32", "tiny_odd_f32", "tiny_ks1_f32", "tiny_ks5_f32",
-         "metrla_c2_f32", "pemsd7m_c1_f32", "big600_ks4_f32"]
+         "metrla_c2_f32", "pemsd7m_c1_f32", "big600_ks4_f32", "metrla_c2_b32_f32", "pemsbay_c3_b64_f32"]
 
 
 def _setup(name):
