@@ -230,7 +230,7 @@ bool pack_fill_block(PackList& L, const stgcn_stblock_desc* d, const stgcn_stblo
     ok &= L.add(PK_TCONV_BWD, d->Kt * v.NC2 * v.CP1, ws + pl.ws_W2d, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt,
                 d->Kt * v.NC2 / 16);
     ok &= L.add(PK_TCONV_BIAS, v.NC2, ws + pl.ws_b2, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
-    const bool k3s = tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) && (d->Kt * d->c_in > 4);
+    const bool k3s = (tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) || tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt)) && (d->Kt * d->c_in > 4);
     if (pl.recompute_tc1 || k3s)
         ok &= L.add(PK_TCONV_DENSE, v.KP1 * v.NC1, ws + pl.ws_W1dense, P->tc1_w, P->tc1_b, P->tc1_aw, P->tc1_ab, d->c_in, d->c0, d->Kt, 0);
     if (k3s && !pl.thin_tc1)
@@ -778,7 +778,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_W2p = take((int64_t)v.NC2 * v.KP2);
     p->ws_W2d = take((int64_t)d->Kt * v.NC2 * v.CP1);
     p->ws_b2 = take(v.NC2);
-    const bool k3s = tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) && (d->Kt * d->c_in > 4);
+    const bool k3s = (tc1_bwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt) || tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt)) && (d->Kt * d->c_in > 4);
     p->ws_W1dense = take((p->recompute_tc1 || k3s) ? (int64_t)v.KP1 * v.NC1 : 0);
     const BwdGeom bgq = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
     p->thin_tc1 = bgq.thin;
@@ -803,6 +803,12 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
 int stgcn_set_debug_stages(int32_t on) {
     const int prev = g_debug_stages;
     if (on == 0 || on == 1) g_debug_stages = on;
+    return prev;
+}
+
+int stgcn_set_tc1_bwd_wgs(int32_t n) {
+    const int prev = g_tc1_bwd_wgs;
+    if (n >= 0) g_tc1_bwd_wgs = n;
     return prev;
 }
 
@@ -912,6 +918,23 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     if (rc) return rc;
 
     // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------
+    if (!pl.recompute_tc1 && !d->x_bstride && !d->x_index_dev && tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt)) {
+        // time-stepping kernel: weights stationary in registers, every input tile read once (stgcn_kernels_tstep.hip.h)
+        Tc1FwdArgs f;
+        memset(&f, 0, sizeof(f));
+        f.x = x; f.Wp = ws + pl.ws_W1p; f.bias = ws + pl.ws_b1; f.WaD = ws + pl.ws_WaDense; f.ba = ws + pl.ws_ba;
+        f.U = saved + pl.sv_U1; f.S = saved + pl.sv_S1; f.A = saved + pl.sv_A;
+        f.B = d->B; f.T = d->T; f.T1 = v.T1; f.N = d->N; f.node_tiles = (d->N + 15) / 16; f.wb = tc1_ts_wb(d->B, d->N);
+        const dim3 grid((unsigned)(f.node_tiles * ((d->B + f.wb - 1) / f.wb))), blk(512);
+        const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
+#define STGCN_TC1_FWD(CIN_)                                                                                   \
+        do {                                                                                                  \
+            if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0>), grid, blk, lds, f);   \
+            else STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1>), grid, blk, lds, f);      \
+        } while (0)
+        if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
+#undef STGCN_TC1_FWD
+    } else
     {
         TconvFwdArgs t1;
         memset(&t1, 0, sizeof(t1));

@@ -21,7 +21,8 @@ namespace stgcn {
 //                                  2 = tc2_ln_fwd_kernel (tmp_conv2 + gate + LayerNorm + dropout of one slab per workgroup).
 //                                  4 = LayerNorm-backward row partials in the epilogue of the kernel that produces dy (stgcn_ln_hook).
 //                                  8 = tc1_bwd_kernel (Align + gate backward + tmp_conv1 weight gradient + transposed conv in one launch).
-enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4, FUSE_TC1_BWD = 8 };
+//                                 16 = tc1_fwd_kernel (time-stepping tmp_conv1 + gate + Align forward, weights stationary).
+enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4, FUSE_TC1_BWD = 8, FUSE_TC1_FWD = 16 };
 inline int fuse_mask() {
     static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
     return m;
@@ -32,10 +33,6 @@ inline bool tc2_ln_fwd_fused_ok(int c1, int c2, int Kt, int N) {
     return (fuse_mask() & FUSE_TC2_LN_FWD) && c1 == 16 && c2 == 64 && Kt >= 2 && Kt <= 4 && N <= 448 && tc2_ln_fwd_lds_bytes(Kt, N) <= 150 * 1024;
 }
 // shapes tc1_bwd_kernel covers (whether a call uses it also depends on need_dx: the kernel always forms the input gradient)
-inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
-    return (fuse_mask() & FUSE_TC1_BWD) && c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64) &&
-           tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
-}
 inline int device_cus() {
     static int cus = 0;
     if (!cus) {
@@ -43,6 +40,21 @@ inline int device_cus() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     return cus;
+}
+// workgroups of tc1_bwd_kernel: 0 = one per CU (but never more than items); a test knob forces small grids so that the ranges of
+// the (item, step) sequence are cut inside items on the emulator too (stgcn_set_tc1_bwd_wgs)
+inline int g_tc1_bwd_wgs = 0;
+inline bool tc1_ts_shape(int c_in, int c0, int c1, int Kt) { return c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64); }
+inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
+    return (fuse_mask() & FUSE_TC1_BWD) && tc1_ts_shape(c_in, c0, c1, Kt) && tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
+}
+inline bool tc1_fwd_shape_ok(int c_in, int c0, int c1, int Kt) { return (fuse_mask() & FUSE_TC1_FWD) && tc1_ts_shape(c_in, c0, c1, Kt); }
+// windows per workgroup of the time-stepping tmp_conv1 kernels: ~one workgroup per CU
+inline int tc1_ts_wb(int B, int N) {
+    const int nt = (N + 15) / 16;
+    int wb = (int)(((long)B * nt + device_cus() - 1) / device_cus());
+    if (wb < 1) wb = 1;
+    return wb > B ? B : wb;
 }
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
     return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && ((c2 == 64 && Kt >= 2 && Kt <= 4) || (c2 == 128 && Kt == 3)) && T1 <= kTsMaxT &&
@@ -172,10 +184,13 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.w2.off = take(g.k1 ? 0 : g.w2.floats);
     g.off_k1 = take(g.k1 ? (long)g.k1_wgs * g.k1_stride : 0);
     g.k3 = (need_dx && !g.thin && tc1_bwd_shape_ok(c_in, c0, c1, Kt)) ? 1 : 0;
-    g.k3_wb = (int)(((long)B * g.node_tiles + device_cus() - 1) / device_cus());   // ~one workgroup per CU, each walking wb windows
-    if (g.k3_wb < 1) g.k3_wb = 1;
-    if (g.k3_wb > B) g.k3_wb = B;
-    g.k3_wgs = g.node_tiles * ((B + g.k3_wb - 1) / g.k3_wb);
+    g.k3_wb = 0;
+    {   // one workgroup per CU walking an equal-weight range of the (window, node tile, output step) sequence
+        const long items = (long)B * g.node_tiles;
+        long wgs = g_tc1_bwd_wgs > 0 ? g_tc1_bwd_wgs : device_cus();
+        if (wgs > items) wgs = items;
+        g.k3_wgs = (int)wgs;
+    }
     g.k3_stride = tc1_bwd_part_floats(c0, c_in, Kt);
     g.off_k3 = take(g.k3 ? (long)g.k3_wgs * g.k3_stride : 0);
     g.total = o;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 }
 
 // ================================================================================================
-// K3: backward of  tmp_conv1 -> Align(c0 -> c1)  (layers.py:252, :223) for `wb` windows x one 16-node tile per workgroup:
+// K3: backward of  tmp_conv1 -> Align(c0 -> c1)  (layers.py:252, :223) on 16-node tiles of one window, walking the time axis:
 //     per tile t1:  dA -> dH = dA Wa^T -> gate backward with the saved U1, S1 -> dZ1 tile (LDS ring only)
 //     dW_eff1 += im2col(x)^T dZ1, db_eff1 += sum dZ1, dWa += H^T dA, dba += sum dA              (per-workgroup partials)
 //     dx[t] = sum_tap dZ1[t - tap] W_eff1[tap]^T  (+ the LayerNorm-backward row partials of the layer that produced x, stgcn_ln_hook)
@@ -315,7 +315,14 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 // tensor of the backward pass, never leaves the chip and x / U1 / S1 are read once.
 // 12 waves: 4 E waves (VALU: tile production, dx stores, hook epilogue) | 4 Mw waves (weight-gradient MFMAs, 24 accumulator tiles each)
 // | 4 Md waves (transposed conv, the whole W_eff1 slice of their 16 input channels stationary in registers), one barrier per step.
-// grid = node_tiles * ceil(B / wb); a workgroup walks its windows one after the other and keeps accumulating (few, large partials).
+//
+// Work distribution: the kernel is MFMA-bound and the path only offers B * ceil(N/16) (window, node tile) items (416 at C2 for 256
+// CUs), so whole items cannot be balanced (two per workgroup on 208 CUs measured 81 % of the chip).  The unit of work is therefore
+// one OUTPUT STEP of one item, weighted by its MFMA count; the linear sequence (item, step) is cut into `gridDim.x` ranges of equal
+// weight and every workgroup walks its range, keeping the weight-gradient accumulators in registers across items.  A range that
+// starts inside an item first re-forms the Kt - 1 dZ1 tiles in front of it (VALU work of the E waves only: no MFMA work is
+// repeated; a tile's weight-gradient contribution belongs to the range that owns output step t1 = tile index).  The cut is a
+// pure function of blockIdx: results are bitwise reproducible.
 // Template: C0 = 64 (NC = 128), CIN in {16, 32, 64}, KT taps.
 // ================================================================================================
 struct Tc1BwdArgs {
@@ -328,12 +335,21 @@ struct Tc1BwdArgs {
     float* dx;                // [B][T][N][CIN]
     float* part;              // [wgs][KT*CIN*NC + NC + C0*16 + 16]  dW_eff1 | db_eff1 | dWa | dba
     LnRowstatOut rs;          // hook: row partials of the LayerNorm in front of x (rs.rowstat == null: none)
-    int B, T, T1, N, node_tiles, wb;
+    int B, T, T1, N, node_tiles;
 };
 inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt) {
-    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + 3 * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4) + 16 * C0) * sizeof(float);
+    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + (size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4) + 16 * C0) * sizeof(float);
 }
 inline int tc1_bwd_part_floats(int C0, int CIN, int Kt) { return Kt * CIN * 2 * C0 + 2 * C0 + C0 * 16 + 16; }
+
+// MFMA weight of output step s of an item = MFMAs one SIMD issues for it (any proportional measure works: it only places the cuts)
+__host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CIN) {
+    int w = 0;
+    if (s < T1) w += KT * (CIN / 16) * 8 + 4;              // weight gradient of tile s: KT*MI m-tiles x 2 n-tiles x 4, + the Align gradient
+    for (int k = 0; k < KT; ++k)
+        if (s - k >= 0 && s - k < T1) w += 32;             // transposed conv: NC / 16 chunks x 4 per tap
+    return w;
+}
 
 template <int C0, int CIN, int KT, int ACT>
 __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
@@ -342,38 +358,74 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
     float* const XT = Zt + RING * 16 * LDZ;            // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row])
-    float* const dAt = XT + RING * CIN * LDX;          // [3][16][16]       dA tiles
-    float* const Ht = dAt + 3 * 16 * 16;               // [2][16][LDH]      H = act(U) * S tiles
+    float* const dAe = XT + RING * CIN * LDX;          // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
+    float* const Ht = dAe + RING * 16 * 16;            // [2][16][LDH]      H = act(U) * S tiles (owned tiles only)
     float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
     float* const WaL = Xo + 2 * 16 * LDO;              // [16 j][C0]        Align map, transposed: WaL[j][i] = Wa[i][j]
     const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const int nt = (int)blockIdx.x % a.node_tiles, bg = (int)blockIdx.x / a.node_tiles, n0 = nt * 16;
     const int N = a.N, T = a.T, T1 = a.T1;
-    const int b_lo = bg * a.wb, b_hi = (b_lo + a.wb < a.B) ? b_lo + a.wb : a.B;
     const int r = tid >> 4, cq = tid & 15;             // E role: row r, float4 column cq
-    const bool rv = n0 + r < N;
-    const int rc = rv ? n0 + r : N - 1;
     float* const part = a.part + (size_t)blockIdx.x * (KT * CIN * NC + NC + C0 * 16 + 16);
     STGCN_PHASE(10, 0);
 
+    // ---- this workgroup's range of the (item, step) sequence: equal MFMA weight per workgroup (identical in every role) -------
+    long Wi = 0;                                       // weight of one item
+    for (int s = 0; s < T; ++s) Wi += tc1_bwd_step_weight(s, T1, KT, CIN);
+    const long items = (long)a.B * a.node_tiles, Wtot = Wi * items;
+    const long w_lo = Wtot * (long)blockIdx.x / (long)gridDim.x, w_hi = Wtot * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    auto unit_at = [&](long pos, long& item, int& step) {   // first unit (item, step) whose start position in the sequence is >= pos
+        item = pos / Wi;
+        const long off = pos - item * Wi;
+        long acc = 0;
+        step = 0;
+        while (step < T && acc < off) {
+            acc += tc1_bwd_step_weight(step, T1, KT, CIN);
+            ++step;
+        }
+        if (step >= T) { ++item; step = 0; }
+    };
+    long item0, item1;
+    int s0, s1;
+    unit_at(w_lo, item0, s0);
+    unit_at(w_hi, item1, s1);
+    if (item1 > items) { item1 = items; s1 = 0; }
+
     if (role == 0) {
         // =========================================== E waves ===========================================================
-        {   // Wa[i][j] (dense, row major) -> WaL[j][i]: thread tid moves Wa[tid >> 2][4 (tid & 3) .. + 3]  (visible after barrier (A))
+        {   // Wa[i][j] (dense, row major) -> WaL[j][i]: thread tid moves Wa[tid >> 2][4 (tid & 3) .. + 3]  (visible after the first barrier)
             const f32x4 v = ld4(a.WaD + (size_t)tid * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) WaL[(4 * (tid & 3) + e) * C0 + (tid >> 2)] = v[e];
         }
         f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
         struct Tile { f32x4 u, s; };
-        for (int b = b_lo; b < b_hi; ++b) {
-            auto fetch = [&](int t1, Tile& t) {
-                const size_t e0 = (((size_t)b * T1 + (t1 < T1 ? t1 : T1 - 1)) * N + rc) * C0 + 4 * cq;
+        STGCN_ACC_DECL();
+        for (long item = item0; item <= item1 && item < items; ++item) {
+            const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
+            if (sb >= se) continue;                    // (uniform over the workgroup: every role evaluates the same list)
+            const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
+            const bool rv = n0 + r < N;
+            const int rc = rv ? n0 + r : N - 1;
+            const int t_lo = sb - KT + 1 > 0 ? sb - KT + 1 : 0;            // first dZ1 tile this range needs
+            const int t_hi = se < T1 ? se : T1;                            // tiles t_lo .. t_hi - 1
+            auto fetch = [&](int t1, Tile& t) __attribute__((always_inline)) {
+                const int tc = t1 < T1 ? t1 : T1 - 1;
+                const size_t e0 = (((size_t)b * T1 + tc) * N + rc) * C0 + 4 * cq;
                 t.u = ld4(a.U + e0);
                 t.s = ld4(a.S + e0);
-                if (!rv) t.s = zero4();
+                if (!rv) t.s = zero4();        // s = 0 makes every product of the gate backward vanish
             };
-            // x tile xt (< T) -> registers ; transposed into the ring by put_x
+            // dA tile t -> registers of 64 threads (row rowq >> 2, quad rowq & 3) -> ring slot t % RING; owned tiles count towards dba
+            auto get_dA = [&](int t, int rowq) __attribute__((always_inline)) {
+                f32x4 v = zero4();
+                if (t < T1 && n0 + (rowq >> 2) < N) v = ld4(a.dA + (((size_t)b * T1 + t) * N + n0 + (rowq >> 2)) * 16 + 4 * (rowq & 3));
+                return v;
+            };
+            auto put_dA = [&](int t, int rowq, f32x4 v) __attribute__((always_inline)) {
+                st4(dAe + (t % RING) * 256 + (rowq >> 2) * 16 + 4 * (rowq & 3), v);
+                if (t >= sb && t < t_hi) dba += v;
+            };
             auto get_x = [&](int xt) {
                 f32x4 v = zero4();
                 if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
@@ -386,25 +438,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     for (int e = 0; e < 4; ++e) d[e * LDX] = v[e];
                 }
             };
-            // dA tile t1 -> dAt[t1 % 3] (threads 0..63: row tid >> 2, quad tid & 3), column sums into dba
-            auto get_dA = [&](int t1) {
-                f32x4 v = zero4();
-                if (tid < 64 && t1 < T1 && n0 + (tid >> 2) < N) v = ld4(a.dA + (((size_t)b * T1 + t1) * N + n0 + (tid >> 2)) * 16 + 4 * (tid & 3));
-                return v;
-            };
-            auto put_dA = [&](int t1, f32x4 v) {
-                if (tid < 64) {
-                    st4(dAt + (t1 % 3) * 256 + (tid >> 2) * 16 + 4 * (tid & 3), v);
-                    dba += v;
-                }
-            };
-            // E(t): dH = dA Wa^T (K = 16 on the VALU), gate backward, dZ1 tile -> ring, H tile
-            auto E = [&](int t, const Tile& tl) {
-                const float* da = dAt + (t % 3) * 256 + r * 16;
+            // E(t): dH = dA Wa^T (K = 16 on the VALU), gate backward, dZ1 tile -> ring; owned tiles (t >= sb) also leave their H and dA
+            // tiles for the Align gradient and count towards the bias partials
+            auto E = [&](int t, const Tile& tl) __attribute__((always_inline)) {
+                const float* da = dAe + (t % RING) * 256 + r * 16;
                 f32x4 dh = zero4();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 d4 = ld4(da + 4 * q);
+                    const f32x4 d4 = ld4(da + 4 * q);      // (broadcast: the 16 threads of a row read the same 16 bytes)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const f32x4 wv = ld4(WaL + (4 * q + jj) * C0 + 4 * cq);   // Wa[4cq .. 4cq+3][j]: one broadcast 16-byte read per row group
@@ -421,29 +462,61 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     dq[i] = dq_;
                     h[i] = gate_fwd(tl.u[i], tl.s[i], ACT);
                 }
-                dbu += du;
-                dbq += dq;
                 float* const Zs = Zt + (t % RING) * 16 * LDZ + r * LDZ;
                 st4(Zs + 4 * cq, du);
                 st4(Zs + C0 + 4 * cq, dq);
-                st4(Ht + (t & 1) * 16 * LDH + r * LDH + 4 * cq, h);
+                if (t >= sb) {                         // uniform
+                    dbu += du;
+                    dbq += dq;
+                    st4(Ht + (t & 1) * 16 * LDH + r * LDH + 4 * cq, h);
+                }
+            };
+            // hook operands of output step t (saved U2 / S2 of the previous block's LayerNorm input, its dropout mask, the slab's mean and
+            // rstd): requested ONE STEP AHEAD of the dx tile they meet -- forming them inside F put two dependent memory round trips on
+            // the E waves' critical path of every step (phase stamps: 7-9 k cycles per step for 6.3 k cycles of MFMAs)
+            struct Hook { f32x4 u, s, k; float mean, rstd; };
+            const bool hk = a.rs.rowstat != nullptr;           // uniform
+            const f32x4 hgam = (hk && cq < CIN / 4) ? ld4(a.rs.gamma + (size_t)rc * CIN + 4 * cq) : zero4();
+            auto hook_fetch = [&](int t, Hook& h) __attribute__((always_inline)) {
+                if (hk && cq < CIN / 4) {
+                    const long slab = (long)b * T + (t < T ? t : T - 1);
+                    const size_t e = ((size_t)slab * N + rc) * CIN + 4 * cq;
+                    h.u = ld4(a.rs.U + e);
+                    h.s = ld4(a.rs.S + e);
+                    h.mean = a.rs.mean[slab];
+                    h.rstd = a.rs.rstd[slab];
+                    h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
+                    if (a.rs.training) {
+                        const uint64_t off = a.rs.offset + (a.rs.offset_dev ? *a.rs.offset_dev : 0);
+                        h.k = dropout_scale4((uint64_t)slab * (((uint64_t)N * CIN) >> 2) + (((uint64_t)rc * CIN + 4 * cq) >> 2), a.rs.seed, off,
+                                             a.rs.thresh, a.rs.keep_scale);
+                    }
+                }
             };
             // finish output step t: dx tile from LDS -> global (16-byte rows) + hook row partials
-            auto F = [&](int t) {
+            auto F = [&](int t, const Hook& h) __attribute__((always_inline)) {
                 if (cq < CIN / 4) {
                     const f32x4 v = ld4(Xo + (t & 1) * 16 * LDO + r * LDO + 4 * cq);
                     if (rv) st4(a.dx + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
-                    if (a.rs.rowstat) {   // uniform
-                        const long slab = (long)b * T + t;
-                        float2 p = rv ? ln_rowstat4(a.rs, v, slab, n0 + r, 4 * cq) : make_float2(0.f, 0.f);
+                    if (hk) {   // uniform
+                        float2 p = make_float2(0.f, 0.f);
+                        if (rv) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float xh = (gate_fwd(h.u[i], h.s[i], a.rs.act) - h.mean) * h.rstd;
+                                const float gg = v[i] * h.k[i] * hgam[i];
+                                p.x += gg;
+                                p.y += gg * xh;
+                            }
+                        }
 #pragma unroll
                         for (int m = CIN / 8; m >= 1; m >>= 1) {
                             p.x += __shfl_xor(p.x, m);
                             p.y += __shfl_xor(p.y, m);
                         }
-                        if (rv && cq == 0) a.rs.rowstat[slab * N + n0 + r] = p;
+                        if (rv && cq == 0) a.rs.rowstat[((long)b * T + t) * N + n0 + r] = p;
                     }
-                } else if (a.rs.rowstat) {   // keep the shuffles of partially used waves convergent (CIN < 64)
+                } else if (hk) {   // keep the shuffles of partially used waves convergent (CIN < 64)
                     float2 p = make_float2(0.f, 0.f);
 #pragma unroll
                     for (int m = CIN / 8; m >= 1; m >>= 1) {
@@ -452,41 +525,57 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     }
                 }
             };
-            Tile p0, p1;
-            fetch(0, p0);
-            fetch(1, p1);
-            f32x4 da_n = get_dA(0);
+            // ---- prologue of the range: tiles t_lo .. min(sb, T1 - 1) and the x tiles of the first weight-gradient step ----------
+            // every tile the range start needs (the Kt - 1 tiles in front of it, tile sb and tile sb + 1) is requested at once, BEFORE the
+            // barrier that frees the ring: fetching them one by one put three dependent memory latencies in front of every range
+            Tile pr[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) fetch(t_lo + k, pr[k]);
             f32x4 xs[KT];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) xs[k] = get_x(k);
-            put_dA(0, da_n);
-            da_n = get_dA(1);
+            for (int k = 0; k < KT; ++k) xs[k] = get_x(sb + k);
+            // dA tiles t_lo .. t_lo + KT: one float4 per thread (wave k stages tile t_lo + k).  The ring is free: every E thread passed
+            // the last two barriers of the previous range after its last read of it
+            put_dA(t_lo + w, lane, get_dA(t_lo + w, lane));
+            __syncthreads();   // (A0) the previous range is fully consumed (ring, H, dA, dx tiles free); WaL and the dA tiles visible
 #pragma unroll
-            for (int k = 0; k < KT; ++k) put_x(k, xs[k]);
-            f32x4 x_n = get_x(KT);
-            __syncthreads();   // (A) dA tile 0 visible to every E thread; previous window fully consumed
-            E(0, p0);
-            p0 = p1;
-            fetch(2, p1);
-            put_dA(1, da_n);
-            da_n = get_dA(2);
-            for (int i = 0; i < T; ++i) {
+            for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);
+            Tile p0;                   // tile min(sb, T1 - 1) + 1: the next one E will need (one of the batch when the range starts early)
+            fetch(t_lo + KT, p0);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int t = t_lo + k;
+                if (t <= sb && t < T1) E(t, pr[k]);                     // uniform
+                else if (t == (sb < T1 ? sb : T1 - 1) + 1) p0 = pr[k];  // uniform
+            }
+            f32x4 x_n = get_x(sb + KT);
+            f32x4 da_n = tid < 64 ? get_dA(t_lo + KT + 1, tid) : zero4();
+            Hook h0;
+            hook_fetch(sb, h0);
+            for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B) tile i (dZ1, H, x, dA) visible to the M waves; dx tile i - 1 visible to the E waves
-                if (i > 0) F(i - 1);
-                if (i + 1 < T1) {
-                    E(i + 1, p0);
-                    p0 = p1;
-                    fetch(i + 3, p1);
-                    put_dA(i + 2, da_n);
-                    da_n = get_dA(i + 3);
+                STGCN_ACC_BEGIN();
+                if (i > sb) {
+                    F(i - 1, h0);
+                    hook_fetch(i, h0);
                 }
-                put_x(i + KT, x_n);      // (tiles beyond T are zero: nothing reads them)
+                if (i + 1 < t_hi) {
+                    E(i + 1, p0);
+                    fetch(i + 2, p0);
+                }
+                if (tid < 64) {          // dA tile i + 2 -> slot (i + 2) % RING (tile i - 2 lived there: last read in step i - 2)
+                    if (i + 2 > t_lo + KT) put_dA(i + 2, tid, da_n);     // (tiles up to t_lo + KT were staged by the prologue)
+                    da_n = get_dA(i + 3, tid);
+                }
+                put_x(i + KT, x_n);      // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1; tiles beyond T are zeros
                 x_n = get_x(i + KT + 1);
+                STGCN_ACC_END();
             }
             __syncthreads();       // (C) last dx tile visible
-            F(T - 1);
+            F(se - 1, h0);
         }
         STGCN_PHASE(10, 4);
+        STGCN_ACC_STORE(10, 8, tid == 0);
         // ---- partials of the E role: db_eff1 (16 rows -> lanes 16 apart -> 4 waves through LDS), dba (wave 0) ----------------
         __syncthreads();           // (D) every role is done with the LDS tiles: Zt becomes the reduction buffer
         float* bred = Zt;          // [4 waves][NC]
@@ -500,7 +589,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                 bred[w * NC + C0 + 4 * l15 + i] = y;
             }
         }
-        {   // dba[j]: threads 0..63 hold (row tid >> 2, quad tid & 3): lanes with equal quad are 4 apart
+        {   // dba[j]: a thread's partial belongs to quad (lane & 3) of some rows: lanes with equal quad are 4 apart, then 4 waves through LDS
             f32x4 v = dba;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -508,10 +597,11 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                 x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
                 v[i] = x;
             }
-            if (tid < 4) st4(part + (size_t)KT * CIN * NC + NC + C0 * 16 + 4 * tid, v);
+            if (lane < 4) st4(bred + 4 * NC + w * 16 + 4 * lane, v);
         }
         __syncthreads();           // (E)
         if (tid < NC) part[(size_t)KT * CIN * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
+        if (tid < 16) part[(size_t)KT * CIN * NC + NC + C0 * 16 + tid] = (bred[4 * NC + tid] + bred[4 * NC + 16 + tid]) + (bred[4 * NC + 32 + tid] + bred[4 * NC + 48 + tid]);
         STGCN_PHASE(10, 6);
     } else if (role == 1) {
         // =========================================== Mw waves: weight gradients ==========================================
@@ -521,10 +611,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             accw[m][0] = zero4();
             accw[m][1] = zero4();
         }
-        for (int b = b_lo; b < b_hi; ++b) {
-            __syncthreads();   // (A)
-            for (int i = 0; i < T; ++i) {
+        STGCN_ACC_DECL();
+        for (long item = item0; item <= item1 && item < items; ++item) {
+            const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
+            if (sb >= se) continue;
+            __syncthreads();   // (A0)
+            for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B)
+                STGCN_ACC_BEGIN();
                 if (i < T1) {
                     const float* const Zs = Zt + (i % RING) * 16 * LDZ;
                     f32x4 bz[2];
@@ -548,14 +642,16 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     }
                     // dWa[i0 = 16w + ..][j] += H^T dA : A[m = ch][k = row] = Ht[row][16w + l15], B[k = row][n = j] = dA[row][j]
                     const float* hh = Ht + (i & 1) * 16 * LDH + (4 * g) * LDH + 16 * w + l15;
-                    const float* dd = dAt + (i % 3) * 256 + (4 * g) * 16 + l15;
+                    const float* dd = dAe + (i % RING) * 256 + (4 * g) * 16 + l15;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acca = mfma4(hh[s * LDH], dd[s * 16], acca);
                 }
+                STGCN_ACC_END();
             }
             __syncthreads();       // (C)
         }
         STGCN_PHASE(10, 5);
+        STGCN_ACC_STORE(10, 9, tid == 0);
 #pragma unroll
         for (int m = 0; m < KT * MI; ++m)
 #pragma unroll
@@ -575,10 +671,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
 #pragma unroll
             for (int q = 0; q < QD; ++q)
                 Wr[k][q] = w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4();
-        for (int b = b_lo; b < b_hi; ++b) {
-            __syncthreads();   // (A)
-            for (int i = 0; i < T; ++i) {
+        STGCN_ACC_DECL();
+        for (long item = item0; item <= item1 && item < items; ++item) {
+            const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
+            if (sb >= se) continue;
+            __syncthreads();   // (A0)
+            for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B)
+                STGCN_ACC_BEGIN();
                 if (w < MI) {
                     f32x4 accd[2] = {zero4(), zero4()};
 #pragma unroll
@@ -596,11 +696,135 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     }
                     st4(Xo + (i & 1) * 16 * LDO + l15 * LDO + 16 * w + 4 * g, accd[0] + accd[1]);   // D[m = ci = 16w + 4g + r][n = row]
                 }
+                STGCN_ACC_END();
             }
             __syncthreads();       // (C)
         }
+        STGCN_ACC_STORE(10, 10, tid == 0);
         __syncthreads();           // (D)
         __syncthreads();           // (E)
+    }
+}
+
+// ================================================================================================
+// F1 (time-stepping): tmp_conv1 + gate + Align(c0 -> c1) forward for `wb` windows x one 16-node tile per workgroup (layers.py:252, :223).
+//   Z^T[o][row] = W_eff1^T[o][K] im2col(x)^T[K][row] per output step: A = the packed weights (PK_TCONV_FWD fragments), the whole
+//   K = Kt * c_in of a wave's two o-tiles (P and Q half of 16 channels) stationary in registers; B = x tiles from an LDS ring (every
+//   input tile is read from memory once and serves Kt output steps).  D leaves a lane with P and Q of 4 channels of one row: bias,
+//   sigmoid, gate and the 16-byte U1 / S1 stores run on registers, and the lane's h values are already in B-operand layout for the
+//   Align product A^T[j][row] += Wa^T[j][i] h^T[i][row] over the wave's own 16 channels (4 MFMAs, no LDS round trip); the four waves'
+//   partial A tiles are summed by the E waves one step later.
+// 8 waves: 4 M waves (MFMA + gate epilogue) | 4 E waves (x tile loads -> ring, A = sum of partials + bias -> memory); one barrier / step.
+// ================================================================================================
+struct Tc1FwdArgs {
+    const float* x;           // [B][T][N][CIN]
+    const float* Wp;          // packed W_eff1 (PK_TCONV_FWD): KCH = Kt*CIN/16 chunks, NC = 2*C0 columns
+    const float* bias;        // b_eff1 [2*C0]
+    const float* WaD;         // [C0][16] dense Align map (PK_ALIGN_DENSE)
+    const float* ba;          // [16] Align bias (PK_ALIGN_BIAS)
+    float* U;                 // [B][T1][N][C0]
+    float* S;
+    float* A;                 // [B][T1][N][16]
+    int B, T, T1, N, node_tiles, wb;
+};
+inline size_t tc1_fwd_lds_bytes(int CIN, int Kt) { return ((size_t)(Kt + 1) * 16 * (CIN + 8) + 2 * 4 * 16 * 20) * sizeof(float); }
+
+template <int C0, int CIN, int KT, int ACT>
+__global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
+    static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    constexpr int RING = KT + 1, LDXS = CIN + 8, CC = CIN / 16, KCH = KT * CC, MT = C0 / 16, RED = 4 * 16 * 20;
+    extern __shared__ float stgcn_smem[];
+    float* const Xs = stgcn_smem;                      // [RING][16][LDXS]  x tiles, row major
+    float* const red = Xs + RING * 16 * LDXS;          // [2][4 waves][16 rows][20]  partial Align tiles, double buffered
+    const bool roleM = threadIdx.x < 256;              // wave-uniform
+    const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int nt = (int)blockIdx.x % a.node_tiles, bg = (int)blockIdx.x / a.node_tiles, n0 = nt * 16;
+    const int N = a.N, T = a.T, T1 = a.T1;
+    const int b_lo = bg * a.wb, b_hi = (b_lo + a.wb < a.B) ? b_lo + a.wb : a.B;
+
+    if (roleM) {
+        // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
+        f32x4 wP[KCH], wQ[KCH];
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            wP[kc] = ld4(a.Wp + ((size_t)(w * KCH + kc) * 64 + lane) * 4);
+            wQ[kc] = ld4(a.Wp + ((size_t)((w + MT) * KCH + kc) * 64 + lane) * 4);
+        }
+        const int c = 16 * w + 4 * g;                  // this lane's 4 channels
+        const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C0 + c);
+        f32x4 waT;                                     // A[m = j = l15][k = i = 16w + 4g + s] = Wa[i][j]
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) waT[sI] = a.WaD[(size_t)(c + sI) * 16 + l15];
+        const bool rowv = n0 + l15 < N;
+        for (int b = b_lo; b < b_hi; ++b) {
+            __syncthreads();   // (A) x tiles 0 .. KT-1 of this window staged
+            for (int i = 0; i < T1; ++i) {
+                __syncthreads();   // (B) x tile i + KT - 1 visible; partial tiles of step i - 1 visible to the E waves
+                f32x4 accP = zero4(), accQ = zero4();
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) {
+                    const int tap = kc / CC, cc = kc % CC;
+                    const f32x4 bf = ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g);   // B[k = ci][n = row]
+#pragma unroll
+                    for (int sI = 0; sI < 4; ++sI) {
+                        accP = mfma4(wP[kc][sI], bf[sI], accP);
+                        accQ = mfma4(wQ[kc][sI], bf[sI], accQ);
+                    }
+                }
+                f32x4 u, sg, h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u[e] = accP[e] + bp[e];
+                    sg[e] = sigmoid_f(accQ[e] + bq[e]);
+                    h[e] = gate_fwd(u[e], sg[e], ACT);
+                }
+                if (rowv) {
+                    const size_t o = (((size_t)b * T1 + i) * N + n0 + l15) * C0 + c;
+                    st4(a.U + o, u);
+                    st4(a.S + o, sg);
+                }
+                f32x4 pa = zero4();                    // this wave's share of A^T[j][row]: its 16 channels of the K = C0 contraction
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) pa = mfma4(waT[sI], h[sI], pa);
+                st4(red + (i & 1) * RED + (w * 16 + l15) * 20 + 4 * g, pa);   // D[m = j = 4g + r][n = row = l15]
+            }
+            __syncthreads();       // (C) last partial tiles visible
+        }
+    } else {
+        // =========================================== E waves ===========================================================
+        const int r = tid >> 4, cq = tid & 15;         // x tiles: row r, float4 column cq (< CIN / 4); A tiles: row r, channel cq
+        const bool rv = n0 + r < N;
+        const float bj = a.ba[cq];
+        for (int b = b_lo; b < b_hi; ++b) {
+            auto get_x = [&](int xt) {
+                f32x4 v = zero4();
+                if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
+                return v;
+            };
+            auto put_x = [&](int xt, f32x4 v) {
+                if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);
+            };
+            auto F = [&](int t) {   // A[t] = sum of the 4 waves' partial tiles + bias
+                const float* rd = red + (t & 1) * RED;
+                const float v = (rd[(0 * 16 + r) * 20 + cq] + rd[(1 * 16 + r) * 20 + cq]) + (rd[(2 * 16 + r) * 20 + cq] + rd[(3 * 16 + r) * 20 + cq]) + bj;
+                if (rv) a.A[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
+            };
+            f32x4 xs[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) xs[k] = get_x(k);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) put_x(k, xs[k]);   // (the previous window's M steps are over: every role passed its barrier (C))
+            f32x4 x_n = get_x(KT);
+            __syncthreads();   // (A)
+            for (int i = 0; i < T1; ++i) {
+                __syncthreads();   // (B)
+                if (i > 0) F(i - 1);
+                put_x(i + KT, x_n);          // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1
+                x_n = get_x(i + KT + 1);
+            }
+            __syncthreads();       // (C)
+            F(T1 - 1);
+        }
     }
 }
 

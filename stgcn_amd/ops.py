@@ -162,6 +162,14 @@ def set_gc_tiled_min_nodes(n: int) -> int:
     return prev
 
 
+def set_tc1_bwd_wgs(n: int) -> int:
+    """Workgroups of the fused tmp_conv1 backward (0 = one per CU); returns the previous value.  Changes workspace plans: set it
+    before the forward of the step it should apply to (test / tuning knob, ``stgcn_set_tc1_bwd_wgs``)."""
+    prev = int(_lib.lib().dll.stgcn_set_tc1_bwd_wgs(int(n)))
+    _plan_cache.clear()
+    return prev
+
+
 def set_gc_ld_pad(pad: int) -> int:
     """Row padding (bf16 elements, multiple of 8) of the 16-bit planes of the tiled graph conv (``stgcn_set_gc_ld_pad``);
     returns the previous value.  Operators and plans made under one setting must be used under the same setting."""

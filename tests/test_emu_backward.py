@@ -92,3 +92,17 @@ def test_block_backward(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
         assert prm.grad is not None, name
         err = np.abs(prm.grad.numpy().astype(np.float64) - ref.reshape(prm.shape)).max()
         assert err < 2e-4 * max(1.0, np.abs(ref).max()), f"{name}: {err}"
+
+
+@pytest.mark.parametrize("wgs", [1, 3, 5])
+def test_tc1_bwd_ranges_cut_inside_items(wgs):
+    """tc1_bwd_kernel hands every workgroup an equal-weight range of the (window, node tile, output step) sequence; with fewer workgroups
+    than items the cuts fall inside items (halo tiles re-formed, weight gradients owned by the range of the tile's output step): same
+    results as one workgroup per item."""
+    bind_emulator()
+    prev = ops.set_tc1_bwd_wgs(wgs)
+    try:
+        test_block_backward(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 6, True)
+        test_block_backward(32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False)
+    finally:
+        ops.set_tc1_bwd_wgs(prev)

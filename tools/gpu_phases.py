@@ -55,9 +55,13 @@ def report(kid, which, go):
     if len(used) == 0:
         print(NAMES[kid], which, "no stamps")
         return
-    t0 = used[used > 0].min()
-    span = used.max() - t0
-    cols = [i for i in range(16) if (used[:, i] != 0).mean() > 0.5]
+    stamps = used[:, :8]                                  # (columns 8.. hold accumulators, not clock values)
+    t0 = stamps[stamps > 0].min()
+    span = stamps.max() - t0
+    cols = [i for i in range(8) if (used[:, i] != 0).mean() > 0.5]
+    busy = [f"acc{i}: {used[:, i].mean():.0f}" for i in range(8, 16) if (used[:, i] != 0).mean() > 0.5]   # role busy-time accumulators
+    if busy:
+        print(f"{NAMES[kid]:18s} {which:6s} busy cycles per role (mean over workgroups): " + "  ".join(busy))
     line = []
     prev = None
     for i in cols:
