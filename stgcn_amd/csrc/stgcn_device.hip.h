@@ -28,12 +28,18 @@ __device__ int stgcn_phase_kid;
             stgcn_phase_buf[blockIdx.x * 16 + (i)] = STGCN_PHASE_CLOCK();                                       \
     } while (0)
 // busy-time accumulators of one role of a wave-specialised kernel (cycles between leaving a barrier and reaching the next one)
-#define STGCN_ACC_DECL() long long stgcn_acc_ = 0, stgcn_t0_ = 0
+#define STGCN_ACC_DECL() long long stgcn_acc_ = 0, stgcn_t0_ = 0, stgcn_acc2_ = 0, stgcn_t2_ = 0
 #define STGCN_ACC_BEGIN() stgcn_t0_ = clock64()
 #define STGCN_ACC_END() stgcn_acc_ += clock64() - stgcn_t0_
+#define STGCN_ACC2_BEGIN() stgcn_t2_ = clock64()
+#define STGCN_ACC2_END() stgcn_acc2_ += clock64() - stgcn_t2_
 #define STGCN_ACC_STORE(kid, i, cond)                                                                           \
     do {                                                                                                        \
         if (stgcn_phase_kid == (kid) && (cond) && blockIdx.x < 4096) stgcn_phase_buf[blockIdx.x * 16 + (i)] = stgcn_acc_; \
+    } while (0)
+#define STGCN_ACC2_STORE(kid, i, cond)                                                                          \
+    do {                                                                                                        \
+        if (stgcn_phase_kid == (kid) && (cond) && blockIdx.x < 4096) stgcn_phase_buf[blockIdx.x * 16 + (i)] = stgcn_acc2_; \
     } while (0)
 #else
 #define STGCN_PHASE(kid, i) ((void)0)
@@ -41,6 +47,9 @@ __device__ int stgcn_phase_kid;
 #define STGCN_ACC_BEGIN() ((void)0)
 #define STGCN_ACC_END() ((void)0)
 #define STGCN_ACC_STORE(kid, i, cond) ((void)0)
+#define STGCN_ACC2_BEGIN() ((void)0)
+#define STGCN_ACC2_END() ((void)0)
+#define STGCN_ACC2_STORE(kid, i, cond) ((void)0)
 #endif
 
 namespace stgcn {

@@ -313,15 +313,15 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 //     dx[t] = sum_tap dZ1[t - tap] W_eff1[tap]^T  (+ the LayerNorm-backward row partials of the layer that produced x, stgcn_ln_hook)
 // replaces align_gate_bwd + tconv_bwd_weight.tc1 + tconv_bwd_data.tc1 (+ ln_bwd_rowstats of the previous block): dZ1, the largest
 // tensor of the backward pass, never leaves the chip and x / U1 / S1 are read once.
-// 12 waves: 4 E waves (VALU: tile production, dx stores, hook epilogue) | 4 Mw waves (weight-gradient MFMAs, 24 accumulator tiles each)
+// 12 waves: 4 E waves (tile production: dH as 4 small MFMAs, gate backward on the VALU, dx stores, hook epilogue) | 4 Mw waves (weight-gradient MFMAs, 24 accumulator tiles each)
 // | 4 Md waves (transposed conv, the whole W_eff1 slice of their 16 input channels stationary in registers), one barrier per step.
 //
 // Work distribution: the kernel is MFMA-bound and the path only offers B * ceil(N/16) (window, node tile) items (416 at C2 for 256
 // CUs), so whole items cannot be balanced (two per workgroup on 208 CUs measured 81 % of the chip).  The unit of work is therefore
 // one OUTPUT STEP of one item, weighted by its MFMA count; the linear sequence (item, step) is cut into `gridDim.x` ranges of equal
 // weight and every workgroup walks its range, keeping the weight-gradient accumulators in registers across items.  A range that
-// starts inside an item first re-forms the Kt - 1 dZ1 tiles in front of it (VALU work of the E waves only: no MFMA work is
-// repeated; a tile's weight-gradient contribution belongs to the range that owns output step t1 = tile index).  The cut is a
+// starts inside an item first re-forms the Kt - 1 dZ1 tiles in front of it (work of the E waves only: no conv / weight-gradient
+// MFMA is repeated; a tile's weight-gradient contribution belongs to the range that owns output step t1 = tile index).  The cut is a
 // pure function of blockIdx: results are bitwise reproducible.
 // Template: C0 = 64 (NC = 128), CIN in {16, 32, 64}, KT taps.
 // ================================================================================================
@@ -338,7 +338,7 @@ struct Tc1BwdArgs {
     int B, T, T1, N, node_tiles;
 };
 inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt) {
-    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + (size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4) + 16 * C0) * sizeof(float);
+    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + (size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4)) * sizeof(float);
 }
 inline int tc1_bwd_part_floats(int C0, int CIN, int Kt) { return Kt * CIN * 2 * C0 + 2 * C0 + C0 * 16 + 16; }
 
@@ -361,11 +361,11 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     float* const dAe = XT + RING * CIN * LDX;          // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
     float* const Ht = dAe + RING * 16 * 16;            // [2][16][LDH]      H = act(U) * S tiles (owned tiles only)
     float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
-    float* const WaL = Xo + 2 * 16 * LDO;              // [16 j][C0]        Align map, transposed: WaL[j][i] = Wa[i][j]
     const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int N = a.N, T = a.T, T1 = a.T1;
-    const int r = tid >> 4, cq = tid & 15;             // E role: row r, float4 column cq
+    const int r = tid >> 4, cq = tid & 15;             // E role, x / dx tiles: row r, float4 column cq
+    const int er = l15, ecq = 4 * w + g;               // E role, dZ1 tiles: row er, float4 column ecq (the D layout of the dH product below)
     float* const part = a.part + (size_t)blockIdx.x * (KT * CIN * NC + NC + C0 * 16 + 16);
     STGCN_PHASE(10, 0);
 
@@ -391,13 +391,13 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     unit_at(w_hi, item1, s1);
     if (item1 > items) { item1 = items; s1 = 0; }
 
+    STGCN_PHASE(10, 1);
     if (role == 0) {
         // =========================================== E waves ===========================================================
-        {   // Wa[i][j] (dense, row major) -> WaL[j][i]: thread tid moves Wa[tid >> 2][4 (tid & 3) .. + 3]  (visible after the first barrier)
-            const f32x4 v = ld4(a.WaD + (size_t)tid * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) WaL[(4 * (tid & 3) + e) * C0 + (tid >> 2)] = v[e];
-        }
+        // dH^T[ch][row] = Wa[ch][j] dA^T[j][row] on the matrix cores (4 MFMAs per wave and tile: K = 16): wave w owns channels 16w .. 16w+15,
+        // A[m = ch][k] = Wa[16w + l15][4g + s] stationary in 4 registers, B[k][n = row] = dA[row = l15][4g + s] (one 16-byte LDS read; both
+        // operands use the k order j = 4g + s).  D leaves a lane with channels 16w + 4g .. + 3 of row l15 = its U / S / dZ1 quad.
+        const f32x4 wa = ld4(a.WaD + (size_t)(16 * w + l15) * 16 + 4 * g);
         f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
         struct Tile { f32x4 u, s; };
         STGCN_ACC_DECL();
@@ -405,16 +405,16 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
             if (sb >= se) continue;                    // (uniform over the workgroup: every role evaluates the same list)
             const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
-            const bool rv = n0 + r < N;
-            const int rc = rv ? n0 + r : N - 1;
+            const bool rv = n0 + r < N, erv = n0 + er < N;
+            const int rc = rv ? n0 + r : N - 1, erc = erv ? n0 + er : N - 1;
             const int t_lo = sb - KT + 1 > 0 ? sb - KT + 1 : 0;            // first dZ1 tile this range needs
             const int t_hi = se < T1 ? se : T1;                            // tiles t_lo .. t_hi - 1
             auto fetch = [&](int t1, Tile& t) __attribute__((always_inline)) {
                 const int tc = t1 < T1 ? t1 : T1 - 1;
-                const size_t e0 = (((size_t)b * T1 + tc) * N + rc) * C0 + 4 * cq;
+                const size_t e0 = (((size_t)b * T1 + tc) * N + erc) * C0 + 4 * ecq;
                 t.u = ld4(a.U + e0);
                 t.s = ld4(a.S + e0);
-                if (!rv) t.s = zero4();        // s = 0 makes every product of the gate backward vanish
+                if (!erv) t.s = zero4();        // s = 0 makes every product of the gate backward vanish
             };
             // dA tile t -> registers of 64 threads (row rowq >> 2, quad rowq & 3) -> ring slot t % RING; owned tiles count towards dba
             auto get_dA = [&](int t, int rowq) __attribute__((always_inline)) {
@@ -438,21 +438,13 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     for (int e = 0; e < 4; ++e) d[e * LDX] = v[e];
                 }
             };
-            // E(t): dH = dA Wa^T (K = 16 on the VALU), gate backward, dZ1 tile -> ring; owned tiles (t >= sb) also leave their H and dA
-            // tiles for the Align gradient and count towards the bias partials
+            // E(t): dH = dA Wa^T, gate backward, dZ1 tile -> ring; owned tiles (t >= sb) also leave their H tile for the Align gradient and
+            // count towards the bias partials
             auto E = [&](int t, const Tile& tl) __attribute__((always_inline)) {
-                const float* da = dAe + (t % RING) * 256 + r * 16;
+                const f32x4 d4 = ld4(dAe + (t % RING) * 256 + er * 16 + 4 * g);
                 f32x4 dh = zero4();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 d4 = ld4(da + 4 * q);      // (broadcast: the 16 threads of a row read the same 16 bytes)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const f32x4 wv = ld4(WaL + (4 * q + jj) * C0 + 4 * cq);   // Wa[4cq .. 4cq+3][j]: one broadcast 16-byte read per row group
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dh[e] += d4[jj] * wv[e];
-                    }
-                }
+                for (int s = 0; s < 4; ++s) dh = mfma4(wa[s], d4[s], dh);
                 f32x4 du, dq, h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -462,13 +454,13 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     dq[i] = dq_;
                     h[i] = gate_fwd(tl.u[i], tl.s[i], ACT);
                 }
-                float* const Zs = Zt + (t % RING) * 16 * LDZ + r * LDZ;
-                st4(Zs + 4 * cq, du);
-                st4(Zs + C0 + 4 * cq, dq);
+                float* const Zs = Zt + (t % RING) * 16 * LDZ + er * LDZ;
+                st4(Zs + 4 * ecq, du);
+                st4(Zs + C0 + 4 * ecq, dq);
                 if (t >= sb) {                         // uniform
                     dbu += du;
                     dbq += dq;
-                    st4(Ht + (t & 1) * 16 * LDH + r * LDH + 4 * cq, h);
+                    st4(Ht + (t & 1) * 16 * LDH + er * LDH + 4 * ecq, h);
                 }
             };
             // hook operands of output step t (saved U2 / S2 of the previous block's LayerNorm input, its dropout mask, the slab's mean and
@@ -528,6 +520,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             // ---- prologue of the range: tiles t_lo .. min(sb, T1 - 1) and the x tiles of the first weight-gradient step ----------
             // every tile the range start needs (the Kt - 1 tiles in front of it, tile sb and tile sb + 1) is requested at once, BEFORE the
             // barrier that frees the ring: fetching them one by one put three dependent memory latencies in front of every range
+            STGCN_ACC2_BEGIN();
             Tile pr[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) fetch(t_lo + k, pr[k]);
@@ -537,7 +530,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             // dA tiles t_lo .. t_lo + KT: one float4 per thread (wave k stages tile t_lo + k).  The ring is free: every E thread passed
             // the last two barriers of the previous range after its last read of it
             put_dA(t_lo + w, lane, get_dA(t_lo + w, lane));
-            __syncthreads();   // (A0) the previous range is fully consumed (ring, H, dA, dx tiles free); WaL and the dA tiles visible
+            __syncthreads();   // (A0) the previous range is fully consumed (ring, H, dA, dx tiles free); the dA tiles visible
 #pragma unroll
             for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);
             Tile p0;                   // tile min(sb, T1 - 1) + 1: the next one E will need (one of the batch when the range starts early)
@@ -552,6 +545,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             f32x4 da_n = tid < 64 ? get_dA(t_lo + KT + 1, tid) : zero4();
             Hook h0;
             hook_fetch(sb, h0);
+            STGCN_ACC2_END();
             for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B) tile i (dZ1, H, x, dA) visible to the M waves; dx tile i - 1 visible to the E waves
                 STGCN_ACC_BEGIN();
@@ -576,17 +570,21 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         }
         STGCN_PHASE(10, 4);
         STGCN_ACC_STORE(10, 8, tid == 0);
-        // ---- partials of the E role: db_eff1 (16 rows -> lanes 16 apart -> 4 waves through LDS), dba (wave 0) ----------------
+        STGCN_ACC2_STORE(10, 11, tid == 0);
+        // ---- partials of the E role: db_eff1 (a wave owns its 16 channels: the 16 rows are the lanes of a group), dba (4 waves through LDS)
         __syncthreads();           // (D) every role is done with the LDS tiles: Zt becomes the reduction buffer
-        float* bred = Zt;          // [4 waves][NC]
+        float* bred = Zt;          // [NC] db_eff1, then at 4 * NC: [4 waves][16] dba
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float x = dbu[i], y = dbq[i];
-            x += __shfl_xor(x, 16); y += __shfl_xor(y, 16);
-            x += __shfl_xor(x, 32); y += __shfl_xor(y, 32);
-            if (g == 0) {
-                bred[w * NC + 4 * l15 + i] = x;
-                bred[w * NC + C0 + 4 * l15 + i] = y;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                x += __shfl_xor(x, m);
+                y += __shfl_xor(y, m);
+            }
+            if (l15 == 0) {
+                bred[4 * ecq + i] = x;
+                bred[C0 + 4 * ecq + i] = y;
             }
         }
         {   // dba[j]: a thread's partial belongs to quad (lane & 3) of some rows: lanes with equal quad are 4 apart, then 4 waves through LDS
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             if (lane < 4) st4(bred + 4 * NC + w * 16 + 4 * lane, v);
         }
         __syncthreads();           // (E)
-        if (tid < NC) part[(size_t)KT * CIN * NC + tid] = (bred[tid] + bred[NC + tid]) + (bred[2 * NC + tid] + bred[3 * NC + tid]);
+        if (tid < NC) part[(size_t)KT * CIN * NC + tid] = bred[tid];
         if (tid < 16) part[(size_t)KT * CIN * NC + NC + C0 * 16 + tid] = (bred[4 * NC + tid] + bred[4 * NC + 16 + tid]) + (bred[4 * NC + 32 + tid] + bred[4 * NC + 48 + tid]);
         STGCN_PHASE(10, 6);
     } else if (role == 1) {

@@ -2,13 +2,12 @@
 //
 // tests/emu/build_emu.py compiles the *unmodified* product sources in stgcn_amd/csrc/ with the host
 // clang++ and `-I tests/emu` so that this header is found instead of the ROCm one.  Every
-// workgroup is executed as 256 cooperative fibers (ucontext) on one host thread; __syncthreads(),
+// workgroup is executed as 256 cooperative fibers (a minimal x86-64 context switch) on one host thread; __syncthreads(),
 // wave shuffles and the f32 MFMA are emulated as rendezvous points, the MFMA with the documented
 // gfx950 lane->element maps (cdna_hip_programming.md section 3) and an fmaf chain in k order, so index
 // math, fragment layouts, masking and barrier placement of the kernels are exercised on the CPU
 // before any GPU minute is spent.  It is not a performance model and it never ships.
 #pragma once
-#include <ucontext.h>
 
 #include <cmath>
 #include <cstddef>
@@ -16,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <vector>
 
@@ -52,24 +52,32 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 
-typedef void* hipEvent_t;
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+// events are host timestamps (launches run synchronously): the library's per-launch timer then reports emulation time per kernel
+typedef double* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0.0); return 0; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }   // launches run synchronously
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    if (e) *e = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    return 0;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
-static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (a && b) ? (float)(*b - *a) : 0.f; return 0; }
 
 namespace emu {
 constexpr int kWave = 64;
 constexpr size_t kLdsBytes = 160 * 1024;
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;                 // saved stack pointer (emu_switch)
     std::vector<char> stack;
     bool done = false;
     unsigned tid = 0;
+    const unsigned* wait_gen = nullptr; // blocked at a barrier until *wait_gen != wait_val (the scheduler does not resume it before)
+    unsigned wait_val = 0;
 };
 struct WaveState {
     float a[kWave], b[kWave];
@@ -80,8 +88,8 @@ struct WaveState {
 };
 struct State {
     dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
-    ucontext_t main_ctx;
-    std::vector<Fiber> fibers;
+    void* main_sp = nullptr;
+    std::vector<Fiber> fibers;          // pool: only grows; a launch uses the first nthreads
     Fiber* cur = nullptr;
     std::function<void()> body;
     int bar_arrived = 0;
