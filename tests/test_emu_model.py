@@ -29,7 +29,7 @@ def _build(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_cheb_f32", "tiny_gc_f32", "tiny_ks1_f32", "tiny_ks5_f32",
-                                  pytest.param("big600_ks4_f32", marks=pytest.mark.full)])      # 600 nodes: tiled path, ~2 min emulated
+                                  "big600_ks4_f32"])      # 600 nodes: tiled path, ~20 s emulated
 def test_model_matches_reference_golden(name):
     fx, model, x, y = _build(name)
     model.eval()
