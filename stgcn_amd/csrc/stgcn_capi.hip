@@ -316,7 +316,7 @@ inline bool tconv4_ok(const TconvFwdArgs& a) {
 template <bool PLAIN>
 int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {
     constexpr int TM = 2, KC = 4;
-    const size_t lds = (size_t)tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TM) * sizeof(float);
+    const size_t lds = (size_t)(tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TM) + 16) * sizeof(float);   // + 16: reduction words of the fused staging
     STGCN_LAUNCH(label, st, (tconv_fwd4_kernel<TM, KC, PLAIN>), dim3(cdiv(aa.f.ts.rows, 16 * TM)), dim3(512), lds, aa);
     return STGCN_OK;
 }

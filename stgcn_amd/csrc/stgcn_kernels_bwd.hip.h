@@ -22,7 +22,7 @@ namespace stgcn {
 //                                  4 = LayerNorm-backward row partials in the epilogue of the kernel that produces dy (stgcn_ln_hook).
 //                                  8 = tc1_bwd_kernel (Align + gate backward + tmp_conv1 weight gradient + transposed conv in one launch).
 //                                 16 = tc1_fwd_kernel (time-stepping tmp_conv1 + gate + Align forward, weights stationary).
-enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4, FUSE_TC1_BWD = 8, FUSE_TC1_FWD = 16 };
+enum FuseBit { FUSE_TC2_BWD = 1, FUSE_TC2_LN_FWD = 2, FUSE_ROWSTATS = 4, FUSE_TC1_BWD = 8, FUSE_TC1_FWD = 16, FUSE_HEAD_LN_FWD = 32, FUSE_HEAD_LN_BWD = 64 };
 inline int fuse_mask() {
     static const int m = getenv("STGCN_FUSE") ? atoi(getenv("STGCN_FUSE")) : 0x7fffffff;
     return m;

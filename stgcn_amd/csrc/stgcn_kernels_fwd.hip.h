@@ -879,11 +879,28 @@ __device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, f32x4 dy, l
 // PLAIN = true : out[(b*outT + col / outC) * N + n][col % outC] = acc : the head's transposed conv, which for T1 = 1 is
 //                ONE dense GEMM dZ[B*N x NC] @ B[NC x Ko*Cin] (weights packed by PK_TCONV_BWDT) instead of Ko masked taps.
 // ================================================================================================
+// PLAIN with lnb.dy set: the A tile is not read from memory but FORMED in the staging pass -- LayerNorm backward + gate backward of the
+// head (the former ln_gate_bwd launch): dH = rstd * (dy * gamma - c1 - xhat * c2), [dU | dQ] = gate'(dH) with the slab constants c1, c2
+// rebuilt from the row partials of the tile's one or two slabs; the tile also goes to dZ (the conv weight gradient reads it) and the
+// per-element products dy * xhat to dgam[slab] (reduced over the batch by the final reduction; dbeta is reduced from dy itself).
+struct LnGateBwdIn {
+    const float* dy;      // [slabs*N][C]  gradient of the LayerNorm output; null = the tile is read through f.ts as usual
+    const float* U;       // [slabs*N][C]  saved gate inputs
+    const float* S;
+    const float* gamma;   // [N][C]
+    const float* mean;    // [slabs]
+    const float* rstd;
+    const float2* rowstat;   // [slabs*N]  (sum g, sum g * xhat) per row
+    float* dZ;            // [slabs*N][2C]
+    float* dgam;          // [slabs][N][C]
+    int N, C, act;
+};
 struct Tconv4Args {
     TconvFwdArgs f;     // ts, Wp, bias, KCH, Cout (NC = 2*Cout), act, U, S, rowstat (gated) -- H, align fields unused
     float* out;         // PLAIN: destination tensor (B, outT, N, outC)
     int outT, outC;
     LnRowstatOut rs;    // PLAIN: LayerNorm-backward row partials of the layer whose output `out` is the gradient of (rs.rowstat != null)
+    LnGateBwdIn lnb;    // PLAIN: see above
 };
 
 template <int TM, int KC, bool PLAIN>
@@ -905,7 +922,74 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                 w[kc][j] = (kc0 + kc < KCH) ? ld4(a.Wp + ((size_t)((wave + WAVES * j) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
     };
     load_round(wA, 0);
-    stage_tile_fwd<TR, 4, THREADS>(a.ts, row0, KP, At, lda);
+    bool staged = false;
+    if constexpr (PLAIN) {
+        if (aa.lnb.dy) {   // uniform
+            staged = true;
+            const LnGateBwdIn& b = aa.lnb;
+            const int N = b.N, C = b.C, c4n = C >> 2;
+            const float inv_n = 1.0f / ((float)N * (float)C);
+            const long rows = a.ts.rows, rend = row0 + TR < rows ? row0 + TR : rows;
+            float* red = At + TR * lda;   // 16 floats behind the tile
+            for (long slab = row0 / N; slab * N < rend; ++slab) {
+                float x = 0.f, y = 0.f;
+                for (int r = tid; r < N; r += THREADS) {
+                    const float2 v = b.rowstat[slab * N + r];
+                    x += v.x;
+                    y += v.y;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    x += __shfl_xor(x, m);
+                    y += __shfl_xor(y, m);
+                }
+                __syncthreads();   // red free (previous slab)
+                if (lane == 0) {
+                    red[wave] = x;
+                    red[WAVES + wave] = y;
+                }
+                __syncthreads();
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    c1 += red[w];
+                    c2 += red[WAVES + w];
+                }
+                c1 *= inv_n;
+                c2 *= inv_n;
+                const float mean = b.mean[slab], rstd = b.rstd[slab];
+                for (int idx = tid; idx < TR * c4n; idx += THREADS) {
+                    const int row = idx / c4n, c4 = idx - row * c4n;
+                    const long R = row0 + row;
+                    if (R >= rows || R / N != slab) continue;
+                    const int n = (int)(R - slab * N);
+                    const size_t e = (size_t)R * C + 4 * c4;
+                    const f32x4 dy = ld4(b.dy + e), u = ld4(b.U + e), sg = ld4(b.S + e), ga = ld4(b.gamma + (size_t)n * C + 4 * c4);
+                    f32x4 du, dq, dg;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xh = (gate_fwd(u[i], sg[i], b.act) - mean) * rstd;
+                        const float dh = rstd * (dy[i] * ga[i] - c1 - xh * c2);
+                        dg[i] = dy[i] * xh;
+                        float du_, dq_;
+                        gate_bwd(dh, u[i], sg[i], b.act, du_, dq_);
+                        du[i] = du_;
+                        dq[i] = dq_;
+                    }
+                    st4(At + row * lda + 4 * c4, du);
+                    st4(At + row * lda + C + 4 * c4, dq);
+                    st4(b.dZ + (size_t)R * 2 * C + 4 * c4, du);
+                    st4(b.dZ + (size_t)R * 2 * C + C + 4 * c4, dq);
+                    st4(b.dgam + e, dg);
+                }
+            }
+            for (int idx = tid; idx < TR * 2 * c4n; idx += THREADS) {   // rows past the end of the last tile
+                const int row = idx / (2 * c4n), c4 = idx - row * 2 * c4n;
+                if (row0 + row >= rows) st4(At + row * lda + 4 * c4, zero4());
+            }
+        }
+    }
+    if (!staged) stage_tile_fwd<TR, 4, THREADS>(a.ts, row0, KP, At, lda);
     __syncthreads();
 
     f32x4 acc[TM][NT];

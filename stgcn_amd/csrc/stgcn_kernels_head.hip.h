@@ -14,9 +14,13 @@ namespace stgcn {
 //   out = hd @ w2 + b2                        one value per (b, n) row
 // wave w owns output-channel tiles w + 4j (NT = c1 / 64); c1 must be 128 (32 float4 columns per row, one
 // per lane of a half-wave, so the fc2 dot product is a half-wave shuffle reduction).
+// With ln.U set the head's LayerNorm (layers.py:278) runs in the tile staging instead of in its own launch: the rows of a tile belong
+// to one or two (b, t) slabs, whose statistics every workgroup rebuilds from the conv epilogue's row partials (N float2 per slab);
+// yln is still written (the fc1 weight gradient reads it), mean / rstd by the workgroup that holds the slab's first row.
 // ================================================================================================
 struct FcFwdArgs {
     TapSrc ts;            // yln [rows][c0] (taps = 1)
+    LnFwdArgs ln;         // fused LayerNorm: U, S, gamma, beta, rowstat, y (= yln), mean, rstd, N, C, act, eps; ln.U == null: yln is an input
     const float* W1p;     // packed PK_LIN_FWD: K = c0, cols = c1
     const float* b1;      // [c1] or null
     const float* w2;      // [c1]
@@ -41,7 +45,37 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     // every load of the tile is requested up front: the fc1 weight fragments of the whole K (<= 8 chunks), then the rows
     PreW<NT, 8> w;
     pre_load_weights<NT, 8>(w, a.W1p, a.KCH, wave, 4);
-    stage_tile_fwd<TR, 4>(a.ts, row0, KP, At, KP + 4);
+    if (a.ln.U) {
+        const int N = a.ln.N, C = a.ln.C, c4n0 = C >> 2, lda0 = KP + 4;
+        const long rows = a.ts.rows, rend = row0 + TR < rows ? row0 + TR : rows;
+        for (long slab = row0 / N; slab * N < rend; ++slab) {   // (uniform: every thread walks the same slabs)
+            float mean, rstd;
+            slab_stats_from_rows(a.ln.rowstat + (size_t)slab * N, N, C, a.ln.eps, stgcn_smem, mean, rstd);
+            if (slab * N >= row0 && threadIdx.x == 0) {
+                a.ln.mean[slab] = mean;
+                a.ln.rstd[slab] = rstd;
+            }
+            for (int idx = threadIdx.x; idx < TR * c4n0; idx += kThreads) {
+                const int row = idx / c4n0, c4 = idx - row * c4n0;
+                const long R = row0 + row;
+                if (R >= rows || R / N != slab) continue;
+                const int n = (int)(R - slab * N);
+                const f32x4 u = ld4(a.ln.U + (size_t)R * C + 4 * c4), sg = ld4(a.ln.S + (size_t)R * C + 4 * c4);
+                const f32x4 ga = ld4(a.ln.gamma + (size_t)n * C + 4 * c4), be = ld4(a.ln.beta + (size_t)n * C + 4 * c4);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], sg[i], a.ln.act) - mean) * rstd * ga[i] + be[i];
+                st4(At + row * lda0 + 4 * c4, o);
+                st4(a.ln.y + (size_t)R * C + 4 * c4, o);
+            }
+        }
+        for (int idx = threadIdx.x; idx < TR * c4n0; idx += kThreads) {   // rows past the end of the last tile
+            const int row = idx / c4n0, c4 = idx - row * c4n0;
+            if (row0 + row >= rows) st4(At + row * lda0 + 4 * c4, zero4());
+        }
+    } else {
+        stage_tile_fwd<TR, 4>(a.ts, row0, KP, At, KP + 4);
+    }
     __syncthreads();
     f32x4 acc[WM][NT];
 #pragma unroll

@@ -339,7 +339,10 @@ class WorkspaceCache:
                                "runs again (one forward/backward per module per flush)")
         b = self.bufs.get(_chain)
         if b is None or b.numel() < n_floats or b.device != device:
-            b = self.bufs[_chain] = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
+            nb = torch.empty(max(n_floats, 1), dtype=torch.float32, device=device)
+            if b is not None and b.device == device:
+                nb[:b.numel()].copy_(b)     # weights a prepack launch left at the head of the buffer stay valid (offsets do not depend on the size)
+            b = self.bufs[_chain] = nb
         return b
 
 
