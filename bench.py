@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--gc-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="operator products of the tiled graph conv (c5)")
+    ap.add_argument("--gc-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="operator products of the graph conv: tiled path (c5) all modes; slab path (c2, c3) fp32 or bf16x3 (forward only, opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -204,6 +204,8 @@ def main():
     assert L.backend == "hip-gfx950"
     if cfg["N"] > 512:
         ops.set_gc_precision(args.gc_precision)
+    elif args.gc_precision == "bf16x3":
+        ops.set_slab_gc_precision("bf16x3")          # (opt-in: forward operator products of the slab-resident graph conv)
 
     gso_np, gso_src = load_gso(cfg)
     N = gso_np.shape[0]
@@ -289,7 +291,7 @@ def main():
                       "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
                       "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err,
                       "chains": args.chains if use_graph else 1,
-                      "operator_products": args.gc_precision if N > 512 else "fp32",
+                      "operator_products": args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32",
                       "input": (f"device-side windows (n_his 12, n_pred {N_PRED}) of a resident (time, N) series, batch position on the device"
                                 if (resident and use_graph) else "(num, 1, n_his, N) window tensors, one batch copied per step")}}
 

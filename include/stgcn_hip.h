@@ -179,6 +179,12 @@ int stgcn_set_gc_tiled_min_nodes(int32_t n);
  * a mode outside 0..2 only queries.                                                                                     */
 int stgcn_set_gc_precision(int32_t mode);
 
+/* Arithmetic of the operator products T_k(L) X on the slab-resident graph-conv path (graphs up to 512 nodes): 0 = exact fp32 MFMAs,
+ * 1 = "bf16x3" (as above: three bf16 MFMAs per product, ~2^-17 relative per product; the 16 x 16 weight contractions, residual, bias
+ * and ReLU stay fp32).  The operator's bf16 fragment planes are always prepared (stgcn_gso_prepare), so the mode can change between
+ * calls.  Returns the previous mode; a mode outside 0..1 only queries.                                                       */
+int stgcn_set_slab_gc_precision(int32_t mode);
+
 /* Tuning knob: extra bf16 elements (multiple of 8) between consecutive rows of every 16-bit plane of the tiled graph conv
  * (operator hi / lo planes, activation operand form), so that the rows of a tile do not all start in the same L2 channel
  * when NP is a power of two.  Changes the sizes stgcn_gso_layout / stgcn_stblock_plan_query report: set it before preparing

@@ -131,6 +131,8 @@ class _Lib:
         d.stgcn_gso_layout.restype = C.c_int
         d.stgcn_set_gc_tiled_min_nodes.argtypes = [C.c_int32]
         d.stgcn_set_gc_tiled_min_nodes.restype = C.c_int
+        d.stgcn_set_slab_gc_precision.argtypes = [C.c_int32]
+        d.stgcn_set_slab_gc_precision.restype = C.c_int
         d.stgcn_set_tc1_bwd_wgs.argtypes = [C.c_int32]
         d.stgcn_set_tc1_bwd_wgs.restype = C.c_int
         d.stgcn_set_debug_stages.argtypes = [C.c_int32]
@@ -216,4 +218,5 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_profile_collect", "stgcn_outblock_plan_query", "stgcn_outblock_forward", "stgcn_outblock_backward", "stgcn_adamw_step", "stgcn_prepack",
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
-                    "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs"]
+                    "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
+                    "stgcn_set_slab_gc_precision"]

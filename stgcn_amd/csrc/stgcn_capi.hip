@@ -11,6 +11,7 @@
 #include "stgcn_kernels_bwd.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
 #include "stgcn_kernels_gctile.hip.h"
+#include "stgcn_kernels_gcslab16.hip.h"
 #include "stgcn_kernels_head.hip.h"
 
 using namespace stgcn;
@@ -546,8 +547,17 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
 #endif
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
-    const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
+    if (g_slab_gc_precision > 0 && a.Ks > 1 && gs16_np32(a.N) * 2 <= 4 * g.waves * 64) {   // operator products on the bf16 matrix cores (bf16x3)
+        const size_t lds16 = gconv_fwd16_lds_bytes(a.NP, a.N);
+        if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<1, 16>), grid, blk, lds16, a);
+        else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<2, 8>), grid, blk, lds16, a);
+        else if (g.maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<3, 8>), grid, blk, lds16, a);
+        else if (g.maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<4, 8>), grid, blk, lds16, a);
+        else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
+        return STGCN_OK;
+    }
+    const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
     if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, 16>), grid, blk, lds, a);
     else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, 8>), grid, blk, lds, a);
     else if (g.maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, 8>), grid, blk, lds, a);
@@ -830,13 +840,21 @@ int stgcn_set_gc_precision(int32_t mode) {
     return prev;
 }
 
+int stgcn_set_slab_gc_precision(int32_t mode) {
+    const int prev = g_slab_gc_precision;
+    if (mode >= 0 && mode <= 1) g_slab_gc_precision = mode;
+    return prev;
+}
+
 int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64_t* scratch_mats, int32_t* tiled) {
     if (N < 1 || N > 32768 || terms < 1 || terms > 9) return fail(STGCN_ERR_INVALID, "stgcn_gso_layout: bad arguments (1 <= N <= 32768, 1 <= terms <= 9)");
     const bool t = gc_is_tiled(N, terms);
     if (NP) *NP = gc_padded_nodes(N, terms);
     // tiled: fp32 matrix, then its bf16 hi / lo planes with leading dimension gc_plane_ld (NP * LD floats for both)
     const int64_t np = gc_padded_nodes(N, terms);
-    if (mats) *mats = t ? 1 + (gc_plane_ld((int)np) + np - 1) / np : (terms > 1 ? terms - 1 : 1);
+    // slab-resident: the fp32 fragments of T_1 .. T_{terms-1}, then their bf16 hi / lo fragment planes (stgcn_kernels_gcslab16.hip.h)
+    const int64_t m16 = terms > 1 ? ((int64_t)(terms - 1) * (int64_t)gs16_term_floats((int)np, N) + np * np - 1) / (np * np) : 0;
+    if (mats) *mats = t ? 1 + (gc_plane_ld((int)np) + np - 1) / np : (terms > 1 ? terms - 1 + m16 : 1);
     if (scratch_mats) *scratch_mats = t ? 0 : 3;
     if (tiled) *tiled = t ? 1 : 0;
     return STGCN_OK;
@@ -873,6 +891,10 @@ int stgcn_gso_prepare(const float* gso, int32_t N, int32_t terms, float* gso_pad
             tk = out;
         }
         STGCN_LAUNCH("gso_frag", st, gso_frag_kernel, grid, blk, 0, tk, NP, gso_pad + (size_t)(k - 1) * M, gso_t_pad + (size_t)(k - 1) * M);
+        const size_t t16 = gs16_term_floats(NP, N), o16 = (size_t)(terms - 1) * M + (size_t)(k - 1) * t16;
+        const int KC32 = gs16_np32(N) / 32;
+        STGCN_LAUNCH("gso_frag16", st, gso_frag16_kernel, dim3(cdiv((int64_t)(NP / 16) * KC32 * 512, kThreads)), blk, 0, tk, NP, KC32, gso_pad + o16,
+                     gso_t_pad + o16);
     }
     return STGCN_OK;
 }

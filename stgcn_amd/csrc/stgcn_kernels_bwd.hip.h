@@ -69,6 +69,8 @@ inline int g_gc_tiled_min_n = 513;
 // arithmetic of the operator products on the tiled path: 0 = fp32 MFMA (exact fp32, default), 1 = bf16x3 (split operands,
 // fp32-class), 2 = bf16 (stgcn_set_gc_precision; see stgcn_kernels_gctile.hip.h)
 inline int g_gc_precision = 0;
+// operator products of the slab-resident graph conv (N <= 512): 0 exact fp32 MFMAs, 1 bf16x3 (stgcn_kernels_gcslab16.hip.h)
+inline int g_slab_gc_precision = 0;
 inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
 // Leading dimension (bf16 elements) of every 16-bit plane (operator hi / lo, operand form).  NP itself is a power-of-two
 // multiple of 128 for the sizes that matter (8192 nodes: 16 KiB rows), so the 128 rows of a tile would all start in the same

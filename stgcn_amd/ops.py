@@ -152,6 +152,14 @@ def gc_layout_epoch() -> int:
     return _gc_layout_epoch
 
 
+def set_slab_gc_precision(mode) -> str:
+    """Operator products of the slab-resident graph conv (graphs up to 512 nodes): "fp32" (exact fp32 MFMAs) or "bf16x3" (three bf16
+    MFMAs per product, fp32-class results); returns the previous mode."""
+    names = ["fp32", "bf16x3"]
+    m = names.index(mode) if isinstance(mode, str) else int(mode)
+    return names[int(_lib.lib().dll.stgcn_set_slab_gc_precision(m))]
+
+
 def set_gc_tiled_min_nodes(n: int) -> int:
     """Graphs with at least ``n`` nodes use the tiled graph conv (default 513); returns the previous threshold.  Operators
     (``gso_prepare``) and plans made under one setting must be used under the same setting (test / tuning knob)."""
