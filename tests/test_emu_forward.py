@@ -43,7 +43,7 @@ def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
         return f.transpose(0, 3, 1, 2, 4).reshape(NP, NP)
     # T_1 = gso exactly; T_k = 2 gso T_{k-1} - T_{k-2} (fp64 accumulation in the prepare kernel), transposes alongside
     terms = ops.graph_terms(bcfg)
-    assert gp.shape[0] == max(terms - 1, 1)
+    assert gp.shape[0] >= max(terms - 1, 1)      # the fp32 fragments of every term, then their bf16 planes (tests/test_emu_gcslab16.py)
     tm2, tm1 = np.eye(N), gso.astype(np.float64)
     for k in range(1, terms):
         if k >= 2:
