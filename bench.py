@@ -42,6 +42,7 @@ CONFIGS = {
                workload="C5: synthetic dense 8192-node graph, STGCNChebGraphConv Ks=5 Kt=3, n_his=12, bs=16, fp32 storage, tiled graph conv, "
                         "dropout 0.5, AdamW; full step"),
 }
+PMC_TRAFFIC_FILE = "r2w_pmc_traffic.json"          # (named explicitly: it has to be re-measured whenever a kernel's traffic changes)
 B_OVERRIDE = os.environ.get("STGCN_BENCH_B")       # (env: batch-size sweeps of tools/, not the headline)
 
 
@@ -159,17 +160,15 @@ def gpu_baseline(model, gso_t, cfg, B, N, dev):
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by tools/pmc_traffic.py
+    """HBM-side bytes per launch from the committed PMC summary of the current kernels (profiles/PMC_TRAFFIC_FILE, written by tools/pmc_traffic.py
     from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command: counters cannot be sampled from inside
     the process being timed).  Returns ({label: bytes}, file name) or ({}, None)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:
-            rec = json.load(open(path))["per_launch"]
-        except (OSError, ValueError, KeyError):
-            continue
-        return {k: int(v["hbm_bytes"]) for k, v in rec.items()}, os.path.basename(path)
-    return {}, None
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+    try:
+        rec = json.load(open(path))["per_launch"]
+    except (OSError, ValueError, KeyError):
+        return {}, None
+    return {k: int(v["hbm_bytes"]) for k, v in rec.items()}, PMC_TRAFFIC_FILE
 
 
 def main():
