@@ -990,12 +990,16 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
         f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;
         const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N);
-        const dim3 grid((unsigned)v.slabs2), blk(512);
-        const bool small = d->N <= 224;   // 7 row tiles per wave
+        const dim3 grid((unsigned)v.slabs2);
+        // 16 waves (4 tile groups) when the grid leaves room for it: at most ~2 workgroups per CU (measured at C2: 25.8 -> ?? us)
+        static const int hv_force = getenv("STGCN_TC2LN_HV") ? atoi(getenv("STGCN_TC2LN_HV")) : 0;
+        const bool wide = hv_force ? hv_force == 4 : (d->N <= 256 && v.slabs2 <= 2L * device_cus());
+        const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (small) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7>), grid, blk, lds, f);  \
-            else STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14>), grid, blk, lds, f);       \
+            if (wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4>), grid, dim3(1024), lds, f);      \
+            else if (small) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2>), grid, dim3(512), lds, f); \
+            else STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2>), grid, dim3(512), lds, f);           \
         } while (0)
         if (d->Kt == 2) STGCN_TC2LN(2); else if (d->Kt == 3) STGCN_TC2LN(3); else STGCN_TC2LN(4);
 #undef STGCN_TC2LN

@@ -63,6 +63,31 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1) for bulk outputs that the same kernel never reads again.  A plain store
+// leaves its line dirty in the XCD's L2 and the kernel boundary then pays for the write-back (MI355X_MICROARCH.md "boundary": + dirty
+// bytes / 6 TB/s); an sc1 store leaves L2 while the kernel is still computing and costs the same per instruction.  Measured on one box
+// (profiles/r31_wt_store_ab.txt, two alternating runs each): plain 0.4197, epilogue stores write-through 0.4155, in-loop stores as
+// well 0.4132 ms per step -- about 1 %, not the 50 us the dirty-byte rule would predict for 300 MB per step.  The compiler does not count inline-asm memory operations in vmcnt: every later
+// s_waitcnt it places is therefore conservative (it waits for these stores as well), never too short.  STGCN_WT_STORES=0 at build
+// time falls back to plain stores (A/B); the CPU emulator always uses the plain store.
+#ifndef STGCN_WT_STORES
+#define STGCN_WT_STORES 1
+#endif
+__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {
+#if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    st4(p, v);
+#endif
+}
+// the same for stores inside a time-stepping loop, whose wave goes on to wait for later loads (STGCN_WT_STORES >= 2: measured slower)
+__device__ __forceinline__ void st4_wt2(float* p, f32x4 v) {
+#if STGCN_WT_STORES >= 2 && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    st4(p, v);
+#endif
+}
 // 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4, gfx950): lane i of the wave copies its 16 bytes at g to
 // lds_base + 16 * i, where lds_base must be WAVE-UNIFORM (it travels in M0) -- the LDS image of one instruction is always the
 // 1 KiB lane-linear block, any permutation has to be applied to the per-lane source address.  Completion is counted in vmcnt;

@@ -354,11 +354,11 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
             dq[i] = dq_;
         }
         float* z = a.dZ + ((size_t)slab * N + node) * (2 * a.C) + 4 * c4;
-        st4(z, du);
-        st4(z + a.C, dq);
+        st4_wt(z, du);
+        st4_wt(z + a.C, dq);
     }
-    st4(a.dgam_part + (size_t)sg * a.n + 4 * (size_t)q, dg);
-    st4(a.dbet_part + (size_t)sg * a.n + 4 * (size_t)q, db);
+    st4_wt(a.dgam_part + (size_t)sg * a.n + 4 * (size_t)q, dg);
+    st4_wt(a.dbet_part + (size_t)sg * a.n + 4 * (size_t)q, db);
 }
 
 // ================================================================================================
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + (acc1[q][r] + acc2[q][r]) + y[r];
-            st4(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
+            st4_wt(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
         }
     }
 }
@@ -749,8 +749,8 @@ __global__ __launch_bounds__(256) void align_gate_bwd_kernel(AlignBwdArgs a) {
                     dq[i] = dq_;
                     h[i] = gate_fwd(u[i], s[i], a.act);
                 }
-                st4(a.dZ + (size_t)R * 2 * c0 + 4 * c4, du);
-                st4(a.dZ + (size_t)R * 2 * c0 + c0 + 4 * c4, dq);
+                st4_wt(a.dZ + (size_t)R * 2 * c0 + 4 * c4, du);
+                st4_wt(a.dZ + (size_t)R * 2 * c0 + c0 + 4 * c4, dq);
             }
             st4(Ht + row * LDH + 4 * c4, h);
         }
@@ -897,8 +897,8 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
                     h[i] = gate_fwd(u[i], sg, a.act);
                 }
                 if (a.dZ) {
-                    st4(a.dZ + (size_t)R * NC + 4 * c4, du);
-                    st4(a.dZ + (size_t)R * NC + c0 + 4 * c4, dq);
+                    st4_wt(a.dZ + (size_t)R * NC + 4 * c4, du);
+                    st4_wt(a.dZ + (size_t)R * NC + c0 + 4 * c4, dq);
                 }
             }
             st4(Ht + row * LDH + 4 * c4, h);

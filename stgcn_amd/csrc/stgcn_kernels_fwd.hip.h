@@ -499,9 +499,9 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 #else
         if (R < a.ts.rows) {
             const size_t o = (size_t)R * Cout + 4 * c4;
-            if (a.U) st4(a.U + o, u);
-            if (a.S) st4(a.S + o, sg);
-            if (a.H) st4(a.H + o, h);
+            if (a.U) st4_wt(a.U + o, u);
+            if (a.S) st4_wt(a.S + o, sg);
+            if (a.H) st4_wt(a.H + o, h);
         }
 #endif
         if (a.rowstat) {   // per-row LayerNorm partials: the c4n lanes holding one row are contiguous in the wave
@@ -780,9 +780,9 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, 
             }
             if (valid) {
                 const size_t o = R * COUT + 4 * c4;
-                if (a.U) st4(a.U + o, u);
-                if (a.S) st4(a.S + o, sg);
-                if (a.H) st4(a.H + o, h);
+                if (a.U) st4_wt(a.U + o, u);
+                if (a.S) st4_wt(a.S + o, sg);
+                if (a.H) st4_wt(a.H + o, h);
             }
             if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
                 float sr = (h[0] + h[1]) + (h[2] + h[3]);
@@ -978,9 +978,9 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                     }
                     st4(At + row * lda + 4 * c4, du);
                     st4(At + row * lda + C + 4 * c4, dq);
-                    st4(b.dZ + (size_t)R * 2 * C + 4 * c4, du);
-                    st4(b.dZ + (size_t)R * 2 * C + C + 4 * c4, dq);
-                    st4(b.dgam + e, dg);
+                    st4_wt(b.dZ + (size_t)R * 2 * C + 4 * c4, du);
+                    st4_wt(b.dZ + (size_t)R * 2 * C + C + 4 * c4, dq);
+                    st4_wt(b.dgam + e, dg);
                 }
             }
             for (int idx = tid; idx < TR * 2 * c4n; idx += THREADS) {   // rows past the end of the last tile
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             const bool rin = row0 + row < a.ts.rows;
             const RowCoord c = row_advance(a.ts, c0, rin ? row : 0);     // (b, t = 0, n) of the dZ row
             const f32x4 v = ld4(Zt + row * LDZ + 4 * q);
-            if (rin) st4(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
+            if (rin) st4_wt(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
             if (aa.rs.rowstat) {   // uniform; the outC / 4 lanes holding one output row are consecutive and aligned
                 const long slab = (long)c.b * aa.outT + tap;
                 float2 p = rin ? ln_rowstat4(aa.rs, v, slab, c.n, ci) : make_float2(0.f, 0.f);
@@ -1073,9 +1073,9 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             }
             if (R < a.ts.rows) {
                 const size_t o = (size_t)R * COUT + 4 * c4;
-                if (a.U) st4(a.U + o, u);
-                if (a.S) st4(a.S + o, sg);
-                if (a.H) st4(a.H + o, h);
+                if (a.U) st4_wt(a.U + o, u);
+                if (a.S) st4_wt(a.S + o, sg);
+                if (a.H) st4_wt(a.H + o, h);
             }
             if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
                 float sr = (h[0] + h[1]) + (h[2] + h[3]);
@@ -1224,8 +1224,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             if (ht < HT) {
                 const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
                 if (a.Xk && h < N) {
-                    st4(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
-                    if (two) st4(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
+                    st4_wt(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
+                    if (two) st4_wt(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_reg_kernel(GconvFwdArgs a, int 
             }
 #pragma unroll
             for (int k = 0; k < NTERM; ++k) {   // acc[k][r] = X_{k+1}[h][c = 4g + r]
-                if (a.Xk && h < N) st4(a.Xk + (((size_t)k * a.slabs + slab) * N + h) * 16 + 4 * g, acc[k]);
+                if (a.Xk && h < N) st4_wt(a.Xk + (((size_t)k * a.slabs + slab) * N + h) * 16 + 4 * g, acc[k]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) yacc = mfma4(acc[k][s], wf[k + 1][s], yacc);
             }

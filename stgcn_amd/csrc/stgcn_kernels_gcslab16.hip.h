@@ -5,8 +5,10 @@
 // four matrix pipes).  v_mfma_f32_16x16x4_f32 delivers 1/16 of the bf16 rate, so the products are formed as in the tiled path
 // (stgcn_kernels_gctile.hip.h, "bf16x3"): both operands split x = hi + lo into two bf16 and
 //     T X ~= Th Xh + Th Xl + Tl Xh          (3 x v_mfma_f32_16x16x32_bf16, fp32 accumulation)
-// the dropped Tl Xl term and the split residuals are ~2^-17 relative per product: fp32-class results (tests: block outputs within
-// 2e-5 abs of the exact-fp32 kernels, parameter gradients within 1e-4 relative) at 3/16 of the MFMA cycles.
+// the dropped Tl Xl term and the split residuals are ~2^-17 relative per product, at 3/16 of the MFMA cycles.  NOT the default: on the
+// METR-LA operator with unit-variance inputs the block output moves by up to 1.2e-4 abs against the exact-fp32 kernels (X_2 = T_2(L) X0
+// carries ~1e-5 per element into tmp_conv2 and the LayerNorm) -- outside the 1e-4 parity bar of the fp32 configurations
+// (tests/test_emu_gcslab16.py, tests/test_gpu_gcslab16.py).  Only the forward kernel exists in this form (measured: -2.8 us per launch).
 // The 16x16 weight contractions, the residual, bias and ReLU stay in fp32 exactly as in gconv_fwd_kernel / gconv_bwd_kernel.
 //
 // Operator storage (stgcn_gso_prepare, behind the fp32 fragments of every term): per term k two planes (hi, lo) in the A/B fragment
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd16_kernel(GconvFwdArgs a) 
             if (ht < HT) {
                 const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
                 if (a.Xk && h < N) {
-                    st4(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
-                    if (two) st4(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
+                    st4_wt(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
+                    if (two) st4_wt(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], sg[i], a.ln.act) - mean) * rstd * ga[i] + be[i];
                 st4(At + row * lda0 + 4 * c4, o);
-                st4(a.ln.y + (size_t)R * C + 4 * c4, o);
+                st4_wt(a.ln.y + (size_t)R * C + 4 * c4, o);
             }
         }
         for (int idx = threadIdx.x; idx < TR * c4n0; idx += kThreads) {   // rows past the end of the last tile
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) p += __shfl_xor(p, m);   // the 32 lanes of a half-wave hold one row
         if (R < a.ts.rows) {
-            st4(a.hd + (size_t)R * c1 + 4 * c4, h);
+            st4_wt(a.hd + (size_t)R * c1 + 4 * c4, h);
             if (c4 == 0) a.out[R] = p + b2;
         }
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
                     dw2[i] += go * h[i];
                 }
                 if (c4 == 0) db2 += go;
-                st4(a.dh1 + (size_t)R * c1 + 4 * c4, d);
+                st4_wt(a.dh1 + (size_t)R * c1 + 4 * c4, d);
             }
             st4(At + row * lda + 4 * c4, d);
         }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
                 const long R = row0 + row;
                 const bool rin = R < a.rows;
                 const f32x4 v = ld4(At + row * lda + 4 * c4);
-                if (rin) st4(a.dyln + (size_t)R * c0 + 4 * c4, v);
+                if (rin) st4_wt(a.dyln + (size_t)R * c0 + 4 * c4, v);
                 const long slab = rin ? R / a.rs.N : 0;
                 const int node = rin ? (int)(R - slab * a.rs.N) : 0;
                 float2 p = rin ? ln_rowstat4(a.rs, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);

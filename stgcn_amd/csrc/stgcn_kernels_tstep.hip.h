@@ -199,8 +199,8 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const size_t o = (size_t)b * N * C2 + (size_t)(n0 + r) * C2 + 4 * (cq + 16 * it);
-                st4(a.dgam_part + o, dgam[it]);
-                st4(a.dbet_part + o, dbet[it]);
+                st4_wt(a.dgam_part + o, dgam[it]);
+                st4_wt(a.dbet_part + o, dbet[it]);
             }
         }
         __syncthreads();       // (D) `red` free: it becomes the bias-reduction buffer
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             auto F = [&](int t, const Hook& h) __attribute__((always_inline)) {
                 if (cq < CIN / 4) {
                     const f32x4 v = ld4(Xo + (t & 1) * 16 * LDO + r * LDO + 4 * cq);
-                    if (rv) st4(a.dx + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
+                    if (rv) st4_wt2(a.dx + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
                     if (hk) {   // uniform
                         float2 p = make_float2(0.f, 0.f);
                         if (rv) {
@@ -778,8 +778,8 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
                 }
                 if (rowv) {
                     const size_t o = (((size_t)b * T1 + i) * N + n0 + l15) * C0 + c;
-                    st4(a.U + o, u);
-                    st4(a.S + o, sg);
+                    st4_wt2(a.U + o, u);
+                    st4_wt2(a.S + o, sg);
                 }
                 f32x4 pa = zero4();                    // this wave's share of A^T[j][row]: its 16 channels of the K = C0 contraction
 #pragma unroll
@@ -835,8 +835,9 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
 //   D leaves a lane with 4 consecutive channels of one row, and with wave w owning o-tiles w and w + c2/16 the P and Q halves of a
 //   channel meet in the same lane: bias, sigmoid, gate, the two-pass slab statistics (values stay in registers), the affine map,
 //   the Philox mask and the 16-byte U2 / S2 / y stores all run on registers -- no LDS round trip of the accumulators.
-// grid = B * T2 workgroups of 512 threads (8 waves: wave = (pair p = wave & 3, half = wave >> 2); the halves take alternate
-// 16-row tiles).  Template: C2 = 64 (p owns channels 16p..16p+15), KT taps, NTI row tiles per wave (N <= 32 * NTI).
+// grid = B * T2 workgroups of 256 * HV threads (4 * HV waves: wave = (pair p = wave & 3, group hf = wave >> 2); group hf takes the
+// 16-row tiles hf, hf + HV, ...).  Template: C2 = 64 (p owns channels 16p..16p+15), KT taps, NTI row tiles per wave (N <= 16 * HV * NTI),
+// HV = 2 or 4 tile groups: with 4 (16 waves, one workgroup per CU) four waves per SIMD interleave their MFMA runs and VALU epilogues.
 // ================================================================================================
 struct Tc2LnFwdArgs {
     const float* G;        // [B][T1][N][16]
@@ -856,15 +857,15 @@ struct Tc2LnFwdArgs {
     const uint64_t* offset_dev;
 };
 constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
-inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 32) * sizeof(float); }
+inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 64) * sizeof(float); }
 
-template <int C2, int KT, int NTI>
-__global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
+template <int C2, int KT, int NTI, int HV>
+__global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
     constexpr int NC = 2 * C2, MT = C2 / 16;
     extern __shared__ float stgcn_smem[];
     float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]
-    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [32]
+    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [3 * 4 * HV]
     const int tid = threadIdx.x, wv = tid >> 6, p = wv & (MT - 1), hf = wv >> 2, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const long slab = blockIdx.x;
     const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N, NPR = a.NPR, ntiles = NPR >> 4;
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     }
     // stage the KT input slabs G[b][t2 + tap] (zero rows beyond N)
     const float* Gb = a.G + ((size_t)b * a.T1 + t2) * N * 16;
-    for (int idx = tid; idx < KT * NPR * 4; idx += 512) {
+    for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
         const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
         st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ld4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
     }
@@ -889,14 +890,18 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     STGCN_PHASE(9, 1);
 
     unsigned kbits2 = 0;
-    // LayerNorm parameters of this lane's elements: requested now, consumed after the statistics (in flight during the MFMA phase)
+    // LayerNorm parameters of this lane's elements: consumed after the statistics.  Two tile groups (256 VGPRs per wave): requested now,
+    // in flight during the MFMA phase; four groups (128 VGPRs): requested after the MFMA phase, in flight during the statistics merge
     f32x4 ga[NTI], be[NTI];
+    auto load_affine = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + 2 * j) * 16 + l15, rcl = row < N ? row : N - 1;
-        ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
-        be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
-    }
+        for (int j = 0; j < NTI; ++j) {
+            const int row = (hf + HV * j) * 16 + l15, rcl = row < N ? row : N - 1;
+            ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
+            be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
+        }
+    };
+    if (HV == 2) load_affine();
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     const uint64_t n4 = ((uint64_t)N * C2) >> 2;
     // Per row tile: MFMAs, then the gate (U = P + b, S = sigmoid(Q + b), h = act(U) * S, kept in hh) and the keep bits of the dropout mask.
@@ -906,7 +911,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     float sum = 0.f, cnt_l = 0.f;
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int nt = hf + 2 * j, row = nt * 16 + l15;
+        const int nt = hf + HV * j, row = nt * 16 + l15;
         hh[j] = zero4();
         if (nt < ntiles) {   // uniform per wave
             f32x4 accP = zero4(), accQ = zero4();
@@ -932,8 +937,8 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
                     h[i] = gate_fwd(u[i], sg[i], a.act);
                 }
                 const size_t o = ((size_t)slab * N + row) * C2 + c;
-                st4(a.U + o, u);
-                st4(a.S + o, sg);
+                st4_wt(a.U + o, u);
+                st4_wt(a.S + o, sg);
                 hh[j] = h;
                 sum += (h[0] + h[1]) + (h[2] + h[3]);
                 cnt_l += 4.f;
@@ -945,6 +950,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
         }
     }
     STGCN_PHASE(9, 3);
+    if (HV != 2) load_affine();
     // slab statistics with ONE barrier: per-wave (count, mean, M2) about the wave's own mean, merged exactly (Chan et al.)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -955,7 +961,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + 2 * j) * 16 + l15;
+        const int row = (hf + HV * j) * 16 + l15;
         if (row < N) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) m2 += (hh[j][i] - mean_w) * (hh[j][i] - mean_w);
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     __syncthreads();
     float nn = 0.f, mean = 0.f, M2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4 * HV; ++k) {
         const float nw = red[3 * k], mw = red[3 * k + 1], qw = red[3 * k + 2];
         if (nw > 0.f) {
             const float d = mw - mean, nt2 = nn + nw;
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     STGCN_PHASE(9, 4);
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + 2 * j) * 16 + l15;
+        const int row = (hf + HV * j) * 16 + l15;
         if (row < N) {
             const size_t e = (size_t)row * C2 + c;
             const unsigned kb = ((NTI > 8 && j < 8) ? kbits2 : kbits) >> (4 * (j & 7));
@@ -998,7 +1004,7 @@ __global__ __launch_bounds__(512) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
                 o[i] = (hh[j][i] - mean) * rstd * ga[j][i] + be[j][i];
                 if (a.training) o[i] = ((kb >> i) & 1u) ? o[i] * a.keep_scale : 0.f;
             }
-            st4(a.y + (size_t)slab * N * C2 + e, o);
+            st4_wt(a.y + (size_t)slab * N * C2 + e, o);
         }
     }
     STGCN_PHASE(9, 5);
