@@ -260,7 +260,23 @@ typedef struct stgcn_outblock_params {
 } stgcn_outblock_params;
 typedef struct stgcn_outblock_grads {
     float *tc_w, *tc_b, *tc_aw, *tc_ab, *ln_w, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    float* loss;    /* stgcn_outblock_backward_loss only (else NULL): the MSE value, written by the gradient reduction of the call (or by
+                       stgcn_grad_flush when the reduction is deferred)                                                                  */
 } stgcn_outblock_grads;
+
+/* nn.MSELoss()(pred, target) fused into the head's backward (main.py:136/167-168): the seed gradient d loss / d pred =
+ * 2 (pred - target) / n * grad_scale is formed inside the fc backward kernel instead of being read, and the loss value comes out of the
+ * call's gradient reduction -- no separate loss launch.  pred = the (B, T1, N) output the forward of the same call chain wrote
+ * (n = B*T1*N values, end_channel = 1); target: n floats, read at target + *target_index_dev * target_index_stride when an index is
+ * given (device-side windowing, as in stgcn_mse_loss_grad).                                                                            */
+typedef struct stgcn_head_loss {
+    const float* pred;
+    const float* target;
+    const int64_t* target_index_dev;   /* nullable */
+    int64_t target_index_stride;
+    float grad_scale;                  /* e.g. 1 / world, or the tail-batch weight */
+    int32_t reserved;
+} stgcn_head_loss;
 
 typedef struct stgcn_outblock_plan {
     int64_t T1, rows, rows_in;        /* T1 = T-Ko+1, rows = B*T1*N, rows_in = B*T*N                             */
@@ -285,6 +301,10 @@ int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outbloc
 /* as above; dx_hook (nullable): LayerNorm of the module that produced x -- its backward row partials are written while dx is formed */
 int stgcn_outblock_backward_hook(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                                  const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
+                                 const stgcn_ln_hook* dx_hook, void* stream);
+/* as stgcn_outblock_backward_hook with the MSE loss fused in place of `dout` (grads->loss receives the loss value) */
+int stgcn_outblock_backward_loss(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
+                                 const stgcn_head_loss* loss, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
                                  const stgcn_ln_hook* dx_hook, void* stream);
 
 /* ---- Whole-model weight pack: the per-call pack launches of all ST blocks and of the head in ONE launch at the start of a

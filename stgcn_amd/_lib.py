@@ -78,8 +78,13 @@ class PrepackBlock(C.Structure):      # stgcn_prepack_block
     _fields_ = [("desc", C.POINTER(StblockDesc)), ("params", C.POINTER(StblockParams)), ("ws", C.c_void_p)]
 
 
-class OutblockGrads(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in HEAD_PARAM_FIELDS]
+class OutblockGrads(C.Structure):      # stgcn_outblock_grads: the parameter gradients, then the fused loss value (NULL unless used)
+    _fields_ = [(n, C.c_void_p) for n in HEAD_PARAM_FIELDS] + [("loss", C.c_void_p)]
+
+
+class HeadLoss(C.Structure):           # stgcn_head_loss
+    _fields_ = [("pred", C.c_void_p), ("target", C.c_void_p), ("target_index_dev", C.c_void_p), ("target_index_stride", C.c_int64),
+                ("grad_scale", C.c_float), ("reserved", C.c_int32)]
 
 
 HEAD_PLAN_FIELDS = ["T1", "rows", "rows_in", "out_floats", "saved_floats", "ws_floats", "sv_U", "sv_S", "sv_mean", "sv_rstd", "sv_yln",
@@ -131,6 +136,9 @@ class _Lib:
         d.stgcn_gso_layout.restype = C.c_int
         d.stgcn_set_gc_tiled_min_nodes.argtypes = [C.c_int32]
         d.stgcn_set_gc_tiled_min_nodes.restype = C.c_int
+        d.stgcn_outblock_backward_loss.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.POINTER(HeadLoss), C.c_void_p,
+                                                   C.c_void_p, C.POINTER(OutblockGrads), C.c_void_p, C.POINTER(LnHook), C.c_void_p]
+        d.stgcn_outblock_backward_loss.restype = C.c_int
         d.stgcn_set_slab_gc_precision.argtypes = [C.c_int32]
         d.stgcn_set_slab_gc_precision.restype = C.c_int
         d.stgcn_set_tc1_bwd_wgs.argtypes = [C.c_int32]
@@ -219,4 +227,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
                     "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
-                    "stgcn_set_slab_gc_precision"]
+                    "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss"]

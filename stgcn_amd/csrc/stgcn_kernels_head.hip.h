@@ -138,10 +138,16 @@ struct FcBwdArgs {
     const float* W1d;     // packed PK_LIN_BWD: K = c1, cols = c0
     float* dh1;           // [rows][c1]
     float* dyln;          // [rows][c0]
-    float* part;          // [wgs][c1 + 1]
+    float* part;          // [wgs][c1 + 2]: dw2 | db2 | sum (pred - target)^2 / n
     long rows;
     int c0, c1, KCH;      // KCH = c1 / 16
     float grad_scale;     // keep_scale when dropout was active, else 1
+    // fused MSE loss (pred != null): dout[R] = 2 (pred[R] - target[R]) / n * loss_scale is formed here instead of read from `dout`
+    const float* pred;
+    const float* target;
+    const long* target_index;   // nullable: target += *target_index * target_index_stride
+    long target_index_stride;
+    float loss_scale;
     LnRowstatOut rs;      // row partials of the head's LayerNorm backward (dyln is its output gradient); rs.rowstat == null: off
 };
 
@@ -152,12 +158,15 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int c1 = a.c1, c0 = a.c0, lda = c1 + 4, c4n = c1 >> 2;
     float* At = stgcn_smem;                // [TR][lda]
-    float* red = stgcn_smem + TR * lda;    // [8][c1] + [8]
+    float* red = stgcn_smem + TR * lda;    // [8][c1] + [8] + [8]
     const long tiles = (a.rows + TR - 1) / TR;
     const int c4 = tid % c4n, rsub = tid / c4n;            // c4n == 32 -> rsub in 0..7, fixed channel group per thread
     f32x4 dw2 = zero4();
-    float db2 = 0.f;
+    float db2 = 0.f, lsum = 0.f;
     const f32x4 w2 = ld4(a.w2 + 4 * c4);
+    const float* tgt = a.target;
+    if (a.pred && a.target_index) tgt += *a.target_index * a.target_index_stride;
+    const float inv_n = 1.0f / (float)a.rows;
     PreW<NT, 8> w;   // fc1 weight fragments of the whole K = c1 (8 chunks), requested before the first tile is touched
     pre_load_weights<NT, 8>(w, a.W1d, a.KCH, wave, 4);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
@@ -167,7 +176,14 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
             const long R = row0 + row;
             f32x4 d = zero4();
             if (R < a.rows) {
-                const float go = a.dout[R];
+                float go;
+                if (a.pred) {   // uniform
+                    const float df = a.pred[R] - tgt[R];
+                    go = 2.0f * df * inv_n * a.loss_scale;
+                    if (c4 == 0) lsum += df * df;
+                } else {
+                    go = a.dout[R];
+                }
                 const f32x4 h = ld4(a.hd + (size_t)R * c1 + 4 * c4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -228,9 +244,12 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
     }
     __syncthreads();
     st4(red + rsub * c1 + 4 * c4, dw2);
-    if (c4 == 0) red[8 * c1 + rsub] = db2;
+    if (c4 == 0) {
+        red[8 * c1 + rsub] = db2;
+        red[8 * c1 + 8 + rsub] = lsum;
+    }
     __syncthreads();
-    float* part = a.part + (size_t)blockIdx.x * (c1 + 1);
+    float* part = a.part + (size_t)blockIdx.x * (c1 + 2);
     if (tid < c1) {
         float s = 0.f;
         for (int k = 0; k < kThreads / c4n; ++k) s += red[k * c1 + tid];
@@ -240,6 +259,9 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
         float s = 0.f;
         for (int k = 0; k < kThreads / c4n; ++k) s += red[8 * c1 + k];
         part[c1] = s;
+        float l = 0.f;
+        for (int k = 0; k < kThreads / c4n; ++k) l += red[8 * c1 + 8 + k];
+        part[c1 + 1] = l * inv_n;
     }
 }
 

@@ -9,6 +9,7 @@ PyTorch is used for device memory (caching allocator), streams and autograd book
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -238,6 +239,55 @@ def mse_loss_and_grad(pred: torch.Tensor, target: torch.Tensor, grad_scale: floa
     L.check(L.dll.stgcn_mse_loss_grad(p.data_ptr(), target.data_ptr(), p.numel(), float(grad_scale), loss.data_ptr(), dpred.data_ptr(),
                                       ti, tis, _stream_of(p)), "stgcn_mse_loss_grad")
     return loss, dpred
+
+
+class _PendingLoss:
+    """MSE loss waiting to be formed inside the head's backward (``stgcn_outblock_backward_loss``): ``mse_backward`` posts it, the
+    ``_OutBlockFn.backward`` that receives the placeholder gradient takes it."""
+    __slots__ = ("placeholder", "pred", "target", "index", "index_stride", "grad_scale", "loss")
+
+
+_pending_loss: Optional[_PendingLoss] = None
+_VIEW_NODES = ("ViewBackward", "UnsafeViewBackward", "ReshapeAliasBackward", "UnsqueezeBackward", "SqueezeBackward", "AliasBackward")
+
+
+def _head_node_of(pred: torch.Tensor):
+    """The fused head's autograd node if ``pred`` is its output seen through shape-only views, else None."""
+    fn = pred.grad_fn
+    while fn is not None and type(fn).__name__.startswith(_VIEW_NODES):
+        nxt = [f for f, _ in fn.next_functions if f is not None]
+        if len(nxt) != 1:
+            return None
+        fn = nxt[0]
+    return fn if fn is not None and type(fn).__name__ == "_OutBlockFnBackward" else None
+
+
+def mse_backward(pred: torch.Tensor, target: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+    """``l = nn.MSELoss()(pred, target); l.backward()`` (main.py:167-168) for a prediction that comes straight out of the fused output
+    head: the seed gradient is formed inside the head's fc backward kernel and the loss value comes out of the step's gradient reduction
+    (no loss launch at all).  Any other ``pred`` takes the one-launch loss kernel (``mse_loss_and_grad``) followed by
+    ``pred.backward(dpred)``.  Returns the loss (shape [1]); with an active gradient sink it is valid after the sink's flush."""
+    global _pending_loss
+    p = pred.detach()
+    if (_head_node_of(pred) is None or not p.is_contiguous() or p.shape != target.shape or not target.is_contiguous()
+            or target.dtype != torch.float32 or os.environ.get("STGCN_FUSED_LOSS", "1") == "0"):
+        loss, dpred = mse_loss_and_grad(pred, target, grad_scale)
+        pred.backward(dpred)
+        return loss
+    _check_device(p, "pred")
+    pl = _PendingLoss()
+    pl.placeholder = torch.empty_like(p)            # never written, never read: its address identifies the request
+    pl.pred, pl.target, pl.grad_scale = p, target, float(grad_scale)
+    pl.index, pl.index_stride = _index_of(target)
+    pl.loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    _pending_loss = pl
+    try:
+        pred.backward(pl.placeholder)
+        if _pending_loss is not None:
+            raise RuntimeError("mse_backward: the output head did not take the fused loss (was its backward run through another path?)")
+    finally:
+        _pending_loss = None
+    return pl.loss
 
 
 class GradSink:
@@ -640,6 +690,10 @@ class _OutBlockFn(torch.autograd.Function):
         sink = _sink
         desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None)
         dout = dout.contiguous()
+        global _pending_loss
+        fused_loss = _pending_loss if (_pending_loss is not None and _pending_loss.placeholder.data_ptr() == dout.data_ptr()) else None
+        if fused_loss is not None:
+            _pending_loss = None
         used = {"tc_aw": c_in > cfg.channels[0], "tc_ab": c_in > cfg.channels[0]}
         grads = []
         for name, p, need in zip(HEAD_PARAM_FIELDS, params, ctx.param_needs_grad):
@@ -655,10 +709,21 @@ class _OutBlockFn(torch.autograd.Function):
         pst = _head_struct(OutblockParams, [None if p is None else p.detach() for p in params])
         gst = _head_struct(OutblockGrads, grads)
         ih = ctx.in_hook if dx is not None else None
-        L.check(L.dll.stgcn_outblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
-                                                   ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
-                                                   None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
-                "stgcn_outblock_backward")
+        if fused_loss is not None:
+            gst.loss = fused_loss.loss.data_ptr()
+            hl = _lib.HeadLoss()
+            hl.pred, hl.target = fused_loss.pred.data_ptr(), fused_loss.target.data_ptr()
+            hl.target_index_dev, hl.target_index_stride, hl.grad_scale = fused_loss.index, fused_loss.index_stride, fused_loss.grad_scale
+            ctx.keep_loss = fused_loss                  # the buffers outlive a deferred reduction
+            L.check(L.dll.stgcn_outblock_backward_loss(C.byref(desc), C.byref(pst), x_cl.data_ptr(), C.byref(hl), saved.data_ptr(),
+                                                       ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
+                                                       None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
+                    "stgcn_outblock_backward_loss")
+        else:
+            L.check(L.dll.stgcn_outblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(),
+                                                       ctx.ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
+                                                       None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
+                    "stgcn_outblock_backward")
         if ih is not None:
             ih.ready, ih.dx_ptr = True, dx.data_ptr()
         if sink is not None:

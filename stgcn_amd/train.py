@@ -89,13 +89,11 @@ def make_optimizer(model: torch.nn.Module, lr: float = 1e-3, weight_decay: float
 
 
 def fwd_loss_bwd(model, x, y):
-    """forward -> MSELoss -> backward (main.py:166-168) with the loss and its gradient from ONE launch
-    (``ops.mse_loss_and_grad``): ``pred.backward(dpred)`` equals ``MSELoss()(pred, y).backward()``.  Returns the loss (shape [])."""
+    """forward -> MSELoss -> backward (main.py:166-168) with the loss formed inside the fused head's backward (``ops.mse_backward``;
+    one loss launch + ``pred.backward(dpred)`` for a model without the fused head).  Returns the loss (shape [])."""
     from . import ops
     y_pred = model(x).reshape(len(x), -1)
-    loss, dpred = ops.mse_loss_and_grad(y_pred, y)
-    y_pred.backward(dpred)
-    return loss[0]
+    return ops.mse_backward(y_pred, y)[0]
 
 
 def fused_tail_supported(model, live_params) -> bool:
@@ -137,7 +135,7 @@ class GradArena:
 
 
 def fused_train_step(model, optimizer, x, y, arena: GradArena, world: int = 1, all_reduce=None):
-    """The loop body of main.py:165-169 with the step tail fused: forward -> one-launch MSE loss + gradient -> backward with
+    """The loop body of main.py:165-169 with the step tail fused: forward -> backward with the MSE loss formed inside the head and
     deferred reductions -> ONE launch for all gradient reductions + AdamW (world == 1), or reductions into the flat arena ->
     ``all_reduce(arena.flat)`` -> AdamW (world > 1; the 1/world of the gradient mean rides on the loss gradient).
     ``param.grad`` are the arena views (overwritten every step, never accumulated)."""
@@ -148,8 +146,7 @@ def fused_train_step(model, optimizer, x, y, arena: GradArena, world: int = 1, a
     arena.install()
     with ops.grad_sink_scope(arena.sink):
         y_pred = model(x).reshape(len(x), -1)
-        loss, dpred = ops.mse_loss_and_grad(y_pred, y, grad_scale=1.0 / world)
-        y_pred.backward(dpred)
+        loss = ops.mse_backward(y_pred, y, grad_scale=1.0 / world)      # (valid after the flush below)
     if world <= 1 and hasattr(optimizer, "flush_with"):
         optimizer.flush_with(arena.sink, arena.grads)
     else:
@@ -188,8 +185,7 @@ def tail_step(model, optimizer, x, y, world: int = 1, rank: int = 0):
     loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
     if hi > lo:
         pred = model(x[lo:hi]).reshape(hi - lo, -1)
-        loss, dpred = ops.mse_loss_and_grad(pred, y[lo:hi].contiguous(), grad_scale=(hi - lo) / n)
-        pred.backward(dpred)
+        loss = ops.mse_backward(pred, y[lo:hi].contiguous(), grad_scale=(hi - lo) / n)
         loss_sum = loss * ((hi - lo) / n)
     if world > 1:
         params = [p for p in model.parameters() if p.requires_grad]
@@ -404,8 +400,7 @@ class GraphedTrainStep:
         self.arena.install()
         with ops.grad_sink_scope(self.arena.sink):
             y_pred = self.model(self.x).reshape(len(self.x), -1)
-            loss, dpred = ops.mse_loss_and_grad(y_pred, self.y, grad_scale=1.0 / self.world)
-            y_pred.backward(dpred)
+            loss = ops.mse_backward(y_pred, self.y, grad_scale=1.0 / self.world)      # (written by the gradient flush of the step)
         if self.world > 1:
             self.arena.sink.flush(stream=torch.cuda.current_stream(self.x.device).cuda_stream)
         return loss[0]

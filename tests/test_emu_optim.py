@@ -208,3 +208,46 @@ def test_module_reuse_before_flush_is_refused():
             m(x)
     arena.sink.flush()
     m(x)        # fine again after the flush
+
+
+def test_mse_loss_fused_into_the_head_backward(monkeypatch):
+    """ops.mse_backward: for a prediction that comes straight out of the fused head the seed gradient is formed inside the fc backward
+    kernel and the loss value comes out of the gradient reduction (stgcn_outblock_backward_loss) -- same loss and the same gradients as
+    the one-launch loss kernel followed by pred.backward(dpred); any other prediction takes that two-call path."""
+    import types
+    from stgcn_amd import models, ops
+    from tests.emu_util import bind_emulator
+    from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture
+    bind_emulator()
+    fx = load_fixture("tiny_cheb_f32")
+    cfg = cfg_from_fixture(fx)
+    N, B = int(fx["n_vertex"]), int(fx["B"])
+    args = types.SimpleNamespace(Kt=cfg.Kt, Ks=cfg.Ks, act_func=cfg.act_func, graph_conv_type=cfg.graph_conv_type,
+                                 gso=torch.from_numpy(fixture_gso("tiny_cheb_f32", fx)), enable_bias=True, droprate=0.0, n_his=cfg.n_his)
+    m = models.STGCNChebGraphConv(args, cfg.blocks, N)
+    m.load_state_dict(fixture_params(fx, cfg, torch.float32), strict=True)
+    m.train()
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.randn(B, 1, cfg.n_his, N, generator=g), torch.randn(B, N, generator=g)
+
+    pred = m(x).reshape(B, -1)
+    assert ops._head_node_of(pred) is not None                       # shape-only views between the head and the loss
+    assert ops._head_node_of(pred * 1.0) is None
+    loss_a, dpred = ops.mse_loss_and_grad(pred, y, grad_scale=0.5)
+    pred.backward(dpred)
+    ga = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    calls = []
+    real = ops._lib.lib().dll.stgcn_outblock_backward_loss
+    monkeypatch.setattr(ops._lib.lib().dll, "stgcn_outblock_backward_loss", lambda *a: (calls.append(1), real(*a))[1])
+    m.zero_grad(set_to_none=True)
+    loss_b = ops.mse_backward(m(x).reshape(B, -1), y, grad_scale=0.5)
+    assert calls == [1]
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - ga[k]).abs().max()) <= 1e-6 * float(ga[k].abs().max()) + 1e-12, k
+
+    m.zero_grad(set_to_none=True)                                    # a prediction with arithmetic behind the head: the two-call path
+    loss_c = ops.mse_backward(m(x).reshape(B, -1) * 1.0, y, grad_scale=0.5)
+    assert calls == [1] and abs(float(loss_a) - float(loss_c)) <= 1e-6 * abs(float(loss_a))
