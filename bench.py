@@ -195,7 +195,12 @@ def main():
     from stgcn_amd.train import FlatGradAllReduce, GraphedTrainStep, init_distributed, make_optimizer, train_step
 
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    rank, local_rank, world = init_distributed()
+    # (test hook: STGCN_BENCH_BACKEND=gloo + STGCN_BENCH_SHARE_GPU=1 drive the N-rank code path with every rank on GPU 0 of a
+    #  one-GPU box -- the numbers of such a run mean nothing, the control flow is what is being exercised)
+    share_gpu = os.environ.get("STGCN_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = init_distributed(os.environ.get("STGCN_BENCH_BACKEND"))
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -307,7 +312,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out["config"]["allreduce"] = {"bytes": int(flat.numel() * 4), "us": round(1e3 * e0.elapsed_time(e1) / 50, 2),
-                                      "placement": "eager RCCL call between the two captured graphs of the step" if use_graph else "eager"}
+                                      "placement": "eager all-reduce (torch.distributed backend " + torch.distributed.get_backend() + "; nccl = RCCL) between the two captured graphs of the step" if use_graph else "eager"}
 
     if rank == 0 and not args.no_profile:
         # per-kernel durations with hipEvents on the launch stream, over the same K steps (second pass)
