@@ -946,8 +946,10 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         memset(&f, 0, sizeof(f));
         f.x = x; f.Wp = ws + pl.ws_W1p; f.bias = ws + pl.ws_b1; f.WaD = ws + pl.ws_WaDense; f.ba = ws + pl.ws_ba;
         f.U = saved + pl.sv_U1; f.S = saved + pl.sv_S1; f.A = saved + pl.sv_A;
-        f.B = d->B; f.T = d->T; f.T1 = v.T1; f.N = d->N; f.node_tiles = (d->N + 15) / 16; f.wb = tc1_ts_wb(d->B, d->N);
-        const dim3 grid((unsigned)(f.node_tiles * ((d->B + f.wb - 1) / f.wb))), blk(512);
+        f.B = d->B; f.T = d->T; f.T1 = v.T1; f.N = d->N; f.node_tiles = (d->N + 15) / 16;
+        const long items = (long)d->B * f.node_tiles;
+        const long want = g_tc1_bwd_wgs > 0 ? g_tc1_bwd_wgs : device_cus();                  // (stgcn_set_tc1_bwd_wgs: test knob of both tc1 kernels)
+        const dim3 grid((unsigned)(items < want ? items : want)), blk(512);                   // equal (item, step) ranges, one workgroup per CU
         const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \
         do {                                                                                                  \

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
 }
 
 // ================================================================================================
-// F1 (time-stepping): tmp_conv1 + gate + Align(c0 -> c1) forward for `wb` windows x one 16-node tile per workgroup (layers.py:252, :223).
+// F1 (time-stepping): tmp_conv1 + gate + Align(c0 -> c1) forward on 16-node tiles of one window (layers.py:252, :223).
 //   Z^T[o][row] = W_eff1^T[o][K] im2col(x)^T[K][row] per output step: A = the packed weights (PK_TCONV_FWD fragments), the whole
 //   K = Kt * c_in of a wave's two o-tiles (P and Q half of 16 channels) stationary in registers; B = x tiles from an LDS ring (every
 //   input tile is read from memory once and serves Kt output steps).  D leaves a lane with P and Q of 4 channels of one row: bias,
@@ -713,6 +713,9 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
 //   Align product A^T[j][row] += Wa^T[j][i] h^T[i][row] over the wave's own 16 channels (4 MFMAs, no LDS round trip); the four waves'
 //   partial A tiles are summed by the E waves one step later.
 // 8 waves: 4 M waves (MFMA + gate epilogue) | 4 E waves (x tile loads -> ring, A = sum of partials + bias -> memory); one barrier / step.
+// Work distribution as in tc1_bwd_kernel: the B * ceil(N/16) (window, node tile) items do not fill 256 CUs evenly (416 at C2), so the
+// sequence of (item, output step) units -- all of equal MFMA weight here -- is cut into gridDim.x equal ranges; a range that starts
+// inside an item only re-reads the Kt - 1 input tiles in front of it (no arithmetic is repeated).
 // ================================================================================================
 struct Tc1FwdArgs {
     const float* x;           // [B][T][N][CIN]
@@ -723,7 +726,7 @@ struct Tc1FwdArgs {
     float* U;                 // [B][T1][N][C0]
     float* S;
     float* A;                 // [B][T1][N][16]
-    int B, T, T1, N, node_tiles, wb;
+    int B, T, T1, N, node_tiles;
 };
 inline size_t tc1_fwd_lds_bytes(int CIN, int Kt) { return ((size_t)(Kt + 1) * 16 * (CIN + 8) + 2 * 4 * 16 * 20) * sizeof(float); }
 
@@ -736,9 +739,12 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     float* const red = Xs + RING * 16 * LDXS;          // [2][4 waves][16 rows][20]  partial Align tiles, double buffered
     const bool roleM = threadIdx.x < 256;              // wave-uniform
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const int nt = (int)blockIdx.x % a.node_tiles, bg = (int)blockIdx.x / a.node_tiles, n0 = nt * 16;
     const int N = a.N, T = a.T, T1 = a.T1;
-    const int b_lo = bg * a.wb, b_hi = (b_lo + a.wb < a.B) ? b_lo + a.wb : a.B;
+    // this workgroup's range of the (item, step) sequence (identical in both roles): units [u_lo, u_hi), item = b * node_tiles + tile
+    const long items = (long)a.B * a.node_tiles, units = items * T1;
+    const long u_lo = units * (long)blockIdx.x / (long)gridDim.x, u_hi = units * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    const long item0 = u_lo / T1, item1 = u_hi / T1;
+    const int s0 = (int)(u_lo - item0 * T1), s1 = (int)(u_hi - item1 * T1);
 
     if (roleM) {
         // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
@@ -753,10 +759,13 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
         f32x4 waT;                                     // A[m = j = l15][k = i = 16w + 4g + s] = Wa[i][j]
 #pragma unroll
         for (int sI = 0; sI < 4; ++sI) waT[sI] = a.WaD[(size_t)(c + sI) * 16 + l15];
-        const bool rowv = n0 + l15 < N;
-        for (int b = b_lo; b < b_hi; ++b) {
-            __syncthreads();   // (A) x tiles 0 .. KT-1 of this window staged
-            for (int i = 0; i < T1; ++i) {
+        for (long item = item0; item <= item1 && item < items; ++item) {
+            const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T1;
+            if (sb >= se) continue;                    // (uniform over the workgroup: both roles evaluate the same list)
+            const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
+            const bool rowv = n0 + l15 < N;
+            __syncthreads();   // (A) x tiles sb .. sb + KT - 1 of this item staged
+            for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B) x tile i + KT - 1 visible; partial tiles of step i - 1 visible to the E waves
                 f32x4 accP = zero4(), accQ = zero4();
 #pragma unroll
@@ -791,9 +800,12 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     } else {
         // =========================================== E waves ===========================================================
         const int r = tid >> 4, cq = tid & 15;         // x tiles: row r, float4 column cq (< CIN / 4); A tiles: row r, channel cq
-        const bool rv = n0 + r < N;
         const float bj = a.ba[cq];
-        for (int b = b_lo; b < b_hi; ++b) {
+        for (long item = item0; item <= item1 && item < items; ++item) {
+            const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T1;
+            if (sb >= se) continue;
+            const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
+            const bool rv = n0 + r < N;
             auto get_x = [&](int xt) {
                 f32x4 v = zero4();
                 if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
@@ -809,19 +821,19 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             };
             f32x4 xs[KT];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) xs[k] = get_x(k);
+            for (int k = 0; k < KT; ++k) xs[k] = get_x(sb + k);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) put_x(k, xs[k]);   // (the previous window's M steps are over: every role passed its barrier (C))
-            f32x4 x_n = get_x(KT);
+            for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);   // (the previous range's M steps are over: every role passed its barrier (C))
+            f32x4 x_n = get_x(sb + KT);
             __syncthreads();   // (A)
-            for (int i = 0; i < T1; ++i) {
+            for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B)
-                if (i > 0) F(i - 1);
+                if (i > sb) F(i - 1);
                 put_x(i + KT, x_n);          // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1
                 x_n = get_x(i + KT + 1);
             }
             __syncthreads();       // (C)
-            F(T1 - 1);
+            F(se - 1);
         }
     }
 }

@@ -96,3 +96,17 @@ def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
     assert np.abs(seg(plan.sv_rstd, (B, T2)) / sv["rstd"] - 1).max() < 1e-4
     assert np.isfinite(y.numpy()).all()
     assert np.abs(y.numpy() - y_ref).max() < 5e-5
+
+
+@pytest.mark.parametrize("wgs", [1, 3, 5])
+def test_tc1_fwd_ranges_cut_inside_items(wgs):
+    """tc1_fwd_kernel hands every workgroup an equal range of the (window, node tile, output step) sequence; with fewer workgroups than
+    items the cuts fall inside items (the Kt - 1 input tiles in front of a cut are read again, nothing is recomputed): same results."""
+    from stgcn_amd import ops
+    bind_emulator()
+    prev = ops.set_tc1_bwd_wgs(wgs)
+    try:
+        test_block_forward_stages(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 7)
+        test_block_forward_stages(32, (64, 16, 64), 3, 1, "cheb_graph_conv", "gtu", 16, 1, 5)
+    finally:
+        ops.set_tc1_bwd_wgs(prev)
