@@ -163,9 +163,10 @@ int stgcn_gso_layout(int32_t N, int32_t terms, int64_t* NP, int64_t* mats, int64
  * can compare them with the oracle.  Returns the previous value; other values only query.                                  */
 int stgcn_set_debug_stages(int32_t on);
 
-/* Tuning / test knob: workgroups of the fused tmp_conv1 backward (tc1_bwd_kernel); 0 = one per CU.  Each workgroup walks an equal-
- * weight range of the (window, node tile, output step) sequence; a small value cuts the ranges inside items (exercised by the
- * emulator tests).  Changes the partial-sum arena of stgcn_stblock_plan_query.  Returns the previous value; n < 0 only queries. */
+/* Test knob: pretend the device has n compute units (0 = ask the runtime).  The launches sized by the CU count -- the equal-weight
+ * (window, node tile, step) ranges of tc1_fwd_kernel / tc1_bwd_kernel, the wave count of tc2_ln_fwd_kernel -- then take their
+ * small-device branches (ranges cut inside items, 8-wave workgroups), which the emulator tests exercise that way.  Changes the
+ * partial-sum arena of stgcn_stblock_plan_query.  Returns the previous value; n < 0 only queries.                              */
 int stgcn_set_tc1_bwd_wgs(int32_t n);
 
 /* Tuning / test knob: graphs with at least n nodes use the tiled graph conv (default 513).  Returns the previous value;

@@ -948,7 +948,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         f.U = saved + pl.sv_U1; f.S = saved + pl.sv_S1; f.A = saved + pl.sv_A;
         f.B = d->B; f.T = d->T; f.T1 = v.T1; f.N = d->N; f.node_tiles = (d->N + 15) / 16;
         const long items = (long)d->B * f.node_tiles;
-        const long want = g_tc1_bwd_wgs > 0 ? g_tc1_bwd_wgs : device_cus();                  // (stgcn_set_tc1_bwd_wgs: test knob of both tc1 kernels)
+        const long want = device_cus();                                                       // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
         const dim3 grid((unsigned)(items < want ? items : want)), blk(512);                   // equal (item, step) ranges, one workgroup per CU
         const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \

@@ -33,29 +33,24 @@ inline bool tc2_ln_fwd_fused_ok(int c1, int c2, int Kt, int N) {
     return (fuse_mask() & FUSE_TC2_LN_FWD) && c1 == 16 && c2 == 64 && Kt >= 2 && Kt <= 4 && N <= 448 && tc2_ln_fwd_lds_bytes(Kt, N) <= 150 * 1024;
 }
 // shapes tc1_bwd_kernel covers (whether a call uses it also depends on need_dx: the kernel always forms the input gradient)
+// test knob (stgcn_set_tc1_bwd_wgs): pretend the device has this many CUs (0 = ask the runtime).  The launch heuristics that size a
+// grid by the CU count -- the (item, step) ranges of the two tc1 kernels, the wave count of tc2_ln_fwd -- then take their small-device
+// branches on the emulator too: ranges cut inside items, the 8-wave variant of tc2_ln_fwd
+inline int g_tc1_bwd_wgs = 0;
 inline int device_cus() {
     static int cus = 0;
+    if (g_tc1_bwd_wgs > 0) return g_tc1_bwd_wgs;
     if (!cus) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     return cus;
 }
-// workgroups of tc1_bwd_kernel: 0 = one per CU (but never more than items); a test knob forces small grids so that the ranges of
-// the (item, step) sequence are cut inside items on the emulator too (stgcn_set_tc1_bwd_wgs)
-inline int g_tc1_bwd_wgs = 0;
 inline bool tc1_ts_shape(int c_in, int c0, int c1, int Kt) { return c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64); }
 inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
     return (fuse_mask() & FUSE_TC1_BWD) && tc1_ts_shape(c_in, c0, c1, Kt) && tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
 }
 inline bool tc1_fwd_shape_ok(int c_in, int c0, int c1, int Kt) { return (fuse_mask() & FUSE_TC1_FWD) && tc1_ts_shape(c_in, c0, c1, Kt); }
-// windows per workgroup of the time-stepping tmp_conv1 kernels: ~one workgroup per CU
-inline int tc1_ts_wb(int B, int N) {
-    const int nt = (N + 15) / 16;
-    int wb = (int)(((long)B * nt + device_cus() - 1) / device_cus());
-    if (wb < 1) wb = 1;
-    return wb > B ? B : wb;
-}
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
     return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && ((c2 == 64 && Kt >= 2 && Kt <= 4) || (c2 == 128 && Kt == 3)) && T1 <= kTsMaxT &&
            tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 64 * 1024;
@@ -189,7 +184,7 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.k3_wb = 0;
     {   // one workgroup per CU walking an equal-weight range of the (window, node tile, output step) sequence
         const long items = (long)B * g.node_tiles;
-        long wgs = g_tc1_bwd_wgs > 0 ? g_tc1_bwd_wgs : device_cus();
+        long wgs = device_cus();
         if (wgs > items) wgs = items;
         g.k3_wgs = (int)wgs;
     }
