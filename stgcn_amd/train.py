@@ -332,7 +332,10 @@ class GraphedTrainStep:
         if not self.fused:
             self.opt.zero_grad(set_to_none=True)
         self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
+        # with a process group alive its watchdog thread polls events while this thread captures: "thread_local" keeps such calls of OTHER
+        # threads from invalidating the capture (the default "global" mode is for single-threaded programs)
+        cap = dict(capture_error_mode="thread_local") if world > 1 else {}
+        with torch.cuda.graph(self.g1, **cap):
             if self.fused:
                 self.loss = self._fused_fwd_bwd()
                 if world > 1:
@@ -354,7 +357,7 @@ class GraphedTrainStep:
         self.g2 = None
         if world > 1:
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            with torch.cuda.graph(self.g2, pool=self.g1.pool(), **cap):
                 if not self.fused:
                     self.flat.mul_(1.0 / world)
                     torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
