@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU pass of a build -> measure iteration (gpurun -- 'bash tools/gpu_round.sh <tag> [stages]').
 #   stages (default "test bench trace"): test = pytest -m gpu | bench = bench.py 200 steps with the per-kernel timer |
-#   trace = rocprofv3 kernel trace of the graph-replayed bench | pmc = FETCH/WRITE/SQ counter passes | smoke | side = C3/C5 configs
+#   trace = rocprofv3 kernel trace of the graph-replayed bench | pmc = FETCH/WRITE counter passes | sq = SQ busy / wait counters | smoke | side = C3/C5 configs
 # Everything lands in gpurun_out/<tag>/ ; summaries worth keeping are copied to profiles/ by hand.
 set -u
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -37,6 +37,10 @@ pmc)
     python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE/pmc_results.db /tmp/pmc_${TAG}_WRITE_SIZE/pmc_results.db $OUT/launch_FETCH_SIZE.log $OUT/launch_WRITE_SIZE.log > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
     python -c "import sqlite3,sys; db=sqlite3.connect('/tmp/pmc_${TAG}_FETCH_SIZE/pmc_results.db'); print([d[1] for d in db.execute('pragma table_info(counters_collection)')])" > $OUT/pmc_schema.txt 2>&1
     head -c 1200 $OUT/pmc_traffic.json; cat $OUT/pmc_traffic.err | tail -3 ;;
+sq)
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d /tmp/pmc_${TAG}_sq -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-profile --no-graph > $OUT/pmc_sq.log 2>&1; echo "pmc sq exit $?" )
+    python tools/rocpd_pmc_summary.py /tmp/pmc_${TAG}_sq/pmc_results.db > $OUT/pmc_sq.md 2>&1
+    grep -E "tc1_bwd|tc2_bwd|tc2_ln|tc1_fwd|gconv" $OUT/pmc_sq.md | cut -c1-230 ;;
 side)
     timeout 900 python tools/gpu_side_configs.py ${SIDE_ARGS:-} > $OUT/side_configs.jsonl 2> $OUT/side_configs.err; echo "side exit $?"; cat $OUT/side_configs.jsonl ;;
 *)  # anything else: a script path relative to the repo
