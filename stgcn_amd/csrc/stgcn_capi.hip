@@ -626,6 +626,20 @@ int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const Wgra
     }
 }
 
+// two independent weight gradients (the head's conv and fc1) in ONE launch when both take the <4 m-tiles> variants
+inline bool wgrad_pair_ok(const TconvBwdWeightArgs& a1, const WgradGeom& w1, const TconvBwdWeightArgs& a2, const WgradGeom& w2) {
+    static const int off = getenv("STGCN_WGRAD_PAIR") ? atoi(getenv("STGCN_WGRAD_PAIR")) == 0 : 0;   // A/B knob
+    return !off && a1.NC == 256 && w1.MTW == 4 && a2.NC == 128 && w2.MTW == 4 && (a1.ts.C & 3) == 0 && (a2.ts.C & 3) == 0;
+}
+int launch_wgrad_pair(const char* label, const TconvBwdWeightArgs& a1, const WgradGeom& w1, const TconvBwdWeightArgs& a2, const WgradGeom& w2,
+                      hipStream_t st) {
+    const int n1 = w1.chunks * w1.mchunks, n2 = w2.chunks * w2.mchunks;
+    const size_t l1 = wgrad_lds_bytes(4, 4), l2 = wgrad_lds_bytes(4, 2);
+    STGCN_LAUNCH(label, st, (wgrad_pair_kernel<4, 4, 4, 2>), dim3((unsigned)(n1 + n2)), dim3(kThreads * kWgradGroups), l1 > l2 ? l1 : l2, a1, n1,
+                 w1.mchunks, a2, n2, w2.mchunks);
+    return STGCN_OK;
+}
+
 // ---- final deterministic reduction: job lists shared by the backward entry points and stgcn_grad_flush ----------------
 struct ReduceList {
     ReduceArgs ra;

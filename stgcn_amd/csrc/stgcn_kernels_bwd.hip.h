@@ -972,8 +972,10 @@ constexpr size_t wgrad_lds_bytes(int MTW, int NTW) {
 }
 
 // VEC: the input channel count is a multiple of 4 (16-byte im2col loads); otherwise scalar loads (narrow first layer).
+// The body is a device function of (flat workgroup index, workgroup count, m chunks) so that two independent weight gradients can
+// share ONE launch (wgrad_pair_kernel below: an empty launch costs 4.6 us inside the replayed step).
 template <int MTW, int NTW, bool VEC>
-__global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
+__device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& a, int flat_wg, int n_wgs, int mchunks) {
     extern __shared__ float stgcn_smem[];
     constexpr int GROUPS = kWgradGroups;
     constexpr int SR = wgrad_step_rows(MTW, NTW);
@@ -984,8 +986,8 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
     float* ct = stgcn_smem + grp * (SR * LDC + SR * LDZ);   // [SR][LDC]
     float* zt = ct + SR * LDC;                               // [SR][LDZ]
     // the m-chunks of one row chunk re-read the same dZ rows: keep them adjacent on one XCD (xcd_item)
-    const int item = xcd_item((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-    const int chunk = item / (int)gridDim.y, mchunk = item % (int)gridDim.y, m0 = mchunk * MC;
+    const int item = xcd_item(flat_wg, n_wgs);
+    const int chunk = item / mchunks, mchunk = item % mchunks, m0 = mchunk * MC;
     const long crow0 = (long)chunk * a.rows_per_chunk;
     long crow1 = crow0 + a.rows_per_chunk;
     if (crow1 > a.ts.rows) crow1 = a.ts.rows;
@@ -1164,6 +1166,16 @@ __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(Tc
         }
     }
     STGCN_PHASE(3, 3);
+}
+template <int MTW, int NTW, bool VEC>
+__global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
+    tconv_bwd_weight_body<MTW, NTW, VEC>(a, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), (int)gridDim.y);
+}
+// two weight gradients of one backward call in one launch: workgroups [0, n1) run the first, [n1, n1 + n2) the second
+template <int MTW1, int NTW1, int MTW2, int NTW2>
+__global__ __launch_bounds__(256 * kWgradGroups) void wgrad_pair_kernel(TconvBwdWeightArgs a1, int n1, int mc1, TconvBwdWeightArgs a2, int n2, int mc2) {
+    if ((int)blockIdx.x < n1) tconv_bwd_weight_body<MTW1, NTW1, true>(a1, (int)blockIdx.x, n1, mc1);     // (uniform per workgroup)
+    else tconv_bwd_weight_body<MTW2, NTW2, true>(a2, (int)blockIdx.x - n1, n2, mc2);
 }
 
 // ================================================================================================
