@@ -902,18 +902,14 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     STGCN_PHASE(9, 1);
 
     unsigned kbits2 = 0;
-    // LayerNorm parameters of this lane's elements: consumed after the statistics.  Two tile groups (256 VGPRs per wave): requested now,
-    // in flight during the MFMA phase; four groups (128 VGPRs): requested after the MFMA phase, in flight during the statistics merge
+    // LayerNorm parameters of this lane's elements: requested now, consumed after the statistics (in flight during the MFMA phase)
     f32x4 ga[NTI], be[NTI];
-    auto load_affine = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NTI; ++j) {
-            const int row = (hf + HV * j) * 16 + l15, rcl = row < N ? row : N - 1;
-            ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
-            be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
-        }
-    };
-    if (HV == 2) load_affine();
+    for (int j = 0; j < NTI; ++j) {
+        const int row = (hf + HV * j) * 16 + l15, rcl = row < N ? row : N - 1;
+        ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
+        be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
+    }
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     const uint64_t n4 = ((uint64_t)N * C2) >> 2;
     // Per row tile: MFMAs, then the gate (U = P + b, S = sigmoid(Q + b), h = act(U) * S, kept in hh) and the keep bits of the dropout mask.
@@ -962,7 +958,6 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
         }
     }
     STGCN_PHASE(9, 3);
-    if (HV != 2) load_affine();
     // slab statistics with ONE barrier: per-wave (count, mean, M2) about the wave's own mean, merged exactly (Chan et al.)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {

