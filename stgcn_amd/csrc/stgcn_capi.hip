@@ -548,13 +548,11 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
-    if (g_slab_gc_precision > 0 && a.Ks > 1 && gs16_np32(a.N) * 2 <= 4 * g.waves * 64) {   // operator products on the bf16 matrix cores (bf16x3)
+    if (g_slab_gc_precision > 0 && a.Ks > 1 && g.maxq <= 3 && gs16_np32(a.N) * 2 <= 4 * g.waves * 64) {   // operator products on the bf16 matrix cores (bf16x3; four tiles per wave would spill: those graphs keep the fp32 kernel)
         const size_t lds16 = gconv_fwd16_lds_bytes(a.NP, a.N);
         if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<1, 16>), grid, blk, lds16, a);
         else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<2, 8>), grid, blk, lds16, a);
-        else if (g.maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<3, 8>), grid, blk, lds16, a);
-        else if (g.maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<4, 8>), grid, blk, lds16, a);
-        else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
+        else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<3, 8>), grid, blk, lds16, a);
         return STGCN_OK;
     }
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed

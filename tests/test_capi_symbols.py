@@ -50,3 +50,29 @@ def test_product_package_never_imports_oracle():
                 elif isinstance(node, ast.ImportFrom):
                     names = [node.module or ""]
                 assert not any(n.split(".")[0] in ("oracle", "tests") for n in names), f"{fn} imports {names}"
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    """Register spills cost the fused kernels 30-50 % (a 17-VGPR spill took tc2_ln_fwd from 23 to 35 us): the gfx950 build must not
+    contain a kernel with a scratch allocation (hipcc -Rpass-analysis=kernel-resource-usage, device code only)."""
+    import subprocess
+    import tempfile
+    from stgcn_amd import build
+    try:
+        hipcc = build.find_hipcc()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", '-DSTGCN_BACKEND_NAME="hip-gfx950"',
+               "-Rpass-analysis=kernel-resource-usage", os.path.join(build.CSRC, "stgcn_capi.hip"), "-o", os.path.join(tmp, "dev.o")]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+    name, bad = None, []
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and int(m.group(1)) > 0:
+            bad.append((name, int(m.group(1))))
+    assert not bad, bad
