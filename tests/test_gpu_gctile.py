@@ -104,7 +104,10 @@ def test_tiled_equals_slab_resident_on_c2():
     for a, b in zip(ga, gb):
         assert (a is None) == (b is None)
         if a is not None:
-            assert rel(a, b) < 1e-3          # (same mask bit: a 16 x 16 graph-conv weight gradient moves by a few 1e-4 when one element flips)
+            # (the same mask bits: a flipped ReLU element moves the small tensors by a few 1e-4 to a few 1e-3 of their largest entry --
+            #  a 16 x 16 graph-conv weight, the 3 x 128 weights of the one-channel first conv -- depending on which element the
+            #  dropout stream of the run happens to put next to zero)
+            assert rel(a, b) < 5e-3
 
 
 # ---- bf16 / bf16x3 operator products (ops.set_gc_precision) -------------------------------------------------------------
