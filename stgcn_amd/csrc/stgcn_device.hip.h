@@ -66,7 +66,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1) for bulk outputs that the same kernel never reads again.  A plain store
 // leaves its line dirty in the XCD's L2 and the kernel boundary then pays for the write-back (MI355X_MICROARCH.md "boundary": + dirty
 // bytes / 6 TB/s); an sc1 store leaves L2 while the kernel is still computing and costs the same per instruction.  Measured on one box
-// (profiles/r31_wt_store_ab.txt, two alternating runs each): plain 0.4197, epilogue stores write-through 0.4155, in-loop stores as
+// (profiles/r2-31_wt_store_ab.txt, two alternating runs each): plain 0.4197, epilogue stores write-through 0.4155, in-loop stores as
 // well 0.4132 ms per step -- about 1 %, not the 50 us the dirty-byte rule would predict for 300 MB per step.  The compiler does not count inline-asm memory operations in vmcnt: every later
 // s_waitcnt it places is therefore conservative (it waits for these stores as well), never too short.  STGCN_WT_STORES=0 at build
 // time falls back to plain stores (A/B); the CPU emulator always uses the plain store.
