@@ -38,6 +38,17 @@ extern "C" {
 #define STGCN_GC_CHEB 0 /* cheb_graph_conv            layers.py:143-172 */
 #define STGCN_GC_KIPF 1 /* graph_conv                 layers.py:194-206 */
 
+/* Storage / arithmetic type of the ACTIVATIONS of a call (desc.dtype).  Parameters, their gradients, LayerNorm statistics, the
+ * partial-sum arena, optimizer state and the head's prediction are fp32 in both modes.
+ *   STGCN_DTYPE_F32  : fp32 tensors, exact fp32 matrix products (BASELINE.json configs[0], [1], [3])
+ *   STGCN_DTYPE_BF16 : x, y, dy, dx and every tensor of `saved` / `ws` that holds activations or activation gradients are bf16
+ *                      (2 bytes per element, round-to-nearest-even; the plan still counts 4-byte units), matrix products run on the
+ *                      bf16 matrix cores with fp32 accumulation, everything else stays fp32 (configs[2], [4]).  The rounding points are
+ *                      restated in oracle/stblock_stages.py (QuantBf16).  Pointers keep their `float*` type in this header: they are
+ *                      opaque device addresses.                                                                                     */
+#define STGCN_DTYPE_F32 0
+#define STGCN_DTYPE_BF16 1
+
 /* One STConvBlock(Kt, Ks, n_vertex, last_block_channel, channels, act_func, graph_conv_type, gso,
  * bias, droprate) (layers.py:241) applied to a batch. */
 typedef struct stgcn_stblock_desc {
@@ -64,7 +75,7 @@ typedef struct stgcn_stblock_desc {
     int64_t x_index_stride;
     int32_t dy_rowstats_ready; /* backward: 1 = the kernel that produced `dy` already wrote this block's LayerNorm-backward row partials
                                   (stgcn_ln_hook handed to that producer's backward call); the block skips its own pass over dy          */
-    int32_t reserved2;
+    int32_t dtype;            /* STGCN_DTYPE_*                                                                               */
 } stgcn_stblock_desc;
 
 /* Parameter pointers, keyed like the reference state_dict under "st_blocks.<l>." :
@@ -220,7 +231,7 @@ typedef struct stgcn_ln_hook {
     const float *mean, *rstd;  /* [B*T2]                                                                              */
     int32_t N, C, act, training;
     float droprate;
-    int32_t pad_;
+    int32_t dtype;             /* STGCN_DTYPE_* of U / S: must equal the dtype of the call the hook is handed to      */
     uint64_t seed, offset;
     const uint64_t* offset_dev;
 } stgcn_ln_hook;
@@ -248,7 +259,7 @@ typedef struct stgcn_outblock_desc {
     float droprate;
     float ln_eps;
     int32_t need_dx;
-    int32_t reserved;
+    int32_t dtype;            /* STGCN_DTYPE_* (x, dx, saved / ws activations; `out`, `dout`, pred / target stay fp32)   */
     int32_t prepacked;        /* as in stgcn_stblock_desc */
     int32_t defer_reduce;     /* as in stgcn_stblock_desc */
 } stgcn_outblock_desc;

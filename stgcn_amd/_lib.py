@@ -17,6 +17,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libstgcn_hip.so")
 STGCN_OK = 0
 ACT = {"glu": 0, "gtu": 1}
 GRAPH_CONV = {"cheb_graph_conv": 0, "graph_conv": 1}
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _fp = C.POINTER(C.c_float)
 
@@ -28,12 +29,12 @@ class StblockDesc(C.Structure):
                 ("droprate", C.c_float), ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32),
                 ("prepacked", C.c_int32), ("defer_reduce", C.c_int32),
                 ("x_bstride", C.c_int64), ("x_index_dev", C.c_void_p), ("x_index_stride", C.c_int64),
-                ("dy_rowstats_ready", C.c_int32), ("reserved2", C.c_int32)]
+                ("dy_rowstats_ready", C.c_int32), ("dtype", C.c_int32)]
 
 
 class LnHook(C.Structure):            # stgcn_ln_hook
     _fields_ = [("rowstat", C.c_void_p), ("U", C.c_void_p), ("S", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
-                ("N", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float), ("pad_", C.c_int32),
+                ("N", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float), ("dtype", C.c_int32),
                 ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p)]
 
 
@@ -63,7 +64,7 @@ class StblockPlan(C.Structure):
 class OutblockDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("c_in", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("c_end", C.c_int32), ("Ko", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float),
-                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("reserved", C.c_int32), ("prepacked", C.c_int32),
+                ("ln_eps", C.c_float), ("need_dx", C.c_int32), ("dtype", C.c_int32), ("prepacked", C.c_int32),
                 ("defer_reduce", C.c_int32)]
 
 

@@ -18,6 +18,8 @@ using namespace stgcn;
 
 namespace {
 thread_local char g_err[512] = "";
+// storage / arithmetic type of the activations of the call being served (set by every entry point from its descriptor)
+thread_local bool g_bf16 = false;
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail(int code, const char* fmt, ...) {
@@ -81,6 +83,25 @@ inline void launch_log(const char* label, const char* kernel, dim3 grid, dim3 bl
         if (e_ != hipSuccess) return fail(STGCN_ERR_LAUNCH, "%s: %s", label, hipGetErrorString(e_)); \
     } while (0)
 
+// launch a kernel whose template arguments mention ET, instantiated for the activation type of the call (g_bf16)
+#define STGCN_LAUNCH_ET(label, st, kernel, grid, block, lds, ...)                                 \
+    do {                                                                                          \
+        if (g_bf16) {                                                                             \
+            using ET = bf16;                                                                      \
+            STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
+        } else {                                                                                  \
+            using ET = float;                                                                     \
+            STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
+        }                                                                                         \
+    } while (0)
+// value of an expression that mentions ET (e.g. wg_capacity of a kernel instantiation)
+#define STGCN_ET_VALUE(expr) (g_bf16 ? [&] { using ET = bf16; return (expr); }() : [&] { using ET = float; return (expr); }())
+// stage-per-launch kernels of round 1 that have no bf16 variant (the bf16 configurations run the fused paths)
+#define STGCN_F32_ONLY(what)                                                                      \
+    do {                                                                                          \
+        if (g_bf16) return fail(STGCN_ERR_UNSUPPORTED, "%s: no bf16 variant (bf16 blocks need the fused time-stepping kernels)", what); \
+    } while (0)
+
 // ---- side stream ----------------------------------------------------------------------------------------------------
 // The weight-gradient kernels of a backward call depend only on dZ, not on the data-gradient chain that follows it, and
 // both are latency-bound launches of ~1 workgroup per CU, so they could run beside each other.  side_fork(st) returns a
@@ -135,6 +156,7 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (d->graph_conv == STGCN_GC_CHEB && d->Ks > 8) return fail(STGCN_ERR_UNSUPPORTED, "Ks=%d > 8", d->Ks);
     if ((d->c_in & 3) != 0 && d->Kt * d->c_in > 16)
         return fail(STGCN_ERR_UNSUPPORTED, "c_in=%d: input channels must be a multiple of 4 unless Kt*c_in <= 16", d->c_in);
+    if (d->dtype != STGCN_DTYPE_F32 && d->dtype != STGCN_DTYPE_BF16) return fail(STGCN_ERR_INVALID, "dtype must be STGCN_DTYPE_F32 or STGCN_DTYPE_BF16");
     if (d->x_bstride < 0 || ((d->x_bstride != 0 || d->x_index_dev) && d->need_dx))
         return fail(STGCN_ERR_INVALID, "strided / indexed input windows (x_bstride, x_index_dev) need need_dx = 0 and x_bstride >= 0");
     return STGCN_OK;
@@ -257,7 +279,7 @@ int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st
     const int n4 = ln.n / 4;
     ln.per = 1024;                                   // float4 columns per workgroup (4 per thread)
     const dim3 grid(cdiv(n4, ln.per), (unsigned)slabs), blk(kThreads);
-    STGCN_LAUNCH(label, st, ln_norm_kernel, grid, blk, 64, ln);
+    STGCN_LAUNCH_ET(label, st, (ln_norm_kernel<ET>), grid, blk, 64, ln);
     return STGCN_OK;
 }
 
@@ -273,10 +295,10 @@ int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st
         const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, tr) * sizeof(float);
         int cap;
         switch (tr) {
-            case 16: cap = wg_capacity(tconv_fwd_kernel<NT, 1, 4>, 256, lds); break;
-            case 32: cap = wg_capacity(tconv_fwd_kernel<NT, 2, 4>, 256, lds); break;
-            case 48: cap = wg_capacity(tconv_fwd_kernel<NT, 3, 4>, 256, lds); break;
-            default: cap = wg_capacity(tconv_fwd_kernel<NT, 4, 8>, 512, lds); break;
+            case 16: cap = STGCN_ET_VALUE(wg_capacity(tconv_fwd_kernel<NT, 1, 4, ET>, 256, lds)); break;
+            case 32: cap = STGCN_ET_VALUE(wg_capacity(tconv_fwd_kernel<NT, 2, 4, ET>, 256, lds)); break;
+            case 48: cap = STGCN_ET_VALUE(wg_capacity(tconv_fwd_kernel<NT, 3, 4, ET>, 256, lds)); break;
+            default: cap = STGCN_ET_VALUE(wg_capacity(tconv_fwd_kernel<NT, 4, 8, ET>, 512, lds)); break;
         }
         const int r = rounds_of(cdiv(a.ts.rows, tr), cap);
         if (force_tr ? tr == force_tr : r < best_rounds) {
@@ -289,10 +311,10 @@ int launch_tconv_fwd_nt(const char* label, const TconvFwdArgs& a, hipStream_t st
     const dim3 grid(cdiv(a.ts.rows, best));
     const size_t lds = (size_t)tile_lds_floats(2 * a.Cout, best) * sizeof(float);
     switch (best) {
-        case 16: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 1, 4>), grid, dim3(256), lds, a); break;
-        case 32: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 2, 4>), grid, dim3(256), lds, a); break;
-        case 48: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 3, 4>), grid, dim3(256), lds, a); break;
-        default: STGCN_LAUNCH(label, st, (tconv_fwd_kernel<NT, 4, 8>), grid, dim3(512), lds, a); break;
+        case 16: STGCN_LAUNCH_ET(label, st, (tconv_fwd_kernel<NT, 1, 4, ET>), grid, dim3(256), lds, a); break;
+        case 32: STGCN_LAUNCH_ET(label, st, (tconv_fwd_kernel<NT, 2, 4, ET>), grid, dim3(256), lds, a); break;
+        case 48: STGCN_LAUNCH_ET(label, st, (tconv_fwd_kernel<NT, 3, 4, ET>), grid, dim3(256), lds, a); break;
+        default: STGCN_LAUNCH_ET(label, st, (tconv_fwd_kernel<NT, 4, 8, ET>), grid, dim3(512), lds, a); break;
     }
     return STGCN_OK;
 }
@@ -318,7 +340,7 @@ template <bool PLAIN>
 int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {
     constexpr int TM = 2, KC = 4;
     const size_t lds = (size_t)(tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TM) + 16) * sizeof(float);   // + 16: reduction words of the fused staging
-    STGCN_LAUNCH(label, st, (tconv_fwd4_kernel<TM, KC, PLAIN>), dim3(cdiv(aa.f.ts.rows, 16 * TM)), dim3(512), lds, aa);
+    STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<TM, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 16 * TM)), dim3(512), lds, aa);
     return STGCN_OK;
 }
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
@@ -439,6 +461,7 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
 }
 
 int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
+    STGCN_F32_ONLY("tiled graph conv");
     if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
     if (a.Ks > 1 && !a.Xk) return fail(STGCN_ERR_INVALID, "tiled graph conv needs the X_k buffers");
     const long ks = a.slabs * a.N * 16;
@@ -475,6 +498,7 @@ int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
 // backward: row pass (g_k, parameter-gradient partials), then dA = sum_k T_k(L^T) g_k by the Clenshaw recurrence
 //     b_K = g_K ; b_k = g_k + 2 L^T b_{k+1} - b_{k+2} (in place over g_k) ; dA = g_0 + L^T b_1 - b_2
 int launch_gconv_bwd_tiled(const GconvBwdArgs& a, hipStream_t st) {
+    STGCN_F32_ONLY("tiled graph conv");
     if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
     if (!a.Gk || a.wgs < 1 || a.tiles_per_wg < 1) return fail(STGCN_ERR_INVALID, "tiled graph-conv backward: missing workspace / geometry");
     const long ks = a.slabs * a.N * 16;
@@ -548,7 +572,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
-    if (g_slab_gc_precision > 0 && a.Ks > 1 && g.maxq <= 3 && gs16_np32(a.N) * 2 <= 4 * g.waves * 64) {   // operator products on the bf16 matrix cores (bf16x3; four tiles per wave would spill: those graphs keep the fp32 kernel)
+    if (!g_bf16 && g_slab_gc_precision > 0 && a.Ks > 1 && g.maxq <= 3 && gs16_np32(a.N) * 2 <= 4 * g.waves * 64) {   // operator products on the bf16 matrix cores (bf16x3; four tiles per wave would spill: those graphs keep the fp32 kernel)
         const size_t lds16 = gconv_fwd16_lds_bytes(a.NP, a.N);
         if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<1, 16>), grid, blk, lds16, a);
         else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd16_kernel<2, 8>), grid, blk, lds16, a);
@@ -556,15 +580,16 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
         return STGCN_OK;
     }
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
-    if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<1, 16>), grid, blk, lds, a);
-    else if (g.maxq <= 2) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<2, 8>), grid, blk, lds, a);
-    else if (g.maxq <= 3) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<3, 8>), grid, blk, lds, a);
-    else if (g.maxq <= 4) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_kernel<4, 8>), grid, blk, lds, a);
+    if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<1, 16, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<3, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<4, 8, ET>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
 
 int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipStream_t st) {
+    STGCN_F32_ONLY(label);
     const long tiles = cdiv(a.ts.rows, kTileRows);
     const dim3 grid((unsigned)tiles);
     const size_t lds = kTileLdsFloats * sizeof(float);
@@ -593,10 +618,10 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
-    if (g.maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<1, 16>), grid, blk, lds, a);
-    else if (g.maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<2, 8>), grid, blk, lds, a);
-    else if (g.maxq <= 3) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<3, 8>), grid, blk, lds, a);
-    else if (g.maxq <= 4) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd_kernel<4, 8>), grid, blk, lds, a);
+    if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<1, 16, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<2, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<3, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<4, 8, ET>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
@@ -604,16 +629,16 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
 template <int MTW>
 int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     const dim3 grid(w.chunks, w.mchunks), blk(kThreads * kWgradGroups);   // (16-byte im2col loads: c_in % 4 == 0, checked by the caller)
-    if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 2, true>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
-    else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<MTW, 4, true>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
+    if (a.NC == 128) STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<MTW, 2, true, ET>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
+    else STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<MTW, 4, true, ET>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
     return STGCN_OK;
 }
 int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     if (a.NC != 128 && a.NC != 256) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient with %d output channels", a.NC);
     if ((a.ts.C & 3) != 0) {   // scalar im2col loads: check_desc only admits such inputs with Kt*c_in <= 16, i.e. ONE m-tile
         if (w.MTW != 1) return fail(STGCN_ERR_UNSUPPORTED, "weight gradient: c_in=%d needs Kt*c_in <= 16", a.ts.C);
-        if (a.NC == 128) STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<1, 2, false>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 2), a);
-        else STGCN_LAUNCH(label, st, (tconv_bwd_weight_kernel<1, 4, false>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 4), a);
+        if (a.NC == 128) STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<1, 2, false, ET>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 2), a);
+        else STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<1, 4, false, ET>), dim3(w.chunks, w.mchunks), dim3(kThreads * kWgradGroups), wgrad_lds_bytes(1, 4), a);
         return STGCN_OK;
     }
     switch (w.MTW) {
@@ -633,8 +658,8 @@ int launch_wgrad_pair(const char* label, const TconvBwdWeightArgs& a1, const Wgr
                       hipStream_t st) {
     const int n1 = w1.chunks * w1.mchunks, n2 = w2.chunks * w2.mchunks;
     const size_t l1 = wgrad_lds_bytes(4, 4), l2 = wgrad_lds_bytes(4, 2);
-    STGCN_LAUNCH(label, st, (wgrad_pair_kernel<4, 4, 4, 2>), dim3((unsigned)(n1 + n2)), dim3(kThreads * kWgradGroups), l1 > l2 ? l1 : l2, a1, n1,
-                 w1.mchunks, a2, n2, w2.mchunks);
+    STGCN_LAUNCH_ET(label, st, (wgrad_pair_kernel<4, 4, 4, 2, ET>), dim3((unsigned)(n1 + n2)), dim3(kThreads * kWgradGroups), l1 > l2 ? l1 : l2, a1, n1,
+                    w1.mchunks, a2, n2, w2.mchunks);
     return STGCN_OK;
 }
 
@@ -778,14 +803,16 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->y_floats = v.rows2 * d->c2;
     int64_t o = 0;
     auto take = [&](int64_t n) { int64_t at = o; o += rup(n, 64); return at; };   // 256-byte aligned carve
+    const bool bf = d->dtype == STGCN_DTYPE_BF16;
+    auto act = [&](int64_t n) { return bf ? (n + 1) / 2 : n; };   // 4-byte units of an activation tensor of n elements
     p->recompute_tc1 = (d->Kt * d->c_in <= 16) ? 1 : 0;   // K <= 16: recomputing Z in backward beats storing 2 x rows1 x c0
-    p->sv_U1 = take(p->recompute_tc1 ? 0 : v.rows1 * d->c0);
-    p->sv_S1 = take(p->recompute_tc1 ? 0 : v.rows1 * d->c0);
-    p->sv_A = take(v.rows1 * d->c1);
-    p->sv_Xk = take((int64_t)(v.terms - 1) * v.rows1 * d->c1);
-    p->sv_G = take(v.rows1 * d->c1);
-    p->sv_U2 = take(v.rows2 * d->c2);
-    p->sv_S2 = take(v.rows2 * d->c2);
+    p->sv_U1 = take(act(p->recompute_tc1 ? 0 : v.rows1 * d->c0));
+    p->sv_S1 = take(act(p->recompute_tc1 ? 0 : v.rows1 * d->c0));
+    p->sv_A = take(act(v.rows1 * d->c1));
+    p->sv_Xk = take((int64_t)(v.terms - 1) * act(v.rows1 * d->c1));
+    p->sv_G = take(act(v.rows1 * d->c1));
+    p->sv_U2 = take(act(v.rows2 * d->c2));
+    p->sv_S2 = take(act(v.rows2 * d->c2));
     p->sv_mean = take(v.slabs2);
     p->sv_rstd = take(v.slabs2);
     p->sv_rowstat = take(2 * v.rows2);
@@ -809,10 +836,10 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_WaDense = take((p->thin_tc1 || k3s) ? (int64_t)d->c0 * d->c1 : 0);
     p->fused_tc1_bwd = bgq.k3;
     p->ws_rowstat_b = take(2 * v.rows2 + 2 * v.slabs2);   // row partials, then the per-slab constants (big slabs only)
-    p->ws_dZ2 = take(v.rows2 * v.NC2);
-    p->ws_dYg = take(v.rows1 * d->c1);
-    p->ws_dA = take(v.rows1 * d->c1);
-    p->ws_dZ1 = take(v.rows1 * v.NC1);
+    p->ws_dZ2 = take(act(v.rows2 * v.NC2));
+    p->ws_dYg = take(act(v.rows1 * d->c1));
+    p->ws_dA = take(act(v.rows1 * d->c1));
+    p->ws_dZ1 = take(act(v.rows1 * v.NC1));
     p->tiled_gc = v.tiled;
     p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
     p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
@@ -928,7 +955,7 @@ int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_param
     memset(h, 0, sizeof(*h));
     h->rowstat = ws + pl.ws_rowstat_b; h->U = saved + pl.sv_U2; h->S = saved + pl.sv_S2; h->gamma = P->ln_w;
     h->mean = saved + pl.sv_mean; h->rstd = saved + pl.sv_rstd;
-    h->N = d->N; h->C = d->c2; h->act = d->act; h->training = d->training; h->droprate = d->droprate;
+    h->N = d->N; h->C = d->c2; h->act = d->act; h->training = d->training; h->droprate = d->droprate; h->dtype = d->dtype;
     h->seed = seed; h->offset = offset; h->offset_dev = offset_dev;
     return STGCN_OK;
 }
@@ -947,6 +974,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     const Derived v = derive(d);
     hipStream_t st = (hipStream_t)stream;
     g_prof_tag = d->reserved;
+    g_bf16 = d->dtype == STGCN_DTYPE_BF16;
 
     rc = d->prepacked ? STGCN_OK : launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
@@ -965,8 +993,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \
         do {                                                                                                  \
-            if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0>), grid, blk, lds, f);   \
-            else STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1>), grid, blk, lds, f);      \
+            if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0, ET>), grid, blk, lds, f);   \
+            else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1, ET>), grid, blk, lds, f);      \
         } while (0)
         if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
 #undef STGCN_TC1_FWD
@@ -1011,9 +1039,9 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4>), grid, dim3(1024), lds, f);      \
-            else if (small) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2>), grid, dim3(512), lds, f); \
-            else STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2>), grid, dim3(512), lds, f);           \
+            if (wide) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4, ET>), grid, dim3(1024), lds, f);      \
+            else if (small) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2, ET>), grid, dim3(512), lds, f); \
+            else STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2, ET>), grid, dim3(512), lds, f);           \
         } while (0)
         if (d->Kt == 2) STGCN_TC2LN(2); else if (d->Kt == 3) STGCN_TC2LN(3); else STGCN_TC2LN(4);
 #undef STGCN_TC2LN

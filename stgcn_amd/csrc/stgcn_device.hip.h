@@ -99,6 +99,204 @@ __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
 }
+
+// ================================================================================================
+// Storage / arithmetic type of the activations ("ET"): float (BASELINE.json configs[0], [1], [3]) or bf16 (configs[2], [4]).
+//   float : fp32 tensors in HBM, exact fp32 matrix products (v_mfma_f32_16x16x4_f32, four per 16-deep product step)
+//   bf16  : every activation / saved tensor / activation gradient that crosses a kernel boundary is stored as bf16 (RNE), every
+//           matrix-product operand is rounded to bf16 where it enters the matrix cores (ONE v_mfma_f32_16x16x16_bf16 per 16-deep step:
+//           a lane's 4 consecutive k values of the "16-chunk" permutation are exactly that instruction's operand layout), and
+//           everything else -- accumulators, gates, LayerNorm statistics and parameters, master weights, gradient partials, the
+//           optimizer -- stays fp32.  oracle/stblock_stages.py restates these rounding points (QuantBf16).
+// Kernels take `typename ET`; tensors keep their `float*` slots in the argument structs (opaque base addresses: the plan sizes
+// them in 4-byte units) and are re-typed with et_ptr<ET>() at the top of the kernel.
+// ================================================================================================
+struct bf16 { unsigned short v; };
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {   // round-to-nearest-even, finite inputs
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// two floats -> two bf16 packed little-endian (v_cvt_pk_bf16_f32 on gfx950; the emulator rounds in software: same RNE result)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+#else
+    return bf16_bits_rne(a) | (bf16_bits_rne(b) << 16);
+#endif
+}
+__device__ __forceinline__ u32x2_t pack_bf16x4(f32x4 v) {
+    u32x2_t r;
+    r[0] = pack_bf16x2(v[0], v[1]);
+    r[1] = pack_bf16x2(v[2], v[3]);
+    return r;
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(u32x2_t r) {
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, r[0] << 16);
+    v[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r[1] << 16);
+    v[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ float bf16_round(float x) { return __builtin_bit_cast(float, bf16_bits_rne(x) << 16); }
+
+template <typename ET> __device__ __forceinline__ const ET* et_ptr(const float* p) { return reinterpret_cast<const ET*>(p); }
+template <typename ET> __device__ __forceinline__ ET* et_ptr(float* p) { return reinterpret_cast<ET*>(p); }
+
+// 4 consecutive elements <-> f32x4 (16-byte / 8-byte accesses), one element <-> float
+__device__ __forceinline__ f32x4 ldx4(const float* p) { return ld4(p); }
+__device__ __forceinline__ f32x4 ldx4(const bf16* p) { return unpack_bf16x4(*reinterpret_cast<const u32x2_t*>(p)); }
+__device__ __forceinline__ void stx4(float* p, f32x4 v) { st4(p, v); }
+__device__ __forceinline__ void stx4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2_t*>(p) = pack_bf16x4(v); }
+__device__ __forceinline__ float ldx1(const float* p) { return *p; }
+__device__ __forceinline__ float ldx1(const bf16* p) { return __builtin_bit_cast(float, (unsigned)p->v << 16); }
+__device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stx1(bf16* p, float v) { p->v = (unsigned short)bf16_bits_rne(v); }
+// write-through variants (see st4_wt)
+__device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { st4_wt(p, v); }
+__device__ __forceinline__ void stx4_wt(bf16* p, f32x4 v) {
+    const u32x2_t r = pack_bf16x4(v);
+#if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+#else
+    *reinterpret_cast<u32x2_t*>(p) = r;
+#endif
+}
+__device__ __forceinline__ void stx4_wt2(float* p, f32x4 v) { st4_wt2(p, v); }
+__device__ __forceinline__ void stx4_wt2(bf16* p, f32x4 v) {
+    const u32x2_t r = pack_bf16x4(v);
+#if STGCN_WT_STORES >= 2 && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+#else
+    *reinterpret_cast<u32x2_t*>(p) = r;
+#endif
+}
+// the value a tensor of type ET holds after v was stored to it (identity for float): kernels that go on USING a value they also
+// store (row partials of a gradient they write, ..) use the stored value, so that every consumer of the tensor sees one number
+template <typename ET> __device__ __forceinline__ float et_round(float v) {
+    if constexpr (sizeof(ET) == 2) return bf16_round(v);
+    else return v;
+}
+template <typename ET> __device__ __forceinline__ f32x4 et_round4(f32x4 v) {
+    if constexpr (sizeof(ET) == 2) return unpack_bf16x4(pack_bf16x4(v));
+    else return v;
+}
+
+// ---- one 16-deep matrix-product step on a wave's 16 x 16 accumulator tile ----------------------------------------------------------
+// Operand fragments: a lane's 4 consecutive k values (k = 4 * (lane >> 4) + s) of one row (A) / column (B).
+//   Mma<float>: frag = f32x4, mma = 4 x v_mfma_f32_16x16x4_f32 (step s contracts component s)
+//   Mma<bf16> : frag = 4 bf16 (one VGPR pair), mma = 1 x v_mfma_f32_16x16x16_bf16
+template <typename ET> struct Mma;
+template <> struct Mma<float> {
+    typedef f32x4 frag;
+    static __device__ __forceinline__ frag cvt(f32x4 v) { return v; }
+    static __device__ __forceinline__ f32x4 mma(const frag& a, const frag& b, f32x4 c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = mfma4(a[s], b[s], c);
+        return c;
+    }
+    // two accumulators sharing the A operand, MFMAs interleaved step by step (independent chains)
+    static __device__ __forceinline__ void mma_b2(const frag& a, const frag& b0, const frag& b1, f32x4& c0, f32x4& c1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c0 = mfma4(a[s], b0[s], c0);
+            c1 = mfma4(a[s], b1[s], c1);
+        }
+    }
+    // two accumulators sharing the B operand
+    static __device__ __forceinline__ void mma_a2(const frag& a0, const frag& a1, const frag& b, f32x4& c0, f32x4& c1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c0 = mfma4(a0[s], b[s], c0);
+            c1 = mfma4(a1[s], b[s], c1);
+        }
+    }
+    // one product spread over two accumulators (even / odd steps): two dependent chains instead of one
+    static __device__ __forceinline__ void mma_split(const frag& a, const frag& b, f32x4& c0, f32x4& c1) {
+        c0 = mfma4(a[0], b[0], c0);
+        c1 = mfma4(a[1], b[1], c1);
+        c0 = mfma4(a[2], b[2], c0);
+        c1 = mfma4(a[3], b[3], c1);
+    }
+    // two independent products, MFMAs interleaved step by step
+    static __device__ __forceinline__ void mma_2x(const frag& a0, const frag& b0, f32x4& c0, const frag& a1, const frag& b1, f32x4& c1) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c0 = mfma4(a0[s], b0[s], c0);
+            c1 = mfma4(a1[s], b1[s], c1);
+        }
+    }
+    // two products into ONE accumulator, steps interleaved
+    static __device__ __forceinline__ void mma_ab2(const frag& a0, const frag& b0, const frag& a1, const frag& b1, f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            c = mfma4(a0[s], b0[s], c);
+            c = mfma4(a1[s], b1[s], c);
+        }
+    }
+};
+template <> struct Mma<bf16> {
+    typedef s16x4 frag;
+    static __device__ __forceinline__ frag cvt(f32x4 v) { return __builtin_bit_cast(s16x4, pack_bf16x4(v)); }
+    static __device__ __forceinline__ f32x4 mma(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_b2(const frag& a, const frag& b0, const frag& b1, f32x4& c0, f32x4& c1) {
+        c0 = mma(a, b0, c0);
+        c1 = mma(a, b1, c1);
+    }
+    static __device__ __forceinline__ void mma_a2(const frag& a0, const frag& a1, const frag& b, f32x4& c0, f32x4& c1) {
+        c0 = mma(a0, b, c0);
+        c1 = mma(a1, b, c1);
+    }
+    static __device__ __forceinline__ void mma_split(const frag& a, const frag& b, f32x4& c0, f32x4& c1) { c0 = mma(a, b, c0); }
+    static __device__ __forceinline__ void mma_2x(const frag& a0, const frag& b0, f32x4& c0, const frag& a1, const frag& b1, f32x4& c1) {
+        c0 = mma(a0, b0, c0);
+        c1 = mma(a1, b1, c1);
+    }
+    static __device__ __forceinline__ void mma_ab2(const frag& a0, const frag& b0, const frag& a1, const frag& b1, f32x4& c) {
+        c = mma(a0, b0, c);
+        c = mma(a1, b1, c);
+    }
+};
+// acc[i][j] += A_i x B_j over one 16-deep step for a WM x NT block of accumulator tiles (fp32: step-major order, every accumulator
+// sees its 4 MFMAs WM * NT issue slots apart)
+template <typename ET, int WM, int NT>
+__device__ __forceinline__ void mma_tile(f32x4 (&acc)[WM][NT], const f32x4 (&a)[WM], const f32x4 (&b)[NT]) {
+    if constexpr (sizeof(ET) == 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], b[j][s], acc[i][j]);
+    } else {
+        typename Mma<ET>::frag fa[WM], fb[NT];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) fa[i] = Mma<ET>::cvt(a[i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = Mma<ET>::cvt(b[j]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Mma<ET>::mma(fa[i], fb[j], acc[i][j]);
+    }
+}
+// four scalars gathered into a fragment (strided LDS reads)
+__device__ __forceinline__ f32x4 gather4(const float* p, int stride) {
+    f32x4 v;
+    v[0] = p[0];
+    v[1] = p[stride];
+    v[2] = p[2 * stride];
+    v[3] = p[3 * stride];
+    return v;
+}
 // XCD-aware work placement (speed only, never correctness): workgroup b is observed to run on XCD b % 8 and every XCD
 // has its own L2, so work items that re-read the same rows (the Kt taps of neighbouring time steps, the m-chunks of a
 // weight-gradient row chunk) are given to ONE XCD as a contiguous range: workgroup b of n takes item

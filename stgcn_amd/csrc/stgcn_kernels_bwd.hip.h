@@ -221,6 +221,7 @@ struct LnBwdArgs {
     const uint64_t* offset_dev;
 };
 
+template <typename ET>
 __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
     const int n4 = a.n >> 2, c4n = a.C >> 2;
     const long total = a.slabs * (long)n4;
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
     float s1 = 0.f, s2 = 0.f;
     if (valid) {
         const size_t base = (size_t)slab * a.n + 4 * (size_t)q;
-        f32x4 dy = ld4(a.dy + base);
-        const f32x4 u = ld4(a.U + base), s = ld4(a.S + base), ga = ld4(a.gamma + 4 * q);
+        f32x4 dy = ldx4(et_ptr<ET>(a.dy) + base);
+        const f32x4 u = ldx4(et_ptr<ET>(a.U) + base), s = ldx4(et_ptr<ET>(a.S) + base), ga = ld4(a.gamma + 4 * q);
         const float mean = a.mean[slab], rstd = a.rstd[slab];
         if (a.training) {
             const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
@@ -512,8 +513,9 @@ struct GconvBwdArgs {
     int wgs;             // BwdGeom::gc_count
 };
 
-template <int MAXQ, int MAXW>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)
+template <int MAXQ, int MAXW, typename ET>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)
 __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
+    typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int THREADS = blockDim.x, NW = THREADS >> 6, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int P = a.parts, prt = (int)(blockIdx.x % (unsigned)P);
@@ -524,13 +526,13 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
     float* const dYs = stgcn_smem + Ks * 16 * LDX; // [NP][LDY] row major
 
     // ---- stage dY (row major) and all X_k (transposed) -----------------------------------------
-    const float* dYsl = a.dY + (size_t)slab * N * 16;
+    const ET* dYsl = et_ptr<ET>(a.dY) + (size_t)slab * N * 16;
     for (int idx = tid; idx < NP * 4; idx += THREADS) {
         const int n = idx >> 2, c4 = idx & 3;
-        st4(dYs + n * LDY + c4 * 4, n < N ? ld4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
+        st4(dYs + n * LDY + c4 * 4, n < N ? ldx4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
         for (int k = 0; k < Ks; ++k) {
-            const float* Xsl = (k == 0 ? a.X0 : a.Xk + (size_t)(k - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
-            const f32x4 v = n < N ? ld4(Xsl + (size_t)n * 16 + c4 * 4) : zero4();
+            const ET* Xsl = (k == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(k - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
+            const f32x4 v = n < N ? ldx4(Xsl + (size_t)n * 16 + c4 * 4) : zero4();
 #pragma unroll
             for (int i = 0; i < 4; ++i) GT0[(k * 16 + c4 * 4 + i) * LDX + n] = v[i];
         }
@@ -546,10 +548,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
             if (kk < Ks) af = ld4(GT0 + (kk * 16 + l15) * LDX + kc * 16 + 4 * g);
             else { af[0] = 1.f; af[1] = 1.f; af[2] = 1.f; af[3] = 1.f; }
             const float* yb = dYs + (kc * 16 + 4 * g) * LDY + l15;
-            c0 = mfma4(af[0], yb[0], c0);
-            c1 = mfma4(af[1], yb[LDY], c1);
-            c0 = mfma4(af[2], yb[2 * LDY], c0);
-            c1 = mfma4(af[3], yb[3 * LDY], c1);
+            MM::mma_split(MM::cvt(af), MM::cvt(gather4(yb, LDY)), c0, c1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[kk * 256 + (4 * g + r) * 16 + l15] = c0[r] + c1[r];
@@ -563,9 +562,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
         if (!(a.kipf && k == 0)) wf = ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g);
         for (int ht = w; ht < HT; ht += NW) {
             const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
-            f32x4 d = zero4();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) d = mfma4(af[s], wf[s], d);
+            const f32x4 d = MM::mma(MM::cvt(af), MM::cvt(wf), zero4());
             st4(GT0 + (k * 16 + l15) * LDX + ht * 16 + 4 * g, d);      // D[h = 4g + r][i = l15]
         }
     }
@@ -599,8 +596,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
             n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
         }
         for (int kc = 0; kc < KCH; ++kc) {
-            const f32x4 af1 = ld4(G1 + l15 * LDX + kc * 16 + 4 * g);
-            const f32x4 af2 = two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4();
+            const typename MM::frag af1 = MM::cvt(ld4(G1 + l15 * LDX + kc * 16 + 4 * g));
+            const typename MM::frag af2 = MM::cvt(two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4());
             f32x4 b1[MAXQ], b2[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
@@ -616,11 +613,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
                 if (wave + WAVES * q < HT) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc1[q] = mfma4(af1[s], b1[q][s], acc1[q]);
-                        if (two) acc2[q] = mfma4(af2[s], b2[q][s], acc2[q]);
-                    }
+                    if (two) MM::mma_2x(af1, MM::cvt(b1[q]), acc1[q], af2, MM::cvt(b2[q]), acc2[q]);
+                    else acc1[q] = MM::mma(af1, MM::cvt(b1[q]), acc1[q]);
                 }
             }
         }
@@ -634,7 +628,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + (acc1[q][r] + acc2[q][r]) + y[r];
-            st4_wt(a.dA + ((size_t)slab * N + h) * 16 + 4 * g, o);
+            stx4_wt(et_ptr<ET>(a.dA) + ((size_t)slab * N + h) * 16 + 4 * g, o);
         }
     }
 }
@@ -799,7 +793,9 @@ struct ThinBwdArgs {
     int c0, act;
 };
 
+template <typename ET>
 __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
+    typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int c0 = a.c0, NC = 2 * c0, LDA = 20, LDH = c0 + 4, LDZ = NC + 4, LDX = 20;
@@ -826,7 +822,9 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         wqr[k] = k < K ? ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4) : zero4();
     }
     const f32x4 bu = ld4(a.bias + 4 * c4), bqv = ld4(a.bias + c0 + 4 * c4);
-    const float* const xsrc = tap_base(a.ts);
+    const ET* const xsrc = tap_base<ET>(a.ts);
+    const ET* const dA_ = et_ptr<ET>(a.dA);
+    ET* const dZ_ = et_ptr<ET>(a.dZ);
     const size_t xbs = (size_t)tap_bstride(a.ts);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * kTileRows;
@@ -834,13 +832,13 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         // dA rows (one 16-byte load per thread) and the K valid taps of x (one scalar load for the first 64*K threads) are
         // requested together; the 16 - K padding columns of the im2col tile are zero-filled meanwhile
         const int ra = tid >> 2, qa = tid & 3;
-        const f32x4 dav = row0 + ra < a.rows ? ld4(a.dA + (size_t)(row0 + ra) * 16 + 4 * qa) : zero4();
+        const f32x4 dav = row0 + ra < a.rows ? ldx4(dA_ + (size_t)(row0 + ra) * 16 + 4 * qa) : zero4();
         float xv0 = 0.f;
         const int rx = tid / K, kx = tid - rx * K;
         if (tid < kTileRows * K && row0 + rx < a.rows) {
             const unsigned Ru = (unsigned)(row0 + rx), b = Ru / per_b, rem = Ru - b * per_b;
             const int tap = kx / a.ts.C, ch = kx - tap * a.ts.C;
-            xv0 = xsrc[((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+            xv0 = ldx1(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
         }
         for (int idx = tid; idx < kTileRows * (16 - K); idx += kThreads) {
             const int r = idx / (16 - K), k = K + idx - r * (16 - K);
@@ -857,7 +855,7 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         f32x4 acc[4][1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][0] = zero4();
-        seg_mma<4, 1>(acc, dAt, LDA, 0, 1, a.WaT, 0, 1, wave, 4);
+        seg_mma<4, 1, ET>(acc, dAt, LDA, 0, 1, a.WaT, 0, 1, wave, 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -892,8 +890,8 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
                     h[i] = gate_fwd(u[i], sg, a.act);
                 }
                 if (a.dZ) {
-                    st4_wt(a.dZ + (size_t)R * NC + 4 * c4, du);
-                    st4_wt(a.dZ + (size_t)R * NC + c0 + 4 * c4, dq);
+                    stx4_wt(dZ_ + (size_t)R * NC + 4 * c4, du);
+                    stx4_wt(dZ_ + (size_t)R * NC + c0 + 4 * c4, dq);
                 }
             }
             st4(Ht + row * LDH + 4 * c4, h);
@@ -906,13 +904,19 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rbase = i * 16 + 4 * g;
+            if constexpr (sizeof(ET) == 4) {
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                const int row = rbase + sx;
-                wacc = mfma4(Ht[row * LDH + wave * 16 + l15], dAt[row * LDA + l15], wacc);
-                const float xa = xt[row * LDX + l15];
-                gacc[0] = mfma4(xa, Zt[row * LDZ + (2 * wave) * 16 + l15], gacc[0]);
-                gacc[1] = mfma4(xa, Zt[row * LDZ + (2 * wave + 1) * 16 + l15], gacc[1]);
+                for (int sx = 0; sx < 4; ++sx) {
+                    const int row = rbase + sx;
+                    wacc = mfma4(Ht[row * LDH + wave * 16 + l15], dAt[row * LDA + l15], wacc);
+                    const float xa = xt[row * LDX + l15];
+                    gacc[0] = mfma4(xa, Zt[row * LDZ + (2 * wave) * 16 + l15], gacc[0]);
+                    gacc[1] = mfma4(xa, Zt[row * LDZ + (2 * wave + 1) * 16 + l15], gacc[1]);
+                }
+            } else {
+                wacc = MM::mma(MM::cvt(gather4(Ht + rbase * LDH + wave * 16 + l15, LDH)), MM::cvt(gather4(dAt + rbase * LDA + l15, LDA)), wacc);
+                MM::mma_b2(MM::cvt(gather4(xt + rbase * LDX + l15, LDX)), MM::cvt(gather4(Zt + rbase * LDZ + (2 * wave) * 16 + l15, LDZ)),
+                           MM::cvt(gather4(Zt + rbase * LDZ + (2 * wave + 1) * 16 + l15, LDZ)), gacc[0], gacc[1]);
             }
         }
     }
@@ -974,7 +978,7 @@ constexpr size_t wgrad_lds_bytes(int MTW, int NTW) {
 // VEC: the input channel count is a multiple of 4 (16-byte im2col loads); otherwise scalar loads (narrow first layer).
 // The body is a device function of (flat workgroup index, workgroup count, m chunks) so that two independent weight gradients can
 // share ONE launch (wgrad_pair_kernel below: an empty launch costs 4.6 us inside the replayed step).
-template <int MTW, int NTW, bool VEC>
+template <int MTW, int NTW, bool VEC, typename ET>
 __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& a, int flat_wg, int n_wgs, int mchunks) {
     extern __shared__ float stgcn_smem[];
     constexpr int GROUPS = kWgradGroups;
@@ -996,7 +1000,8 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
     const int K = a.ts.taps * a.ts.C;
     const unsigned per_b = (unsigned)(a.ts.Tdst * a.ts.N);   // rows < 2^31 (checked on the host): 32-bit divisions only
     const int csh = pow2_shift(a.ts.C);
-    const float* const xsrc = tap_base(a.ts);
+    const ET* const xsrc = tap_base<ET>(a.ts);
+    const ET* const dZ_ = et_ptr<ET>(a.dZ);
     const size_t xbs = (size_t)tap_bstride(a.ts);
 
     // staging registers (next step's tiles are fetched while the current step's MFMAs run)
@@ -1019,7 +1024,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
                     if (R < crow1 && kidx < K) {
                         const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                         const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
-                        v = ld4(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+                        v = ldx4(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
                     }
                 }
                 creg[i] = v;
@@ -1036,7 +1041,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
                     if (R < crow1 && kidx < K) {
                         const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                         const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
-                        v = xsrc[((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch];
+                        v = ldx1(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
                     }
                 }
                 cs[i] = v;
@@ -1047,7 +1052,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
             const int idx = tid + z * kThreads;
             const int r = idx / (NC / 4), q = idx - r * (NC / 4);
             const long R = r0 + r;
-            zreg[z] = R < crow1 ? ld4(a.dZ + (size_t)R * NC + 4 * q) : zero4();
+            zreg[z] = R < crow1 ? ldx4(dZ_ + (size_t)R * NC + 4 * q) : zero4();
         }
     };
     auto store_regs = [&]() {
@@ -1103,18 +1108,31 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
         // g = 0..3 read rows 4 apart, which the LDC/LDZ = 4 (mod 8) padding spreads over distinct banks
 #pragma unroll 1
         for (int k16 = 0; k16 < SR / 16; ++k16) {
+            if constexpr (sizeof(ET) == 4) {
 #pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                const int row = k16 * 16 + 4 * g + sx;
-                float av[MTW], bv[NTW];
+                for (int sx = 0; sx < 4; ++sx) {
+                    const int row = k16 * 16 + 4 * g + sx;
+                    float av[MTW], bv[NTW];
 #pragma unroll
-                for (int i = 0; i < MTW; ++i) av[i] = ct[row * LDC + i * 16 + l15];
+                    for (int i = 0; i < MTW; ++i) av[i] = ct[row * LDC + i * 16 + l15];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bv[j] = zt[row * LDZ + (wave * NTW + j) * 16 + l15];
+                    for (int j = 0; j < NTW; ++j) bv[j] = zt[row * LDZ + (wave * NTW + j) * 16 + l15];
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+                }
+            } else {
+                const int row = k16 * 16 + 4 * g;
+                typename Mma<ET>::frag fa[MTW], fb[NTW];
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) fa[i] = Mma<ET>::cvt(gather4(ct + row * LDC + i * 16 + l15, LDC));
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) fb[j] = Mma<ET>::cvt(gather4(zt + row * LDZ + (wave * NTW + j) * 16 + l15, LDZ));
 #pragma unroll
                 for (int i = 0; i < MTW; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[i][j] = mfma4(av[i], bv[j], acc[i][j]);
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = Mma<ET>::mma(fa[i], fb[j], acc[i][j]);
             }
         }
     }
@@ -1167,15 +1185,15 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
     }
     STGCN_PHASE(3, 3);
 }
-template <int MTW, int NTW, bool VEC>
+template <int MTW, int NTW, bool VEC, typename ET>
 __global__ __launch_bounds__(256 * kWgradGroups) void tconv_bwd_weight_kernel(TconvBwdWeightArgs a) {
-    tconv_bwd_weight_body<MTW, NTW, VEC>(a, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), (int)gridDim.y);
+    tconv_bwd_weight_body<MTW, NTW, VEC, ET>(a, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y), (int)gridDim.y);
 }
 // two weight gradients of one backward call in one launch: workgroups [0, n1) run the first, [n1, n1 + n2) the second
-template <int MTW1, int NTW1, int MTW2, int NTW2>
+template <int MTW1, int NTW1, int MTW2, int NTW2, typename ET>
 __global__ __launch_bounds__(256 * kWgradGroups) void wgrad_pair_kernel(TconvBwdWeightArgs a1, int n1, int mc1, TconvBwdWeightArgs a2, int n2, int mc2) {
-    if ((int)blockIdx.x < n1) tconv_bwd_weight_body<MTW1, NTW1, true>(a1, (int)blockIdx.x, n1, mc1);     // (uniform per workgroup)
-    else tconv_bwd_weight_body<MTW2, NTW2, true>(a2, (int)blockIdx.x - n1, n2, mc2);
+    if ((int)blockIdx.x < n1) tconv_bwd_weight_body<MTW1, NTW1, true, ET>(a1, (int)blockIdx.x, n1, mc1);     // (uniform per workgroup)
+    else tconv_bwd_weight_body<MTW2, NTW2, true, ET>(a2, (int)blockIdx.x - n1, n2, mc2);
 }
 
 // ================================================================================================

@@ -154,7 +154,9 @@ struct TapSrc {
     const long* idx_dev;
     long idx_stride;
 };
-__device__ __forceinline__ const float* tap_base(const TapSrc& ts) { return ts.src + (ts.idx_dev ? *ts.idx_dev * ts.idx_stride : 0); }
+// (idx_stride counts ELEMENTS of the source's storage type)
+template <typename ET = float>
+__device__ __forceinline__ const ET* tap_base(const TapSrc& ts) { return et_ptr<ET>(ts.src) + (ts.idx_dev ? *ts.idx_dev * ts.idx_stride : 0); }
 __device__ __forceinline__ long tap_bstride(const TapSrc& ts) { return ts.bstride ? ts.bstride : (long)ts.Tsrc * ts.N; }
 
 // per-tile row bookkeeping in LDS: rowbase[r] = flat source row of tap 0, rowt[r] = t (or -2^20 if the
@@ -178,11 +180,11 @@ __device__ __forceinline__ void tile_rowinfo(const TapSrc& ts, long tile_row0, i
 }
 
 // Stage columns [k0, k0 + kseg) of the implicit matrix for the TR rows of the tile into At[TR][lda].
-template <int TR = kTileRows, int THREADS = kThreads>
+template <int TR = kTileRows, int THREADS = kThreads, typename ET = float>
 __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                   float* At, int lda) {
     const int K = ts.taps * ts.C, csh = pow2_shift(ts.C);
-    const float* const src = tap_base(ts);
+    const ET* const src = tap_base<ET>(ts);
     if ((ts.C & 3) == 0) {
         const int q4 = kseg >> 2, qsh = pow2_shift(q4);
         for (int idx = threadIdx.x; idx < TR * q4; idx += THREADS) {
@@ -192,7 +194,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             if (kidx < K) {
                 const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = ld4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+                if (tt >= 0 && tt < ts.Tsrc) v = ldx4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
             st4(At + r * lda + 4 * q, v);
         }
@@ -209,7 +211,7 @@ __device__ __forceinline__ void tile_load_segment(const TapSrc& ts, const int* r
             const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
             const int tt = rowt[r] + ts.dir * tap;
             float v = 0.f;
-            if (tt >= 0 && tt < ts.Tsrc) v = src[((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch];
+            if (tt >= 0 && tt < ts.Tsrc) v = ldx1(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             At[r * lda + q] = v;
         }
     }
@@ -246,12 +248,12 @@ template <int TR, int THREADS>
 struct TileRegs {
     f32x4 v[(TR * (kSegMax / 4) + THREADS - 1) / THREADS];
 };
-template <int TR, int THREADS>
+template <int TR, int THREADS, typename ET = float>
 __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const int* rowbase, const int* rowt, int k0, int kseg,
                                                       TileRegs<TR, THREADS>& regs) {
     constexpr int NV = (TR * (kSegMax / 4) + THREADS - 1) / THREADS;
     const int K = ts.taps * ts.C, q4 = kseg >> 2, qsh = pow2_shift(q4), csh = pow2_shift(ts.C);
-    const float* const src = tap_base(ts);
+    const ET* const src = tap_base<ET>(ts);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = threadIdx.x + i * THREADS;
@@ -262,7 +264,7 @@ __device__ __forceinline__ void tile_prefetch_segment(const TapSrc& ts, const in
             if (kidx < K) {
                 const int tap = fast_div(kidx, ts.C, csh), ch = kidx - tap * ts.C;
                 const int tt = rowt[r] + ts.dir * tap;
-                if (tt >= 0 && tt < ts.Tsrc) v = ld4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
+                if (tt >= 0 && tt < ts.Tsrc) v = ldx4(src + ((size_t)(rowbase[r] + ts.dir * tap * ts.N)) * ts.C + ch);
             }
         }
         regs.v[i] = v;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void seg_load_weights(SegWeights<NT>& w, int kcs, con
         for (int j = 0; j < NT; ++j)
             w.b[kc][j] = kc < kcs ? ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
 }
-template <int WM, int NT>
+template <int WM, int NT, typename ET = float>
 __device__ __forceinline__ void seg_mma_w(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int kcs, const SegWeights<NT>& w) {
     const int lane = threadIdx.x & 63;
     const float* arow = At + (mt0 * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
@@ -307,18 +309,13 @@ __device__ __forceinline__ void seg_mma_w(f32x4 (&acc)[WM][NT], const float* At,
             f32x4 a[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], w.b[kc][j][s], acc[i][j]);
+            mma_tile<ET, WM, NT>(acc, a, w.b[kc]);
         }
     }
 }
 
 // acc[i][j] += A_tile(m-tile mt0+i) x Wp(n-tile nt0 + j*nts) over kcs 16-wide chunks of this segment.
-template <int WM, int NT>
+template <int WM, int NT, typename ET = float>
 __device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int kcs, const float* Wp,
                                         int kc0, int KCH, int nt0, int nts) {
     const int lane = threadIdx.x & 63;
@@ -329,12 +326,7 @@ __device__ __forceinline__ void seg_mma(f32x4 (&acc)[WM][NT], const float* At, i
         for (int j = 0; j < NT; ++j) b[j] = ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc0 + kc) * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], b[j][s], acc[i][j]);
+        mma_tile<ET, WM, NT>(acc, a, b);
     }
 }
 
@@ -352,7 +344,7 @@ __device__ __forceinline__ void pre_load_weights(PreW<NT, KMAX>& w, const float*
 #pragma unroll
         for (int j = 0; j < NT; ++j) w.b[kc][j] = kc < KCH ? ld4(Wp + ((size_t)((nt0 + j * nts) * KCH + kc) * 64 + lane) * 4) : zero4();
 }
-template <int WM, int NT, int KMAX>
+template <int WM, int NT, int KMAX, typename ET = float>
 __device__ __forceinline__ void pre_mma(f32x4 (&acc)[WM][NT], const float* At, int lda, int mt0, int KCH, const PreW<NT, KMAX>& w) {
     const int lane = threadIdx.x & 63;
     const float* arow = At + (mt0 * 16 + (lane & 15)) * lda + 4 * (lane >> 4);
@@ -362,12 +354,7 @@ __device__ __forceinline__ void pre_mma(f32x4 (&acc)[WM][NT], const float* At, i
             f32x4 a[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) a[i] = ld4(arow + i * 16 * lda + kc * 16);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(a[i][s], w.b[kc][j][s], acc[i][j]);
+            mma_tile<ET, WM, NT>(acc, a, w.b[kc]);
         }
     }
 }
@@ -403,9 +390,14 @@ struct TconvFwdArgs {
 
 // TM = m-tiles (16 rows) per tile; WAVES = 4 or 8.  With 8 waves the two halves of the workgroup (wave >> 2) own
 // the two halves of the tile's rows: twice the waves in flight per CU at the same LDS footprint.
-template <int NT, int TM, int WAVES>
+template <int NT, int TM, int WAVES, typename ET>
 __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
     constexpr int TR = TM * 16, THREADS = WAVES * 64, WM = TM / (WAVES / 4);   // rows per tile, m-tiles per wave
+    typedef Mma<ET> MM;
+    ET* const U_ = et_ptr<ET>(a.U);
+    ET* const S_ = et_ptr<ET>(a.S);
+    ET* const H_ = et_ptr<ET>(a.H);
+    ET* const A_ = et_ptr<ET>(a.A);
     extern __shared__ float stgcn_smem[];
     int* rowbase = reinterpret_cast<int*>(stgcn_smem);
     int* rowt = rowbase + 64;
@@ -432,16 +424,16 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
         // tile loads of segment s+1 are issued and stay in flight while the MFMAs of segment s run.
         TileRegs<TR, THREADS> regs;
         int kseg = KP < kSegMax ? KP : kSegMax;
-        tile_prefetch_segment<TR, THREADS>(a.ts, rowbase, rowt, 0, kseg, regs);
+        tile_prefetch_segment<TR, THREADS, ET>(a.ts, rowbase, rowt, 0, kseg, regs);
         tile_commit_segment<TR, THREADS>(kseg, regs, At, kseg + 4);
         for (int k0 = 0; k0 < KP; k0 += kSegMax) {
             kseg = (KP - k0) < kSegMax ? (KP - k0) : kSegMax;
             const int kn = k0 + kSegMax, ksegn = (KP - kn) < kSegMax ? (KP - kn) : kSegMax;
             SegWeights<NT> w;
             seg_load_weights<NT>(w, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
-            if (kn < KP) tile_prefetch_segment<TR, THREADS>(a.ts, rowbase, rowt, kn, ksegn, regs);
+            if (kn < KP) tile_prefetch_segment<TR, THREADS, ET>(a.ts, rowbase, rowt, kn, ksegn, regs);
             __syncthreads();                       // At (segment k0) committed by every thread
-            seg_mma_w<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, w);
+            seg_mma_w<WM, NT, ET>(acc, At, kseg + 4, mt0, kseg >> 4, w);
             if (kn < KP) {
                 __syncthreads();                   // every wave done reading At
                 tile_commit_segment<TR, THREADS>(ksegn, regs, At, ksegn + 4);
@@ -455,14 +447,14 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
 #if STGCN_ABL == 4
         for (int idx = threadIdx.x; idx < TR * (kseg + 4); idx += THREADS) At[idx] = 0.5f;
 #else
-        tile_load_segment<TR, THREADS>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
+        tile_load_segment<TR, THREADS, ET>(a.ts, rowbase, rowt, k0, kseg, At, kseg + 4);
 #endif
         __syncthreads();
         STGCN_PHASE(1, 2 + 2 * (k0 / kSegMax));
 #if STGCN_ABL == 5
         acc[0][0][0] += At[threadIdx.x];
 #else
-        seg_mma<WM, NT>(acc, At, kseg + 4, mt0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
+        seg_mma<WM, NT, ET>(acc, At, kseg + 4, mt0, kseg >> 4, a.Wp, k0 >> 4, a.KCH, wave, 4);
 #endif
         STGCN_PHASE(1, 3 + 2 * (k0 / kSegMax));
     }
@@ -495,13 +487,13 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
             h[i] = gate_fwd(u[i], sg[i], a.act);
         }
 #if STGCN_ABL == 3
-        if (R < a.ts.rows && u[0] == 12345.678f) st4(a.U + (size_t)R * Cout + 4 * c4, sg);
+        if (R < a.ts.rows && u[0] == 12345.678f) stx4(U_ + (size_t)R * Cout + 4 * c4, sg);
 #else
         if (R < a.ts.rows) {
             const size_t o = (size_t)R * Cout + 4 * c4;
-            if (a.U) st4_wt(a.U + o, u);
-            if (a.S) st4_wt(a.S + o, sg);
-            if (a.H) st4_wt(a.H + o, h);
+            if (a.U) stx4_wt(U_ + o, u);
+            if (a.S) stx4_wt(S_ + o, sg);
+            if (a.H) stx4_wt(H_ + o, h);
         }
 #endif
         if (a.rowstat) {   // per-row LayerNorm partials: the c4n lanes holding one row are contiguous in the wave
@@ -529,17 +521,14 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
         for (int kc = 0; kc < KCHa; ++kc) {
             const f32x4 b = ld4(a.Wap + ((size_t)(nt * KCHa + kc) * 64 + lane) * 4);
             const f32x4 av = ld4(At + (wv * 16 + l15) * ldh + kc * 16 + 4 * g);
-            c0 = mfma4(av[0], b[0], c0);
-            c1v = mfma4(av[1], b[1], c1v);
-            c0 = mfma4(av[2], b[2], c0);
-            c1v = mfma4(av[3], b[3], c1v);
+            MM::mma_split(MM::cvt(av), MM::cvt(b), c0, c1v);
         }
         const int col = nt * 16 + l15;
         const float bb = a.ba[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long R = row0 + wv * 16 + 4 * g + r;
-            if (R < a.ts.rows) a.A[(size_t)R * a.c1 + col] = c0[r] + c1v[r] + bb;
+            if (R < a.ts.rows) stx1(A_ + (size_t)R * a.c1 + col, c0[r] + c1v[r] + bb);
         }
     }
     STGCN_PHASE(1, 13);
@@ -572,11 +561,11 @@ __device__ __forceinline__ RowCoord row_advance(const TapSrc& ts, RowCoord c, in
 }
 
 // Whole tile of a forward (dir = +1) tap source -> At[TR][lda], columns [0, KP): batches of SB loads per thread in flight.
-template <int TR, int SB, int THREADS = kThreads>
+template <int TR, int SB, int THREADS = kThreads, typename ET = float>
 __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int KP, float* At, int lda) {
     const int tid = threadIdx.x, K = ts.taps * ts.C;
     const RowCoord c0 = row_coord(ts, row0 < ts.rows ? row0 : 0);
-    const float* const src = tap_base(ts);
+    const ET* const src = tap_base<ET>(ts);
     const long bs = tap_bstride(ts);
     if ((ts.C & 3) == 0) {
         const int c4n = ts.C >> 2, c4sh = pow2_shift(c4n), per_tap = TR * c4n, total = ts.taps * per_tap;
@@ -595,7 +584,7 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
                     dst[i] = r * lda + tap * ts.C + 4 * c4;
                     if (row0 + r < ts.rows) {
                         const RowCoord c = row_advance(ts, c0, r);
-                        v[i] = ld4(src + ((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + 4 * c4);
+                        v[i] = ldx4(src + ((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + 4 * c4);
                     }
                 }
             }
@@ -626,7 +615,7 @@ __device__ __forceinline__ void stage_tile_fwd(const TapSrc& ts, long row0, int 
                     if (q < K && row0 + r < ts.rows) {
                         const int tap = q / ts.C, ch = q - tap * ts.C;
                         const RowCoord c = row_advance(ts, c0, r);
-                        v[i] = src[((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + ch];
+                        v[i] = ldx1(src + ((size_t)c.b * bs + (size_t)(c.t + tap) * ts.N + c.n) * ts.C + ch);
                     }
                 }
             }
@@ -846,9 +835,10 @@ struct LnRowstatOut {
     const uint64_t* offset_dev;
 };
 // contribution of 4 consecutive channels (c .. c+3) of row (slab, node): returns (sum g, sum g*xhat) of those 4
+template <typename ET = float>
 __device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, f32x4 dy, long slab, int node, int c) {
     const size_t e = ((size_t)slab * o.N + node) * o.C + c;
-    const f32x4 u = ld4(o.U + e), s = ld4(o.S + e), ga = ld4(o.gamma + (size_t)node * o.C + c);
+    const f32x4 u = ldx4(et_ptr<ET>(o.U) + e), s = ldx4(et_ptr<ET>(o.S) + e), ga = ld4(o.gamma + (size_t)node * o.C + c);
     const float mean = o.mean[slab], rstd = o.rstd[slab];
     if (o.training) {
         const uint64_t off = o.offset + (o.offset_dev ? *o.offset_dev : 0);
@@ -903,10 +893,14 @@ struct Tconv4Args {
     LnGateBwdIn lnb;    // PLAIN: see above
 };
 
-template <int TM, int KC, bool PLAIN>
+template <int TM, int KC, bool PLAIN, typename ET>
 __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
     constexpr int WAVES = 8, NT = 2, THREADS = 512, TR = TM * 16, NC = 256, COUT = 128, LDZ = NC + 4;
     const TconvFwdArgs& a = aa.f;
+    ET* const U_ = et_ptr<ET>(a.U);
+    ET* const S_ = et_ptr<ET>(a.S);
+    ET* const H_ = et_ptr<ET>(a.H);
+    ET* const out_ = et_ptr<ET>(aa.out);
     extern __shared__ float stgcn_smem[];
     float* At = stgcn_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -964,7 +958,8 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                     if (R >= rows || R / N != slab) continue;
                     const int n = (int)(R - slab * N);
                     const size_t e = (size_t)R * C + 4 * c4;
-                    const f32x4 dy = ld4(b.dy + e), u = ld4(b.U + e), sg = ld4(b.S + e), ga = ld4(b.gamma + (size_t)n * C + 4 * c4);
+                    const f32x4 dy = ldx4(et_ptr<ET>(b.dy) + e), u = ldx4(et_ptr<ET>(b.U) + e), sg = ldx4(et_ptr<ET>(b.S) + e),
+                                ga = ld4(b.gamma + (size_t)n * C + 4 * c4);
                     f32x4 du, dq, dg;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -978,8 +973,8 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                     }
                     st4(At + row * lda + 4 * c4, du);
                     st4(At + row * lda + C + 4 * c4, dq);
-                    st4_wt(b.dZ + (size_t)R * 2 * C + 4 * c4, du);
-                    st4_wt(b.dZ + (size_t)R * 2 * C + C + 4 * c4, dq);
+                    stx4_wt(et_ptr<ET>(b.dZ) + (size_t)R * 2 * C + 4 * c4, du);
+                    stx4_wt(et_ptr<ET>(b.dZ) + (size_t)R * 2 * C + C + 4 * c4, dq);
                     st4_wt(b.dgam + e, dg);
                 }
             }
@@ -989,7 +984,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             }
         }
     }
-    if (!staged) stage_tile_fwd<TR, 4, THREADS>(a.ts, row0, KP, At, lda);
+    if (!staged) stage_tile_fwd<TR, 4, THREADS, ET>(a.ts, row0, KP, At, lda);
     __syncthreads();
 
     f32x4 acc[TM][NT];
@@ -1005,12 +1000,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                 f32x4 av[TM];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[i] = ld4(arow + i * 16 * lda + (kc0 + kc) * 16);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma4(av[i][s], w[kc][j][s], acc[i][j]);
+                mma_tile<ET, TM, NT>(acc, av, w[kc]);
             }
         }
     };
@@ -1043,11 +1033,11 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             const int row = (tid + it * THREADS) / Q4;
             const bool rin = row0 + row < a.ts.rows;
             const RowCoord c = row_advance(a.ts, c0, rin ? row : 0);     // (b, t = 0, n) of the dZ row
-            const f32x4 v = ld4(Zt + row * LDZ + 4 * q);
-            if (rin) st4_wt(aa.out + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
+            const f32x4 v = et_round4<ET>(ld4(Zt + row * LDZ + 4 * q));   // (the hook below sees what the tensor holds)
+            if (rin) stx4_wt(out_ + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
             if (aa.rs.rowstat) {   // uniform; the outC / 4 lanes holding one output row are consecutive and aligned
                 const long slab = (long)c.b * aa.outT + tap;
-                float2 p = rin ? ln_rowstat4(aa.rs, v, slab, c.n, ci) : make_float2(0.f, 0.f);
+                float2 p = rin ? ln_rowstat4<ET>(aa.rs, v, slab, c.n, ci) : make_float2(0.f, 0.f);
                 for (int m = aa.outC >> 3; m >= 1; m >>= 1) {
                     p.x += __shfl_xor(p.x, m);
                     p.y += __shfl_xor(p.y, m);
@@ -1073,9 +1063,9 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             }
             if (R < a.ts.rows) {
                 const size_t o = (size_t)R * COUT + 4 * c4;
-                if (a.U) st4_wt(a.U + o, u);
-                if (a.S) st4_wt(a.S + o, sg);
-                if (a.H) st4_wt(a.H + o, h);
+                if (a.U) stx4_wt(U_ + o, u);
+                if (a.S) stx4_wt(S_ + o, sg);
+                if (a.H) stx4_wt(H_ + o, h);
             }
             if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
                 float sr = (h[0] + h[1]) + (h[2] + h[3]);
@@ -1119,8 +1109,9 @@ struct GconvFwdArgs {
     float* XT;           // tiled path only: two bf16 operand-form buffers (plan: ws_XT), used when g_gc_precision > 0
 };
 
-template <int MAXQ, int MAXW>
+template <int MAXQ, int MAXW, typename ET>
 __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
+    typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int THREADS = blockDim.x, tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int P = a.parts, part = (int)(blockIdx.x % (unsigned)P);
@@ -1132,10 +1123,12 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     float* const XT0 = stgcn_smem;   // X0 transposed: [16][LDX]
 
     STGCN_PHASE(4, 0);
-    const float* Asl = a.A + (size_t)slab * N * 16;
+    const ET* Asl = et_ptr<ET>(a.A) + (size_t)slab * N * 16;
+    ET* const Xk_ = et_ptr<ET>(a.Xk);
+    ET* const G_ = et_ptr<ET>(a.G);
     for (int idx = tid; idx < NP * 4; idx += THREADS) {
         const int n = idx >> 2, c4 = idx & 3;
-        const f32x4 v = n < N ? ld4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+        const f32x4 v = n < N ? ldx4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
 #pragma unroll
         for (int i = 0; i < 4; ++i) XT0[(c4 * 4 + i) * LDX + n] = v[i];
     }
@@ -1161,14 +1154,13 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         return wf;
     };
     {   // term 0: X0 W0
-        const f32x4 wf = wfrag(0);
+        const typename MM::frag wf = MM::cvt(wfrag(0));
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
             const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const int h = ht * 16 + l15;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) yacc[q] = mfma4(XT0[(4 * g + s) * LDX + h], wf[s], yacc[q]);
+                yacc[q] = MM::mma(MM::cvt(gather4(XT0 + (4 * g) * LDX + h, LDX)), wf, yacc[q]);
             }
         }
     }
@@ -1177,7 +1169,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         const bool two = k0 + 1 < a.Ks;
         const float* T1 = a.Lp + (size_t)(k0 - 1) * MSZ;
         const float* T2 = T1 + MSZ;
-        const f32x4 wf1 = wfrag(k0), wf2 = two ? wfrag(k0 + 1) : zero4();
+        const typename MM::frag wf1 = MM::cvt(wfrag(k0)), wf2 = MM::cvt(two ? wfrag(k0 + 1) : zero4());
         STGCN_PHASE(4, 2 * k0);
         f32x4 acc1[MAXQ], acc2[MAXQ], p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // fragments one (p) and two (n) chunks ahead
 #pragma unroll
@@ -1193,7 +1185,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
         }
         for (int kc = 0; kc < KCH; ++kc) {
-            const f32x4 af = ld4(XT0 + l15 * LDX + kc * 16 + 4 * g);   // A[c = l15][node = kc*16 + 4g + s]
+            const typename MM::frag af = MM::cvt(ld4(XT0 + l15 * LDX + kc * 16 + 4 * g));   // A[c = l15][node = kc*16 + 4g + s]
             f32x4 b1[MAXQ], b2[MAXQ];
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
@@ -1209,11 +1201,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
 #pragma unroll
             for (int q = 0; q < MAXQ; ++q) {
                 if (wave + WAVES * q < HT) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        acc1[q] = mfma4(af[s], b1[q][s], acc1[q]);
-                        if (two) acc2[q] = mfma4(af[s], b2[q][s], acc2[q]);
-                    }
+                    if (two) MM::mma_b2(af, MM::cvt(b1[q]), MM::cvt(b2[q]), acc1[q], acc2[q]);
+                    else acc1[q] = MM::mma(af, MM::cvt(b1[q]), acc1[q]);
                 }
             }
         }
@@ -1224,14 +1213,11 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             if (ht < HT) {
                 const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
                 if (a.Xk && h < N) {
-                    st4_wt(a.Xk + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
-                    if (two) st4_wt(a.Xk + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
+                    stx4_wt(Xk_ + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
+                    if (two) stx4_wt(Xk_ + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    yacc[q] = mfma4(acc1[q][s], wf1[s], yacc[q]);
-                    if (two) yacc[q] = mfma4(acc2[q][s], wf2[s], yacc[q]);
-                }
+                if (two) MM::mma_ab2(MM::cvt(acc1[q]), wf1, MM::cvt(acc2[q]), wf2, yacc[q]);
+                else yacc[q] = MM::mma(MM::cvt(acc1[q]), wf1, yacc[q]);
             }
         }
     }
@@ -1244,7 +1230,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = ht * 16 + 4 * g + r;
-                if (h < N) a.G[((size_t)slab * N + h) * 16 + l15] = fmaxf(yacc[q][r] + bb + res[q][r], 0.f);
+                if (h < N) stx1(G_ + ((size_t)slab * N + h) * 16 + l15, fmaxf(yacc[q][r] + bb + res[q][r], 0.f));
             }
         }
     }
@@ -1404,6 +1390,7 @@ __device__ __forceinline__ void slab_stats_from_rows(const float2* rs, int N, in
     rstd = 1.0f / sqrtf(m2 / ((float)N * (float)C) + eps);
 }
 
+template <typename ET>
 __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
     extern __shared__ float stgcn_smem[];
     const long slab = blockIdx.y;
@@ -1415,14 +1402,14 @@ __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
         a.rstd[slab] = rstd;
     }
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-    const float* U = a.U + (size_t)slab * a.n;
-    const float* S = a.S + (size_t)slab * a.n;
-    float* y = a.y + (size_t)slab * a.n;
+    const ET* U = et_ptr<ET>(a.U) + (size_t)slab * a.n;
+    const ET* S = et_ptr<ET>(a.S) + (size_t)slab * a.n;
+    ET* y = et_ptr<ET>(a.y) + (size_t)slab * a.n;
     int q1 = (chunk + 1) * a.per;
     if (q1 > n4) q1 = n4;
 #pragma unroll 2
     for (int q = chunk * a.per + tid; q < q1; q += kThreads) {
-        const f32x4 u = ld4(U + 4 * q), s = ld4(S + 4 * q), ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
+        const f32x4 u = ldx4(U + 4 * q), s = ldx4(S + 4 * q), ga = ld4(a.gamma + 4 * q), be = ld4(a.beta + 4 * q);
         f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], s[i], a.act) - mean) * rstd * ga[i] + be[i];
@@ -1431,7 +1418,7 @@ __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] *= k[i];
         }
-        st4(y + 4 * q, o);
+        stx4(y + 4 * q, o);
     }
 }
 

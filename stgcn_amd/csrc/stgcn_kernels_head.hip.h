@@ -34,7 +34,7 @@ struct FcFwdArgs {
     const uint64_t* offset_dev;
 };
 
-template <int WM>
+template <int WM, typename ET>
 __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     constexpr int TR = WM * 16, NT = 2;
     extern __shared__ float stgcn_smem[];
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
                 const long R = row0 + row;
                 if (R >= rows || R / N != slab) continue;
                 const int n = (int)(R - slab * N);
-                const f32x4 u = ld4(a.ln.U + (size_t)R * C + 4 * c4), sg = ld4(a.ln.S + (size_t)R * C + 4 * c4);
+                const f32x4 u = ldx4(et_ptr<ET>(a.ln.U) + (size_t)R * C + 4 * c4), sg = ldx4(et_ptr<ET>(a.ln.S) + (size_t)R * C + 4 * c4);
                 const f32x4 ga = ld4(a.ln.gamma + (size_t)n * C + 4 * c4), be = ld4(a.ln.beta + (size_t)n * C + 4 * c4);
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (gate_fwd(u[i], sg[i], a.ln.act) - mean) * rstd * ga[i] + be[i];
                 st4(At + row * lda0 + 4 * c4, o);
-                st4_wt(a.ln.y + (size_t)R * C + 4 * c4, o);
+                stx4_wt(et_ptr<ET>(a.ln.y) + (size_t)R * C + 4 * c4, o);
             }
         }
         for (int idx = threadIdx.x; idx < TR * c4n0; idx += kThreads) {   // rows past the end of the last tile
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
             if (row0 + row >= rows) st4(At + row * lda0 + 4 * c4, zero4());
         }
     } else {
-        stage_tile_fwd<TR, 4>(a.ts, row0, KP, At, KP + 4);
+        stage_tile_fwd<TR, 4, kThreads, ET>(a.ts, row0, KP, At, KP + 4);
     }
     __syncthreads();
     f32x4 acc[WM][NT];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-    pre_mma<WM, NT, 8>(acc, At, KP + 4, 0, a.KCH, w);
+    pre_mma<WM, NT, 8, ET>(acc, At, KP + 4, 0, a.KCH, w);
     __syncthreads();
     const int c1 = a.c1, ldz = c1 + 4;
     float* Zt = At;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcFwdArgs a) {
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) p += __shfl_xor(p, m);   // the 32 lanes of a half-wave hold one row
         if (R < a.ts.rows) {
-            st4_wt(a.hd + (size_t)R * c1 + 4 * c4, h);
+            stx4_wt(et_ptr<ET>(a.hd) + (size_t)R * c1 + 4 * c4, h);
             if (c4 == 0) a.out[R] = p + b2;
         }
     }
@@ -151,7 +151,7 @@ struct FcBwdArgs {
     LnRowstatOut rs;      // row partials of the head's LayerNorm backward (dyln is its output gradient); rs.rowstat == null: off
 };
 
-template <int WM, int NT>
+template <int WM, int NT, typename ET>
 __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
     constexpr int TR = WM * 16;
     extern __shared__ float stgcn_smem[];
@@ -184,14 +184,14 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
                 } else {
                     go = a.dout[R];
                 }
-                const f32x4 h = ld4(a.hd + (size_t)R * c1 + 4 * c4);
+                const f32x4 h = ldx4(et_ptr<ET>(a.hd) + (size_t)R * c1 + 4 * c4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     d[i] = h[i] != 0.f ? go * w2[i] * a.grad_scale : 0.f;
                     dw2[i] += go * h[i];
                 }
                 if (c4 == 0) db2 += go;
-                st4_wt(a.dh1 + (size_t)R * c1 + 4 * c4, d);
+                stx4_wt(et_ptr<ET>(a.dh1) + (size_t)R * c1 + 4 * c4, d);
             }
             st4(At + row * lda + 4 * c4, d);
         }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = zero4();
-        pre_mma<WM, NT, 8>(acc, At, lda, 0, a.KCH, w);
+        pre_mma<WM, NT, 8, ET>(acc, At, lda, 0, a.KCH, w);
         if (a.rs.rowstat && c0 == c1) {
             // dyln through the LDS tile: 16-byte row-major stores, and the LayerNorm-backward row partials while the row is on chip
             __syncthreads();   // every wave is done reading At
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
             for (int row = rsub; row < TR; row += kThreads / c4n) {   // c4n lanes (half a wave for c0 = 128) hold one row
                 const long R = row0 + row;
                 const bool rin = R < a.rows;
-                const f32x4 v = ld4(At + row * lda + 4 * c4);
-                if (rin) st4_wt(a.dyln + (size_t)R * c0 + 4 * c4, v);
+                const f32x4 v = et_round4<ET>(ld4(At + row * lda + 4 * c4));   // (the row partials below see what the tensor holds)
+                if (rin) stx4_wt(et_ptr<ET>(a.dyln) + (size_t)R * c0 + 4 * c4, v);
                 const long slab = rin ? R / a.rs.N : 0;
                 const int node = rin ? (int)(R - slab * a.rs.N) : 0;
-                float2 p = rin ? ln_rowstat4(a.rs, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);
+                float2 p = rin ? ln_rowstat4<ET>(a.rs, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);
                 for (int m = c4n >> 1; m >= 1; m >>= 1) {
                     p.x += __shfl_xor(p.x, m);
                     p.y += __shfl_xor(p.y, m);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const long R = row0 + i * 16 + 4 * g + r;
-                        if (R < a.rows && col < c0) a.dyln[(size_t)R * c0 + col] = acc[i][j][r];
+                        if (R < a.rows && col < c0) stx1(et_ptr<ET>(a.dyln) + (size_t)R * c0 + col, acc[i][j][r]);
                     }
             }
         }

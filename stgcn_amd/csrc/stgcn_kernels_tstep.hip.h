@@ -63,8 +63,14 @@ inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
 // The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
 // walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
 // spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
-template <int C2, int KT, bool TRAINING, int ACT>
+template <int C2, int KT, bool TRAINING, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
+    typedef Mma<ET> MM;
+    const ET* const dy_ = et_ptr<ET>(a.dy);
+    const ET* const U_ = et_ptr<ET>(a.U);
+    const ET* const S_ = et_ptr<ET>(a.S);
+    const ET* const G_ = et_ptr<ET>(a.G);
+    ET* const dYg_ = et_ptr<ET>(a.dYg);
     constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20, RING = KT + 1, RED = 4 * 16 * LDG;
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [KT + 1][16][LDZ]  ring of dZ2 tiles
@@ -88,9 +94,9 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                t.dy[it] = ld4(a.dy + e0 + 64 * it);
-                t.u[it] = ld4(a.U + e0 + 64 * it);
-                t.s[it] = ld4(a.S + e0 + 64 * it);
+                t.dy[it] = ldx4(dy_ + e0 + 64 * it);
+                t.u[it] = ldx4(U_ + e0 + 64 * it);
+                t.s[it] = ldx4(S_ + e0 + 64 * it);
                 if (!rv) { t.dy[it] = zero4(); t.s[it] = zero4(); }   // s = 0 makes every product of the gate backward vanish
             }
         };
@@ -225,15 +231,15 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     } else {
         // =========================================== M waves ===========================================================
         // stationary weights of the transposed conv: wave w contracts o in [w*NC/4, (w+1)*NC/4) of every tap
-        f32x4 Wr[KT][QW];
+        typename MM::frag Wr[KT][QW];
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
-            for (int q = 0; q < QW; ++q) Wr[k][q] = ld4(a.Wd + (size_t)(k * 16 + l15) * NC + w * (NC / 4) + q * 16 + 4 * g);
+            for (int q = 0; q < QW; ++q) Wr[k][q] = MM::cvt(ld4(a.Wd + (size_t)(k * 16 + l15) * NC + w * (NC / 4) + q * 16 + 4 * g));
         // all G tiles of this (window, node tile), transposed
         for (int idx = tid; idx < T1 * 64; idx += 256) {
             const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
-            const f32x4 v = n0 + rr < N ? ld4(a.G + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
+            const f32x4 v = n0 + rr < N ? ldx4(G_ + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
 #pragma unroll
             for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
         }
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 const float* rd = red + (t & 1) * RED;
                 float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
                 if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
-                if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
+                if (rv) stx1(dYg_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
             }
             if (t1 < T2) {     // weight gradient of tile t1: A[m = i][k = row] = G[t1 + tap][row][i] (one 16-byte read), B[k = row][n = o] = dZ2
                 const float* const Zs = Zt + (t1 % RING) * 16 * LDZ;
@@ -260,13 +266,14 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) bz[j][s] = Zs[(4 * g + s) * LDZ + (w * NTW + j) * 16 + l15];
                 }
+                typename MM::frag fz[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) fz[j] = MM::cvt(bz[j]);
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
-                    const f32x4 af = ld4(GT + ((t1 + k) * 16 + l15) * LDG + 4 * g);
+                    const typename MM::frag af = MM::cvt(ld4(GT + ((t1 + k) * 16 + l15) * LDG + 4 * g));
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) accw[k][j] = mfma4(af[s], bz[j][s], accw[k][j]);
+                    for (int j = 0; j < NTW; j += 2) MM::mma_b2(af, fz[j], fz[j + 1], accw[k][j], accw[k][j + 1]);
                 }
             }
             // transposed conv for output step t1: taps with 0 <= t1 - tap < T2; two independent MFMA chains
@@ -278,9 +285,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                     const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + w * (NC / 4) + 4 * g;
 #pragma unroll
                     for (int q = 0; q < QW; ++q) {
-                        const f32x4 z = ld4(zr + q * 16);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
+                        MM::mma_split(Wr[k][q], MM::cvt(ld4(zr + q * 16)), accd[0], accd[1]);
                     }
                 }
             }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             const float* rd = red + (t & 1) * RED;
             float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
             if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
-            if (rv) a.dYg[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
+            if (rv) stx1(dYg_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
         }
         STGCN_PHASE(8, 5);
 #pragma unroll
@@ -351,9 +356,17 @@ __host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CI
     return w;
 }
 
-template <int C0, int CIN, int KT, int ACT>
+template <int C0, int CIN, int KT, int ACT, typename ET>
 __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    typedef Mma<ET> MM;
+    const ET* const dA_ = et_ptr<ET>(a.dA);
+    const ET* const U_ = et_ptr<ET>(a.U);
+    const ET* const S_ = et_ptr<ET>(a.S);
+    const ET* const x_ = et_ptr<ET>(a.x);
+    ET* const dx_ = et_ptr<ET>(a.dx);
+    const ET* const hU_ = et_ptr<ET>(a.rs.U);
+    const ET* const hS_ = et_ptr<ET>(a.rs.S);
     constexpr int NC = 2 * C0, LDZ = NC + 4, RING = KT + 1, LDX = 20, LDH = C0 + 4, LDO = CIN + 4, MI = CIN / 16, QD = NC / 16;
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         // dH^T[ch][row] = Wa[ch][j] dA^T[j][row] on the matrix cores (4 MFMAs per wave and tile: K = 16): wave w owns channels 16w .. 16w+15,
         // A[m = ch][k] = Wa[16w + l15][4g + s] stationary in 4 registers, B[k][n = row] = dA[row = l15][4g + s] (one 16-byte LDS read; both
         // operands use the k order j = 4g + s).  D leaves a lane with channels 16w + 4g .. + 3 of row l15 = its U / S / dZ1 quad.
-        const f32x4 wa = ld4(a.WaD + (size_t)(16 * w + l15) * 16 + 4 * g);
+        const typename MM::frag wa = MM::cvt(ld4(a.WaD + (size_t)(16 * w + l15) * 16 + 4 * g));
         f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
         struct Tile { f32x4 u, s; };
         STGCN_ACC_DECL();
@@ -412,14 +425,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             auto fetch = [&](int t1, Tile& t) __attribute__((always_inline)) {
                 const int tc = t1 < T1 ? t1 : T1 - 1;
                 const size_t e0 = (((size_t)b * T1 + tc) * N + erc) * C0 + 4 * ecq;
-                t.u = ld4(a.U + e0);
-                t.s = ld4(a.S + e0);
+                t.u = ldx4(U_ + e0);
+                t.s = ldx4(S_ + e0);
                 if (!erv) t.s = zero4();        // s = 0 makes every product of the gate backward vanish
             };
             // dA tile t -> registers of 64 threads (row rowq >> 2, quad rowq & 3) -> ring slot t % RING; owned tiles count towards dba
             auto get_dA = [&](int t, int rowq) __attribute__((always_inline)) {
                 f32x4 v = zero4();
-                if (t < T1 && n0 + (rowq >> 2) < N) v = ld4(a.dA + (((size_t)b * T1 + t) * N + n0 + (rowq >> 2)) * 16 + 4 * (rowq & 3));
+                if (t < T1 && n0 + (rowq >> 2) < N) v = ldx4(dA_ + (((size_t)b * T1 + t) * N + n0 + (rowq >> 2)) * 16 + 4 * (rowq & 3));
                 return v;
             };
             auto put_dA = [&](int t, int rowq, f32x4 v) __attribute__((always_inline)) {
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             };
             auto get_x = [&](int xt) {
                 f32x4 v = zero4();
-                if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
+                if (cq < CIN / 4 && rv && xt < T) v = ldx4(x_ + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
                 return v;
             };
             auto put_x = [&](int xt, f32x4 v) {
@@ -442,9 +455,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             // count towards the bias partials
             auto E = [&](int t, const Tile& tl) __attribute__((always_inline)) {
                 const f32x4 d4 = ld4(dAe + (t % RING) * 256 + er * 16 + 4 * g);
-                f32x4 dh = zero4();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) dh = mfma4(wa[s], d4[s], dh);
+                const f32x4 dh = MM::mma(wa, MM::cvt(d4), zero4());
                 f32x4 du, dq, h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -473,8 +484,8 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                 if (hk && cq < CIN / 4) {
                     const long slab = (long)b * T + (t < T ? t : T - 1);
                     const size_t e = ((size_t)slab * N + rc) * CIN + 4 * cq;
-                    h.u = ld4(a.rs.U + e);
-                    h.s = ld4(a.rs.S + e);
+                    h.u = ldx4(hU_ + e);
+                    h.s = ldx4(hS_ + e);
                     h.mean = a.rs.mean[slab];
                     h.rstd = a.rs.rstd[slab];
                     h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
@@ -488,8 +499,8 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             // finish output step t: dx tile from LDS -> global (16-byte rows) + hook row partials
             auto F = [&](int t, const Hook& h) __attribute__((always_inline)) {
                 if (cq < CIN / 4) {
-                    const f32x4 v = ld4(Xo + (t & 1) * 16 * LDO + r * LDO + 4 * cq);
-                    if (rv) st4_wt2(a.dx + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
+                    const f32x4 v = et_round4<ET>(ld4(Xo + (t & 1) * 16 * LDO + r * LDO + 4 * cq));   // (the hook below sees what the tensor holds)
+                    if (rv) stx4_wt2(dx_ + (((size_t)b * T + t) * N + n0 + r) * CIN + 4 * cq, v);
                     if (hk) {   // uniform
                         float2 p = make_float2(0.f, 0.f);
                         if (rv) {
@@ -625,24 +636,18 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                         bz[0][s] = Zs[(4 * g + s) * LDZ + (2 * w) * 16 + l15];
                         bz[1][s] = Zs[(4 * g + s) * LDZ + (2 * w + 1) * 16 + l15];
                     }
+                    const typename MM::frag fz0 = MM::cvt(bz[0]), fz1 = MM::cvt(bz[1]);
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const float* xt = XT + (size_t)((i + k) % RING) * CIN * LDX + l15 * LDX + 4 * g;
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            const f32x4 af = ld4(xt + mi * 16 * LDX);   // A[m = ch][k = row]
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                accw[k * MI + mi][0] = mfma4(af[s], bz[0][s], accw[k * MI + mi][0]);
-                                accw[k * MI + mi][1] = mfma4(af[s], bz[1][s], accw[k * MI + mi][1]);
-                            }
-                        }
+                        for (int mi = 0; mi < MI; ++mi)   // A[m = ch][k = row]
+                            MM::mma_b2(MM::cvt(ld4(xt + mi * 16 * LDX)), fz0, fz1, accw[k * MI + mi][0], accw[k * MI + mi][1]);
                     }
                     // dWa[i0 = 16w + ..][j] += H^T dA : A[m = ch][k = row] = Ht[row][16w + l15], B[k = row][n = j] = dA[row][j]
                     const float* hh = Ht + (i & 1) * 16 * LDH + (4 * g) * LDH + 16 * w + l15;
                     const float* dd = dAe + (i % RING) * 256 + (4 * g) * 16 + l15;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acca = mfma4(hh[s * LDH], dd[s * 16], acca);
+                    acca = MM::mma(MM::cvt(gather4(hh, LDH)), MM::cvt(gather4(dd, 16)), acca);
                 }
                 STGCN_ACC_END();
             }
@@ -663,12 +668,12 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     } else {
         // =========================================== Md waves: transposed conv ===========================================
         // wave w < MI owns input channels 16w .. 16w+15: A[m = ci][k = o] = W_eff1[(tap, ci)][o], the whole K = KT * NC in registers
-        f32x4 Wr[KT][QD];
+        typename MM::frag Wr[KT][QD];
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
             for (int q = 0; q < QD; ++q)
-                Wr[k][q] = w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4();
+                Wr[k][q] = MM::cvt(w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4());
         STGCN_ACC_DECL();
         for (long item = item0; item <= item1 && item < items; ++item) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
@@ -686,9 +691,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                             const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + 4 * g;
 #pragma unroll
                             for (int q = 0; q < QD; ++q) {
-                                const f32x4 z = ld4(zr + 16 * q);   // B[k = o][n = row]
-#pragma unroll
-                                for (int s = 0; s < 4; ++s) accd[s & 1] = mfma4(Wr[k][q][s], z[s], accd[s & 1]);
+                                MM::mma_split(Wr[k][q], MM::cvt(ld4(zr + 16 * q)), accd[0], accd[1]);   // B[k = o][n = row]
                             }
                         }
                     }
@@ -730,9 +733,14 @@ struct Tc1FwdArgs {
 };
 inline size_t tc1_fwd_lds_bytes(int CIN, int Kt) { return ((size_t)(Kt + 1) * 16 * (CIN + 8) + 2 * 4 * 16 * 20) * sizeof(float); }
 
-template <int C0, int CIN, int KT, int ACT>
+template <int C0, int CIN, int KT, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    typedef Mma<ET> MM;
+    const ET* const x_ = et_ptr<ET>(a.x);
+    ET* const U_ = et_ptr<ET>(a.U);
+    ET* const S_ = et_ptr<ET>(a.S);
+    ET* const A_ = et_ptr<ET>(a.A);
     constexpr int RING = KT + 1, LDXS = CIN + 8, CC = CIN / 16, KCH = KT * CC, MT = C0 / 16, RED = 4 * 16 * 20;
     extern __shared__ float stgcn_smem[];
     float* const Xs = stgcn_smem;                      // [RING][16][LDXS]  x tiles, row major
@@ -748,17 +756,18 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
 
     if (roleM) {
         // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
-        f32x4 wP[KCH], wQ[KCH];
+        typename MM::frag wP[KCH], wQ[KCH];
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) {
-            wP[kc] = ld4(a.Wp + ((size_t)(w * KCH + kc) * 64 + lane) * 4);
-            wQ[kc] = ld4(a.Wp + ((size_t)((w + MT) * KCH + kc) * 64 + lane) * 4);
+            wP[kc] = MM::cvt(ld4(a.Wp + ((size_t)(w * KCH + kc) * 64 + lane) * 4));
+            wQ[kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + MT) * KCH + kc) * 64 + lane) * 4));
         }
         const int c = 16 * w + 4 * g;                  // this lane's 4 channels
         const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C0 + c);
-        f32x4 waT;                                     // A[m = j = l15][k = i = 16w + 4g + s] = Wa[i][j]
+        f32x4 waT_;                                    // A[m = j = l15][k = i = 16w + 4g + s] = Wa[i][j]
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) waT[sI] = a.WaD[(size_t)(c + sI) * 16 + l15];
+        for (int sI = 0; sI < 4; ++sI) waT_[sI] = a.WaD[(size_t)(c + sI) * 16 + l15];
+        const typename MM::frag waT = MM::cvt(waT_);
         for (long item = item0; item <= item1 && item < items; ++item) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T1;
             if (sb >= se) continue;                    // (uniform over the workgroup: both roles evaluate the same list)
@@ -771,12 +780,8 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
                     const int tap = kc / CC, cc = kc % CC;
-                    const f32x4 bf = ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g);   // B[k = ci][n = row]
-#pragma unroll
-                    for (int sI = 0; sI < 4; ++sI) {
-                        accP = mfma4(wP[kc][sI], bf[sI], accP);
-                        accQ = mfma4(wQ[kc][sI], bf[sI], accQ);
-                    }
+                    // B[k = ci][n = row]
+                    MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g)), accP, accQ);
                 }
                 f32x4 u, sg, h;
 #pragma unroll
@@ -787,12 +792,11 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
                 }
                 if (rowv) {
                     const size_t o = (((size_t)b * T1 + i) * N + n0 + l15) * C0 + c;
-                    st4_wt2(a.U + o, u);
-                    st4_wt2(a.S + o, sg);
+                    stx4_wt2(U_ + o, u);
+                    stx4_wt2(S_ + o, sg);
                 }
-                f32x4 pa = zero4();                    // this wave's share of A^T[j][row]: its 16 channels of the K = C0 contraction
-#pragma unroll
-                for (int sI = 0; sI < 4; ++sI) pa = mfma4(waT[sI], h[sI], pa);
+                // this wave's share of A^T[j][row]: its 16 channels of the K = C0 contraction
+                const f32x4 pa = MM::mma(waT, MM::cvt(h), zero4());
                 st4(red + (i & 1) * RED + (w * 16 + l15) * 20 + 4 * g, pa);   // D[m = j = 4g + r][n = row = l15]
             }
             __syncthreads();       // (C) last partial tiles visible
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             const bool rv = n0 + r < N;
             auto get_x = [&](int xt) {
                 f32x4 v = zero4();
-                if (cq < CIN / 4 && rv && xt < T) v = ld4(a.x + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
+                if (cq < CIN / 4 && rv && xt < T) v = ldx4(x_ + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
                 return v;
             };
             auto put_x = [&](int xt, f32x4 v) {
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             auto F = [&](int t) {   // A[t] = sum of the 4 waves' partial tiles + bias
                 const float* rd = red + (t & 1) * RED;
                 const float v = (rd[(0 * 16 + r) * 20 + cq] + rd[(1 * 16 + r) * 20 + cq]) + (rd[(2 * 16 + r) * 20 + cq] + rd[(3 * 16 + r) * 20 + cq]) + bj;
-                if (rv) a.A[(((size_t)b * T1 + t) * N + n0 + r) * 16 + cq] = v;
+                if (rv) stx1(A_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
             };
             f32x4 xs[KT];
 #pragma unroll
@@ -871,9 +875,13 @@ struct Tc2LnFwdArgs {
 constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
 inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 64) * sizeof(float); }
 
-template <int C2, int KT, int NTI, int HV>
+template <int C2, int KT, int NTI, int HV, typename ET>
 __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
+    typedef Mma<ET> MM;
+    ET* const U_ = et_ptr<ET>(a.U);
+    ET* const S_ = et_ptr<ET>(a.S);
+    ET* const y_ = et_ptr<ET>(a.y);
     constexpr int NC = 2 * C2, MT = C2 / 16;
     extern __shared__ float stgcn_smem[];
     float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]
@@ -884,17 +892,17 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
 
     STGCN_PHASE(9, 0);
     // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)
-    f32x4 wP[KT], wQ[KT];
+    typename MM::frag wP[KT], wQ[KT];
 #pragma unroll
     for (int kc = 0; kc < KT; ++kc) {
-        wP[kc] = ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4);
-        wQ[kc] = ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4);
+        wP[kc] = MM::cvt(ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4));
+        wQ[kc] = MM::cvt(ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4));
     }
     // stage the KT input slabs G[b][t2 + tap] (zero rows beyond N)
-    const float* Gb = a.G + ((size_t)b * a.T1 + t2) * N * 16;
+    const ET* Gb = et_ptr<ET>(a.G) + ((size_t)b * a.T1 + t2) * N * 16;
     for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
         const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
-        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ld4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
+        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ldx4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
     }
     const int c = 16 * p + 4 * g;   // this lane's 4 channels
     const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C2 + c);
@@ -930,12 +938,8 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
             f32x4 accP = zero4(), accQ = zero4();
 #pragma unroll
             for (int kc = 0; kc < KT; ++kc) {
-                const f32x4 bf = ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g);   // B[k = 4g + s][n = row]
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    accP = mfma4(wP[kc][s], bf[s], accP);
-                    accQ = mfma4(wQ[kc][s], bf[s], accQ);
-                }
+                // B[k = 4g + s][n = row]
+                MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g)), accP, accQ);
             }
             if (a.training) {
                 const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (((size_t)(row < N ? row : 0) * C2 + c) >> 2), a.seed, off, a.thresh, 1.0f);
@@ -950,8 +954,8 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
                     h[i] = gate_fwd(u[i], sg[i], a.act);
                 }
                 const size_t o = ((size_t)slab * N + row) * C2 + c;
-                st4_wt(a.U + o, u);
-                st4_wt(a.S + o, sg);
+                stx4_wt(U_ + o, u);
+                stx4_wt(S_ + o, sg);
                 hh[j] = h;
                 sum += (h[0] + h[1]) + (h[2] + h[3]);
                 cnt_l += 4.f;
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
                 o[i] = (hh[j][i] - mean) * rstd * ga[j][i] + be[j][i];
                 if (a.training) o[i] = ((kb >> i) & 1u) ? o[i] * a.keep_scale : 0.f;
             }
-            st4_wt(a.y + (size_t)slab * N * C2 + e, o);
+            stx4_wt(y_ + (size_t)slab * N * C2 + e, o);
         }
     }
     STGCN_PHASE(9, 5);

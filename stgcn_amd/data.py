@@ -59,8 +59,9 @@ def calc_chebynet_gso(gso, lambda_max: str = "scipy_norm2", seed=None):
     lambda_max="scipy_norm2" (default, drop-in): scipy.sparse.linalg.norm(gso, 2) exactly as the reference calls it.  That
     routine is an un-converged randomised solver whose result depends on numpy's global RNG state (SURVEY.md section 8c
     hazard 1: 1.00955 vs the true 1.01200 for METR-LA under np.random.seed(42)); pass ``seed`` to pin it (numpy's global
-    seed is set immediately before the call, like the fixtures of tests/golden do), or leave it None to inherit the
-    caller's RNG state like the reference does.
+    seed is set immediately before the call, like the fixtures of tests/golden do, and the caller's RNG state is restored
+    afterwards), or leave it None to inherit the caller's RNG state like the reference does.  Data-parallel runs: every rank
+    builds its own operator, so either pass the same ``seed`` on every rank or call ``train.sync_operators(model)``.
     lambda_max="exact": the true largest singular value via dense LAPACK -- deterministic, but a ~0.25 % different
     operator from the one the reference trains with."""
     gso = sp.csc_matrix(gso) if not sp.issparse(gso) else gso.tocsc()
@@ -68,8 +69,14 @@ def calc_chebynet_gso(gso, lambda_max: str = "scipy_norm2", seed=None):
     if lambda_max == "scipy_norm2":
         from scipy.sparse.linalg import norm
         if seed is not None:
+            state = np.random.get_state()          # the pin must not clobber the caller's global RNG stream
             np.random.seed(int(seed))
-        eig = norm(gso, 2)
+            try:
+                eig = norm(gso, 2)
+            finally:
+                np.random.set_state(state)
+        else:
+            eig = norm(gso, 2)
     elif lambda_max == "exact":
         eig = float(np.linalg.norm(gso.toarray(), 2))
     else:

@@ -36,6 +36,7 @@ class DropoutStream:
     the running part of the offset lives in a device int64 that the captured step bumps (``advance``);
     each block adds its own static site id.  The trainer gives each data-parallel rank its own seed."""
     seed: int = 0x5EED5EED
+    rank_offset: int = 0      # added to every seed set through manual_seed (train.init_distributed: the data-parallel rank)
     _offset: int = 0
     _sites: int = 0
     counter = None            # device int64[1] in graph mode
@@ -44,7 +45,7 @@ class DropoutStream:
 
     @classmethod
     def manual_seed(cls, seed: int):
-        cls.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cls.seed = (int(seed) + cls.rank_offset) & 0xFFFFFFFFFFFFFFFF      # ranks stay decorrelated when user code re-seeds after init
         cls._offset = 0
         if cls.counter is not None:
             cls.counter.zero_()

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import os
 
+import torch
 import torch.nn as nn
 
 from . import layers
@@ -56,23 +57,36 @@ class _STGCNBase(nn.Module):
             head = (self.output.cfg, T, self.output._params(), self.output._ws)
         # step counters a trainer asked to advance with the first launch of each TRAINING forward (train.GraphedTrainStep)
         counters = getattr(self, "_step_counters", None) if self.training else None
-        ops.prepack_modules(blocks, head, x.shape[0], x.device, counters)
+        ops.prepack_modules(blocks, head, x.shape[0], x.device, counters, dtype=x.dtype)
         return [b[3] for b in blocks] + ([head[3]] if head is not None else [])
 
+    def set_compute_dtype(self, dtype):
+        """Storage / arithmetic type of the activations: ``torch.float32`` (the reference's arithmetic, default) or ``torch.bfloat16``
+        (BASELINE.json configs[2], [4]: bf16 activations and saved tensors, bf16 matrix cores with fp32 accumulation; parameters,
+        LayerNorm statistics, gradients and the optimizer stay fp32).  A float32 input is cast once at the model's entry; the
+        prediction comes back as float32.  No counterpart in the reference (it runs fp32 only)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+        self.compute_dtype = dtype
+        return self
+
     def forward(self, x):
+        cd = getattr(self, "compute_dtype", None)
+        if cd is not None and x.dtype != cd and x.is_floating_point():
+            x = x.to(cd)
         marked = self._prepack(x)
         try:
             x = self.st_blocks(x)
             if self.Ko > 1:
                 x = self.output(x)
             elif self.Ko == 0:
-                x = self.fc1(x.permute(0, 2, 3, 1))
+                x = self.fc1(x.permute(0, 2, 3, 1).float())
                 x = self.relu(x)
                 x = self.fc2(x).permute(0, 3, 1, 2)
         finally:
             for wsc in marked:      # a module that did not run (exception) must pack by itself next time
                 wsc.prepacked = False
-        return x
+        return x if x.dtype == torch.float32 else x.float()      # (Ko == 1 hands the last block's output through)
 
 
 class STGCNChebGraphConv(_STGCNBase):

@@ -41,9 +41,15 @@ def _stream_of(t: torch.Tensor) -> Optional[int]:
     return None
 
 
-def _check_device(t: torch.Tensor, what: str):
+ACT_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16}      # storage / arithmetic types of the activations
+
+
+def _check_device(t: torch.Tensor, what: str, activation: bool = False):
     L = _lib.lib()
-    if t.dtype != torch.float32:
+    if activation:
+        if t.dtype not in ACT_DTYPES:
+            raise TypeError(f"{what}: expected float32 or bfloat16 activations, got {t.dtype}")
+    elif t.dtype != torch.float32:
         raise TypeError(f"{what}: expected float32, got {t.dtype}")
     if L.is_emulator:
         if t.is_cuda:
@@ -86,7 +92,7 @@ def window_strided_rows(x_p: torch.Tensor) -> Optional[int]:
 
 
 def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False,
-              x_bstride: int = 0, x_index: Optional[int] = None, x_index_stride: int = 0) -> StblockDesc:
+              x_bstride: int = 0, x_index: Optional[int] = None, x_index_stride: int = 0, dtype: torch.dtype = torch.float32) -> StblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")  # layers.py:117-118
     if cfg.graph_conv_type not in _lib.GRAPH_CONV:
@@ -105,6 +111,7 @@ def make_desc(cfg: BlockConfig, B: int, T: int, training: bool, need_dx: bool, p
     d.prepacked = 1 if prepacked else 0
     d.defer_reduce = 1 if defer else 0
     d.x_bstride, d.x_index_dev, d.x_index_stride = int(x_bstride), x_index, int(x_index_stride)
+    d.dtype = ACT_DTYPES[dtype]
     return d
 
 
@@ -409,13 +416,22 @@ class LnHookState:
     backward forms the block's LayerNorm-backward row partials while its input gradient is still on chip (``stgcn_ln_hook``) and marks
     the state ready; the block's own backward then skips its pass over dy -- if the gradient it receives is the very buffer the
     consumer wrote (``dx_ptr``), i.e. nothing else contributed to it."""
-    __slots__ = ("hook", "keep", "ready", "dx_ptr")
+    __slots__ = ("hook", "keep", "ready", "dx_ptr", "dx_version", "y_ptr")
 
     def __init__(self, hook, keep):
-        self.hook, self.keep, self.ready, self.dx_ptr = hook, keep, False, None
+        self.hook, self.keep, self.ready, self.dx_ptr, self.dx_version, self.y_ptr = hook, keep, False, None, -1, None
+
+    def mark_ready(self, dx: torch.Tensor) -> None:
+        # the producer trusts the partials only for THIS buffer in THIS state: an in-place edit of the gradient between consumer and
+        # producer (a tensor hook doing g.mul_(), in-place clipping) bumps the version counter and sends the producer back to its own pass
+        self.ready, self.dx_ptr, self.dx_version = True, dx.data_ptr(), dx._version
+
+    def matches(self, dy: torch.Tensor) -> bool:
+        return self.ready and self.dx_ptr == dy.data_ptr() and self.dx_version == dy._version
 
 
 _ln_hooks: "Dict[int, tuple]" = {}      # data_ptr of a block output -> (state, the output tensor itself)
+_offer_hook_next = False                # set by st_conv_block for the apply() that follows (grad mode is invisible inside Function.forward)
 
 
 def _offer_ln_hook(y: torch.Tensor, state: LnHookState) -> None:
@@ -424,7 +440,22 @@ def _offer_ln_hook(y: torch.Tensor, state: LnHookState) -> None:
     # operator (a block used on its own) are evicted oldest-first, so at most 8 outputs are pinned.
     while len(_ln_hooks) >= 8:
         _ln_hooks.pop(next(iter(_ln_hooks)))
-    _ln_hooks[y.data_ptr()] = (state, y)
+    state.y_ptr = y.data_ptr()
+    _ln_hooks[state.y_ptr] = (state, y)
+
+
+def _retire_ln_hook(state: Optional[LnHookState]) -> None:
+    """The producing block's backward ran: an offer nobody took (the block's output went to a non-fused consumer) must not keep
+    pinning y / saved / ws."""
+    if state is not None and state.y_ptr is not None:
+        e = _ln_hooks.get(state.y_ptr)
+        if e is not None and e[0] is state:
+            del _ln_hooks[state.y_ptr]
+
+
+def clear_ln_hooks() -> None:
+    """Drop every pending LayerNorm-hook offer (forwards whose backward never ran)."""
+    _ln_hooks.clear()
 
 
 def _take_ln_hook(x_cl: torch.Tensor) -> Optional[LnHookState]:
@@ -456,15 +487,16 @@ class _STBlockFn(torch.autograd.Function):
         bstride = 0 if x_cl.is_contiguous() else window_strided_rows(x_cl)
         assert bstride is not None and not (bstride and need_dx), "st_conv_block hands over dense or window-strided inputs only"
         xi, xis = _index_of(x_cl)
-        desc = make_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked(), x_bstride=bstride, x_index=xi, x_index_stride=xis)
+        desc = make_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked(), x_bstride=bstride, x_index=xi, x_index_stride=xis,
+                         dtype=x_cl.dtype)
         plan = query_plan(desc)
         dev = x_cl.device
         ps = [None if p is None else p.detach() for p in params]
         for p in ps:
             if p is not None:
                 assert p.is_contiguous() and p.dtype == torch.float32 and p.device == dev
-        y = torch.empty(B, plan.T2, N, cfg.channels[2], dtype=torch.float32, device=dev)
-        saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=dev)
+        y = torch.empty(B, plan.T2, N, cfg.channels[2], dtype=x_cl.dtype, device=dev)      # (activations keep the input's type)
+        saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=dev)            # (4-byte units whatever the activation type)
         ws = wsc.get(plan.ws_floats, dev)
         pst = _param_struct(StblockParams, ps)
         L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_pad.data_ptr(), y.data_ptr(),
@@ -472,7 +504,9 @@ class _STBlockFn(torch.autograd.Function):
                 "stgcn_stblock_forward")
         ctx.in_hook = _take_ln_hook(x_cl) if need_dx else None          # LayerNorm of the module that produced x (if it was a fused block)
         ctx.own_hook = None
-        if any(p is not None and p.requires_grad for p in params):       # (a later backward is possible)
+        global _offer_hook_next
+        offer, _offer_hook_next = _offer_hook_next, False
+        if offer:       # a later backward is possible: grad mode on and something upstream requires grad (decided in st_conv_block)
             hk = _lib.LnHook()
             L.check(L.dll.stgcn_stblock_ln_hook(C.byref(desc), C.byref(pst), saved.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev),
                                                 C.byref(hk)), "stgcn_stblock_ln_hook")
@@ -497,10 +531,13 @@ class _STBlockFn(torch.autograd.Function):
         B, T, N, c_in = x_cl.shape
         sink = _sink
         desc = make_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None, x_bstride=ctx.x_window[0], x_index=ctx.x_window[1],
-                         x_index_stride=ctx.x_window[2])
+                         x_index_stride=ctx.x_window[2], dtype=x_cl.dtype)
         dy = dy.contiguous()
+        if dy.dtype != x_cl.dtype:
+            dy = dy.to(x_cl.dtype)
         own = ctx.own_hook
-        if own is not None and own.ready and own.dx_ptr == dy.data_ptr():
+        _retire_ln_hook(own)
+        if own is not None and own.matches(dy):
             desc.dy_rowstats_ready = 1       # the consumer of y wrote this block's LayerNorm-backward row partials with its dx
         plan = query_plan(desc)
         dev = x_cl.device
@@ -528,7 +565,7 @@ class _STBlockFn(torch.autograd.Function):
                                                   None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
                 "stgcn_stblock_backward")
         if ih is not None:
-            ih.ready, ih.dx_ptr = True, dx.data_ptr()
+            ih.mark_ready(dx)
         if sink is not None:
             sink.blocks.append((desc, gst, ws, (grads, params)))
             sink.owners.append(ctx.wsc)
@@ -546,18 +583,22 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     strides, exactly what the reference's own forward returns.  ``params`` follows PARAM_FIELDS order.
     ``offset_dev``: optional 1-element int64 device tensor added to ``offset`` on the device (hipGraph replay).
     """
-    _check_device(x, "x")
+    _check_device(x, "x", activation=True)
     if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
         raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
     x_cl = x.permute(0, 2, 3, 1)
     if x.requires_grad or window_strided_rows(x_cl) is None:
         x_cl = x_cl.contiguous()                    # no copy when x is already channels-last (or c_in == 1)
     # (else: overlapping windows of a resident series are read in place -- device-side windowing, no 12x replicated tensor)
+    global _offer_hook_next
+    # the LayerNorm-hook offer pins y / saved / ws until a consumer's or this block's backward takes it: only when a backward can follow
+    # (eval / no_grad forwards would otherwise leave stale entries behind)
+    _offer_hook_next = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
     y_cl = _STBlockFn.apply(x_cl, gso_pad, gso_t_pad, cfg, training, seed, offset, offset_dev, wsc, *params)
     return y_cl.permute(0, 3, 1, 2)
 
 
-def prepack_modules(blocks, head, B: int, device, counters=None) -> None:
+def prepack_modules(blocks, head, B: int, device, counters=None, dtype: torch.dtype = torch.float32) -> None:
     """One pack launch for a whole model step (stgcn_prepack): ``blocks`` is a list of (cfg, T_in, params, wsc) of the ST
     blocks in order, ``head`` is (cfg, T_in, params, wsc) or None.  Marks every workspace so that the module's next forward
     skips its own pack launch.  Parameters only change in optimizer.step(), so this runs once per forward of the model."""
@@ -565,7 +606,7 @@ def prepack_modules(blocks, head, B: int, device, counters=None) -> None:
     arr = (_lib.PrepackBlock * max(len(blocks), 1))()
     keep = []
     for i, (cfg, T, params, wsc) in enumerate(blocks):
-        desc = make_desc(cfg, B, T, True, True)
+        desc = make_desc(cfg, B, T, True, True, dtype=dtype)
         plan = query_plan(desc)
         ps = [None if p is None else p.detach() for p in params]
         pst = _param_struct(StblockParams, ps)
@@ -577,7 +618,7 @@ def prepack_modules(blocks, head, B: int, device, counters=None) -> None:
     hd = hp = hws = None
     if head is not None:
         cfg, T, params, wsc = head
-        hdesc = make_head_desc(cfg, B, T, True, True)
+        hdesc = make_head_desc(cfg, B, T, True, True, dtype=dtype)
         hplan = query_head_plan(hdesc)
         hps = [None if p is None else p.detach() for p in params]
         hpst = _head_struct(OutblockParams, hps)
@@ -617,7 +658,8 @@ def head_supported(cfg: HeadConfig) -> bool:
             and (cfg.c_in % 4 == 0 or cfg.Ko * cfg.c_in <= 16))
 
 
-def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False) -> OutblockDesc:
+def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: bool, prepacked: bool = False, defer: bool = False,
+                   dtype: torch.dtype = torch.float32) -> OutblockDesc:
     if cfg.act_func not in _lib.ACT:
         raise NotImplementedError(f"ERROR: The activation function {cfg.act_func} is not implemented.")
     d = OutblockDesc()
@@ -630,6 +672,7 @@ def make_head_desc(cfg: HeadConfig, B: int, T: int, training: bool, need_dx: boo
     d.need_dx = 1 if need_dx else 0
     d.prepacked = 1 if prepacked else 0
     d.defer_reduce = 1 if defer else 0
+    d.dtype = ACT_DTYPES[dtype]
     return d
 
 
@@ -662,7 +705,7 @@ class _OutBlockFn(torch.autograd.Function):
         L = _lib.lib()
         B, T, N, c_in = x_cl.shape
         need_dx = bool(x_cl.requires_grad)
-        desc = make_head_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked())
+        desc = make_head_desc(cfg, B, T, training, need_dx, prepacked=wsc.take_prepacked(), dtype=x_cl.dtype)
         plan = query_head_plan(desc)
         dev = x_cl.device
         ps = [None if p is None else p.detach() for p in params]
@@ -688,8 +731,10 @@ class _OutBlockFn(torch.autograd.Function):
         cfg = ctx.cfg
         B, T, N, c_in = x_cl.shape
         sink = _sink
-        desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None)
+        desc = make_head_desc(cfg, B, T, ctx.training, ctx.need_dx, defer=sink is not None, dtype=x_cl.dtype)
         dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
         global _pending_loss
         fused_loss = _pending_loss if (_pending_loss is not None and _pending_loss.placeholder.data_ptr() == dout.data_ptr()) else None
         if fused_loss is not None:
@@ -725,7 +770,7 @@ class _OutBlockFn(torch.autograd.Function):
                                                        None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
                     "stgcn_outblock_backward")
         if ih is not None:
-            ih.ready, ih.dx_ptr = True, dx.data_ptr()
+            ih.mark_ready(dx)
         if sink is not None:
             sink.head = (desc, gst, ctx.ws, (grads, params))
             sink.owners.append(ctx.wsc)
@@ -738,7 +783,7 @@ def output_block(x: torch.Tensor, cfg: HeadConfig, params, training: bool, seed:
                  offset_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused OutputBlock.forward (model/layers.py:276-284): logical (B, c_in, T, N) -> (B, 1, T-Ko+1, N).
     ``params`` follows HEAD_PARAM_FIELDS order."""
-    _check_device(x, "x")
+    _check_device(x, "x", activation=True)
     if x.dim() != 4 or x.shape[1] != cfg.c_in or x.shape[3] != cfg.n_vertex:
         raise ValueError(f"expected input (B, {cfg.c_in}, T, {cfg.n_vertex}), got {tuple(x.shape)}")
     x_cl = x.permute(0, 2, 3, 1).contiguous()

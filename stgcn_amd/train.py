@@ -47,8 +47,34 @@ def init_distributed(backend: Optional[str] = None):
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world > 1:      # every data-parallel rank draws its own dropout masks (the shards are different windows of one global batch)
         from .layers import DropoutStream
-        DropoutStream.manual_seed(DropoutStream.seed + rank)
+        base = DropoutStream.seed - DropoutStream.rank_offset
+        DropoutStream.rank_offset = rank        # survives a later DropoutStream.manual_seed(s) of user code (set-seed-after-init order)
+        DropoutStream.manual_seed(base)
     return rank, local_rank, world
+
+
+def sync_operators(model, src: int = 0) -> None:
+    """Data-parallel replicas must train with ONE graph shift operator: ``gso`` is a plain attribute (not a parameter, not a
+    buffer, never all-reduced -- layers.py:128/179 of the reference), and the reference's ``calc_chebynet_gso`` depends on numpy's
+    global RNG state (script/utility.py:59-76), so differently seeded ranks would silently hold different operators.  Broadcasts
+    every fused block's ``gso`` from rank ``src`` (no-op without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return
+    from .layers import STConvBlock
+    seen = {}
+    for m in model.modules():
+        if isinstance(m, STConvBlock) and torch.is_tensor(m.gso):
+            g = seen.get(id(m.gso))
+            if g is None:
+                g = m.gso.detach().clone().contiguous()
+                dist.broadcast(g, src=src)
+                seen[id(m.gso)] = g
+            m.gso = g
+            m.graph_conv.gso = g
+            gc = getattr(m.graph_conv, "cheb_graph_conv", None) or getattr(m.graph_conv, "graph_conv", None)
+            if gc is not None:
+                gc.gso = g
+            m._gso_cache = None
 
 
 class FlatGradAllReduce:
@@ -177,16 +203,28 @@ def tail_step(model, optimizer, x, y, world: int = 1, rank: int = 0):
     the SUM all-reduce of the gradients is exactly the gradient of the mean loss over the n windows (``weight by local count``,
     SURVEY.md section 8e).  Eager launches: a captured step has a fixed batch shape.  Returns the global mean loss (tensor)."""
     from . import ops
+    from .layers import DropoutStream
     n = len(x)
     per = (n + world - 1) // world
     lo, hi = min(rank * per, n), min(rank * per + per, n)
     optimizer.zero_grad(set_to_none=True)
     dev = x.device
     loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-    if hi > lo:
-        pred = model(x[lo:hi]).reshape(hi - lo, -1)
-        loss = ops.mse_backward(pred, y[lo:hi].contiguous(), grad_scale=(hi - lo) / n)
-        loss_sum = loss * ((hi - lo) / n)
+    # A live GraphedTrainStep may have put its step counters (dropout position, AdamW step count, series window index) on the model's
+    # weight-pack launch (``model._step_counters``): this eager step must not let that launch advance the WINDOW index (the tail batch
+    # is handed over explicitly; the next replay has to start at the window the index already points to), so the counters are suspended
+    # around the forward and the two that a tail step does consume -- dropout position and optimizer step count -- are advanced below.
+    folded = getattr(model, "_step_counters", None)
+    if folded is not None:
+        model._step_counters = None
+    try:
+        if hi > lo:
+            pred = model(x[lo:hi]).reshape(hi - lo, -1)
+            loss = ops.mse_backward(pred, y[lo:hi].contiguous(), grad_scale=(hi - lo) / n)
+            loss_sum = loss * ((hi - lo) / n)
+    finally:
+        if folded is not None:
+            model._step_counters = folded
     if world > 1:
         params = [p for p in model.parameters() if p.requires_grad]
         live = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], device=dev)
@@ -197,7 +235,10 @@ def tail_step(model, optimizer, x, y, world: int = 1, rank: int = 0):
         for p, g in zip(keep, flat.split([p.numel() for p in keep])):
             p.grad = g.view_as(p).clone()
         dist.all_reduce(loss_sum, op=dist.ReduceOp.SUM)
+    if getattr(optimizer, "trainer_owns_step", False) and hasattr(optimizer, "device_step_counter"):
+        optimizer.device_step_counter(dev).add_(1)       # (the suspended pack launch would have counted this step)
     optimizer.step()
+    DropoutStream.advance()      # device-counter mode: the tail batch and the next replay must not share dropout masks
     return loss_sum[0].detach()
 
 
@@ -298,7 +339,10 @@ class GraphedTrainStep:
             # warmed-up allocator state): the window position after construction is (warmup + 1) * B * world.
             usable = num // (B * world) * (B * world)
             assert usable > 0, "series shorter than one global minibatch of windows"
-            self.x = torch.as_strided(series, (B, 1, n_his, N), (N, n_his * N, N, 1))           # window b = rows [b, b + n_his)
+            # a model with bf16 activations reads its windows from a bf16 copy of the series (made once; the labels stay fp32)
+            cd = getattr(model, "compute_dtype", None)
+            self.series_x = series if cd in (None, series.dtype) else series.to(cd)
+            self.x = torch.as_strided(self.series_x, (B, 1, n_his, N), (N, n_his * N, N, 1))   # window b = rows [b, b + n_his)
             self.y = series[n_his + n_pred - 1:n_his + n_pred - 1 + B]                         # label rows, (B, N) contiguous
             self.index = torch.full((1,), rank * B, dtype=torch.int64, device=dev)             # first window of this rank
             self._index_bump = (self.index, B * world, usable)

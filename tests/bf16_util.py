@@ -1,0 +1,150 @@
+"""bf16 configurations (BASELINE.json configs[2], [4]): run one ST block with bfloat16 activations through the bound library (the CPU
+emulator or the HIP library, same host code) and compare every stored tensor and every gradient with the bf16 statement of the stage
+oracle (oracle/stblock_stages.py, QuantBf16: same rounding points, float64 accumulation).
+
+Tolerances (stated here, asserted by `assert_bf16_errors`):
+  * stored bf16 tensors: the HIP value and the oracle value are both bf16 numbers formed from sums that differ only in accumulation
+    order / precision (fp32 vs float64), so they are EQUAL except where the sum sits on a rounding boundary (one bf16 ulp apart), and a
+    flipped value then perturbs what is computed from it.  Bars: relative rms error <= 2^-9 (0.2 %: well below the bf16 quantisation
+    noise of 2^-9 / sqrt(3) per element that the fp32 -> bf16 statement itself introduces) and max |diff| <= 2^-5 of the tensor's max.
+  * fp32 outputs (LayerNorm statistics, parameter gradients): relative-to-max error <= 1e-2 (parameter gradients are sums over
+    10^4 - 10^5 products of bf16 numbers: flips average out; measured values are ~1e-3).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import stblock_stages as st
+from stgcn_amd import _lib, ops
+from tests.emu_util import block_case, nonsym_gso, params_in_field_order
+
+Q = st.QuantBf16()
+RMS_TOL = 2.0 ** -9
+MAX_TOL = 2.0 ** -5
+F32_TOL = 1e-2
+
+
+def bf16_tensor(a: np.ndarray, dev) -> torch.Tensor:
+    """float array -> torch.bfloat16 tensor holding RNE-rounded values."""
+    bits = st.to_bf16_bits(a).astype(np.int16)
+    return torch.from_numpy(bits).view(torch.bfloat16).to(dev)
+
+
+def bf16_numpy(t: torch.Tensor) -> np.ndarray:
+    return st.from_bf16_bits(t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16))
+
+
+def seg_bf16(buf_f32: np.ndarray, off_floats: int, shape) -> np.ndarray:
+    """A bf16 tensor stored inside a float32 plan buffer (offsets count 4-byte units)."""
+    n = int(np.prod(shape))
+    bits = buf_f32.view(np.uint16)[2 * off_floats:2 * off_floats + n]
+    return st.from_bf16_bits(bits).reshape(shape)
+
+
+def err_stored(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    d = np.abs(np.asarray(got, dtype=np.float64) - ref)
+    rms_ref = max(1e-30, float(np.sqrt((ref ** 2).mean())))
+    return dict(rms=float(np.sqrt((d ** 2).mean())) / rms_ref, max=float(d.max()) / max(1e-30, float(np.abs(ref).max())),
+                mismatch=float((d > 0).mean()))
+
+
+def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, seed=99, offset=3, pdrop=0.5):
+    """Returns ({name: stored-tensor error dict}, {name: relative-to-max error of an fp32 output})."""
+    L = _lib.lib()
+    cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    if gso is None:
+        gso = nonsym_gso(N, 5)
+    rs = np.random.RandomState(11)
+    x_np = Q(rs.standard_normal((B, c_in, T, N)))                     # bf16 values, logical NCHW
+    T2 = T - 2 * (Kt - 1)
+    dy_np = Q(rs.standard_normal((B, channels[2], T2, N)))
+    bcfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=c_in, channels=tuple(channels), act_func=act, graph_conv_type=gct, droprate=pdrop)
+    gp, gt = ops.gso_prepare(torch.from_numpy(gso).to(dev), ops.graph_terms(bcfg))
+    params = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(p, "st_blocks.0.", gct)]
+    x = bf16_tensor(x_np, dev).requires_grad_(c_in > 1)
+    wsc = ops.WorkspaceCache()
+    y = ops.st_conv_block(x, gp, gt, bcfg, params, training, seed, offset, wsc)
+    assert y.dtype == torch.bfloat16
+    y.backward(bf16_tensor(dy_np, dev))
+    if str(dev).startswith("cuda"):
+        torch.cuda.synchronize()
+
+    cl = lambda a: np.ascontiguousarray(a.transpose(0, 2, 3, 1)).astype(np.float64)
+    keep = None
+    if training:
+        ks = ops.dropout_mask(B * T2 * N * channels[2], pdrop, seed, offset, dev).cpu().numpy().reshape(B, T2, N, channels[2])
+        keep = (ks > 0).astype(np.float64)
+    g64 = gso.astype(np.float64)
+    bp = st.block_params_np(p, "st_blocks.0.", gct, np.float64)
+    y_ref, sv = st.stblock_fwd(cl(x_np), g64, bp, Kt, c_in, channels, gct, act, keep, pdrop, q=Q, gc_form="poly")
+    stages = {}
+    dx_ref, g_ref = st.stblock_bwd(cl(dy_np), sv, g64, bp, Kt, c_in, channels, gct, act, pdrop, need_dx=c_in > 1, q=Q, gc_form="poly",
+                                   stages=stages)
+    # the same block in the fp64 statement: how far the bf16 configuration is from the reference arithmetic (reported, loosely bounded)
+    y64, sv64 = st.stblock_fwd(cl(x_np), g64, bp, Kt, c_in, channels, gct, act, keep, pdrop)
+
+    desc = ops.make_desc(bcfg, B, T, training, c_in > 1, dtype=torch.bfloat16)
+    plan = ops.query_plan(desc)
+    ws = wsc.buf.cpu().numpy()
+    saved = torch.empty(plan.saved_floats, device=dev)
+    y2 = torch.empty(B, T2, N, channels[2], dtype=torch.bfloat16, device=dev)
+    pst = ops._param_struct(_lib.StblockParams, [None if t is None else t.detach() for t in params])
+    x_cl = x.detach().permute(0, 2, 3, 1).contiguous()
+    ws2 = torch.empty(plan.ws_floats, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream if str(dev).startswith("cuda") else None
+    L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gp.data_ptr(), y2.data_ptr(), saved.data_ptr(),
+                                        ws2.data_ptr(), seed, offset, None, stream), "fwd")
+    if str(dev).startswith("cuda"):
+        torch.cuda.synchronize()
+    svn = saved.cpu().numpy()
+    T1 = plan.T1
+    c0, c1, c2 = channels
+    terms = 2 if gct == "graph_conv" else Ks
+    stored, f32 = {}, {}
+    if not plan.recompute_tc1:
+        stored["fwd.U1"] = err_stored(seg_bf16(svn, plan.sv_U1, (B, T1, N, c0)), sv["U1"])
+        stored["fwd.S1"] = err_stored(seg_bf16(svn, plan.sv_S1, (B, T1, N, c0)), sv["S1"])
+    stored["fwd.A"] = err_stored(seg_bf16(svn, plan.sv_A, (B, T1, N, c1)), sv["A"])
+    per = B * T1 * N * c1 // 2      # 4-byte units per term: the X_k follow each other without padding (c1 = 16 elements per row)
+    for k in range(1, terms):
+        stored[f"fwd.X{k}"] = err_stored(seg_bf16(svn, plan.sv_Xk + (k - 1) * per, (B, T1, N, c1)), sv["Xs"][k])
+    stored["fwd.G"] = err_stored(seg_bf16(svn, plan.sv_G, (B, T1, N, c1)), sv["G"])
+    stored["fwd.U2"] = err_stored(seg_bf16(svn, plan.sv_U2, (B, T2, N, c2)), sv["U2"])
+    stored["fwd.S2"] = err_stored(seg_bf16(svn, plan.sv_S2, (B, T2, N, c2)), sv["S2"])
+    stored["fwd.y"] = err_stored(cl(bf16_numpy(y)), y_ref)
+    stored["fwd.y_vs_fp64"] = err_stored(cl(bf16_numpy(y)), y64)          # (reported; bounded loosely below)
+    f32["fwd.mean"] = float(np.abs(svn[plan.sv_mean:plan.sv_mean + B * T2].reshape(B, T2) - sv["mean"]).max() / max(1e-30, np.abs(sv["mean"]).max() + 1e-3))
+    f32["fwd.rstd"] = float(np.abs(svn[plan.sv_rstd:plan.sv_rstd + B * T2].reshape(B, T2) / sv["rstd"] - 1).max())
+    f32["fwd.y_repeat_bitwise"] = float((y2.view(torch.int16) != y.detach().permute(0, 2, 3, 1).contiguous().view(torch.int16)).sum().item())
+    stored["bwd.dYg"] = err_stored(seg_bf16(ws, plan.ws_dYg, (B, T1, N, c1)), stages["dYg"])
+    stored["bwd.dA"] = err_stored(seg_bf16(ws, plan.ws_dA, (B, T1, N, c1)), stages["dA"])
+    if c_in > 1:
+        stored["bwd.dx"] = err_stored(cl(bf16_numpy(x.grad)), dx_ref)
+    rel = lambda got, ref: float(np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()))
+    for name, prm in zip(_lib.PARAM_FIELDS, params):
+        ref = g_ref[name]
+        if prm is None:
+            continue
+        if ref is None:
+            f32["grad_none_ok." + name] = 0.0 if prm.grad is None else 1.0
+            continue
+        f32["grad." + name] = rel(prm.grad.cpu().numpy().astype(np.float64), ref.reshape(prm.shape)) if prm.grad is not None else float("inf")
+    return stored, f32
+
+
+def assert_bf16_errors(stored, f32):
+    bad = {}
+    for k, e in stored.items():
+        if k.endswith("_vs_fp64"):
+            if not (e["rms"] <= 3e-2):          # bf16 storage + bf16 operands vs exact arithmetic: ~1 % rms on unit-variance outputs
+                bad[k] = e
+            continue
+        if not (e["rms"] <= RMS_TOL and e["max"] <= MAX_TOL):
+            bad[k] = e
+    for k, v in f32.items():
+        tol = 0.0 if (k.startswith("grad_none_ok") or k.endswith("bitwise")) else (1e-4 if k in ("fwd.mean", "fwd.rstd") else F32_TOL)
+        if not (v <= tol):
+            bad[k] = v
+    assert not bad, f"out of tolerance: {bad}\nstored: {stored}\nf32: {f32}"

@@ -171,6 +171,32 @@ static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, e
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
+// v_mfma_f32_16x16x16_bf16: lane l holds 4 bf16 of A[i = l & 15][k = 4 * (l >> 4) + e] and of B[k][j = l & 15]; C/D as the f32 form
+typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 emu_mfma_f32_16x16x16bf16_1k(emu_s16x4 a, emu_s16x4 b, emu_f32x4 c) {
+    const unsigned t = emu::g.threadIdx_.x;
+    emu::WaveState& w = emu::g.waves[t / emu::kWave];
+    const int lane = t % emu::kWave;
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t xa = (uint32_t)(unsigned short)a[e] << 16, xb = (uint32_t)(unsigned short)b[e] << 16;
+        memcpy(&w.a8[lane][e], &xa, 4);
+        memcpy(&w.b8[lane][e], &xb, 4);
+    }
+    emu::wave_barrier();
+    emu_f32x4 d = c;
+    const int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg)
+            for (int e = 0; e < 4; ++e) acc = fmaf(w.a8[i + 16 * kg][e], w.b8[j + 16 * kg][e], acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    if (lane == 0) emu::g.n_mfma++;
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) emu_mfma_f32_16x16x16bf16_1k((a), (b), (c))
 // global_load_lds: lane i copies `size` bytes from its own global pointer to (wave-uniform LDS base) + size * i + offset
 static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned size, int off) {
     memcpy(static_cast<char*>(lds_base) + (emu::g.threadIdx_.x % emu::kWave) * size + off, g, size);
