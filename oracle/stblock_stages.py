@@ -235,7 +235,19 @@ def gconv_bwd(dG, G, Xs, gso, Wk, q=None, form="recursion"):
             for k in range(1, Ks):
                 dA = dA + _gso_apply(q(Tk[k]).T, q(Gk[k]))
             return dA, dWk, dbias
-        raise NotImplementedError("bf16 statement of the tiled (Clenshaw) backward: see gconv_bwd_clenshaw_q")
+        # tiled path: g_k = q(dY) q(W_k^T) (+ dY on k = 0) stored as q(g_k); then the Clenshaw recurrence in place over the stored
+        # buffers, every operator product with q(L^T) and the stored operand, every result stored:
+        #     b_K = g_K ; b_k = q(g_k + 2 L^T b_{k+1} - b_{k+2}) ; dA = g_0 + L^T b_1 - b_2
+        K = Ks - 1
+        g = [q(Gk[k] + (dY if k == 0 else 0.0)) for k in range(Ks)]
+        if K == 0:
+            return g[0], dWk, dbias
+        LT = q(np.asarray(gso, dtype=np.float64)).T
+        b = list(g)
+        for k in range(K - 1, 0, -1):
+            b[k] = q(g[k] + 2.0 * _gso_apply(LT, b[k + 1]) - (b[k + 2] if k + 2 <= K else 0.0))
+        dA = g[0] + _gso_apply(LT, b[1]) - (b[2] if K >= 2 else 0.0)
+        return dA, dWk, dbias
     dWk = np.stack([Xs[k].reshape(-1, Xs[k].shape[-1]).T @ dY.reshape(-1, dY.shape[-1]) for k in range(Ks)])
     dbias = dY.reshape(-1, dY.shape[-1]).sum(0)
     Gk = [dY @ Wk[k].T for k in range(Ks)]
@@ -250,13 +262,16 @@ def gconv_bwd(dG, G, Xs, gso, Wk, q=None, form="recursion"):
 
 
 # ----------------------------------------------------------------------------- LayerNorm + dropout
-def ln_dropout_fwd(H, gamma, beta, keep, p, eps=1e-12):
+def ln_dropout_fwd(H, gamma, beta, keep, p, eps=1e-12, H_norm=None):
     """LayerNorm over the joint [N, C] axes per (b, t), biased variance (layers.py:246, 255),
-    then inverted dropout with an explicit keep mask (layers.py:256).  keep None -> eval."""
+    then inverted dropout with an explicit keep mask (layers.py:256).  keep None -> eval.
+    H_norm (bf16 statement only): the values that are normalised when they differ from the values the statistics were formed from --
+    the kernels that run LayerNorm as a separate pass (ln_norm_kernel, the head's fc staging) rebuild H from the STORED gate inputs,
+    while the statistics always come from the unrounded H of the conv epilogue."""
     mean = H.mean(axis=(2, 3), keepdims=True)
     var = ((H - mean) ** 2).mean(axis=(2, 3), keepdims=True)
     rstd = 1.0 / np.sqrt(var + eps)
-    y = (H - mean) * rstd * gamma + beta
+    y = ((H if H_norm is None else H_norm) - mean) * rstd * gamma + beta
     if keep is not None:
         y = y * keep * (1.0 / (1.0 - p))
     return y, mean[..., 0, 0], rstd[..., 0, 0]
@@ -292,10 +307,12 @@ def _gate(U, S, act):
 
 
 def stblock_fwd(x, gso, bp, Kt, c_in, channels, graph_conv_type="cheb_graph_conv", act="glu",
-                keep=None, p_drop=0.0, q=None, gc_form="poly"):
+                keep=None, p_drop=0.0, q=None, gc_form="poly", ln_from_stored=False):
     """x channels-last (B,T,N,c_in).  Returns (y (B,T2,N,c2), saved dict).
     ``q``: rounding rule of the bf16 configurations (QuantBf16; x must then hold bf16 values): `saved` carries what the HIP path
-    stores (q(U1), q(S1), q(A), q(X_k), q(G), q(U2), q(S2)) plus the unrounded H1 / H2 of the forward; y is q(dropout(LN(H2)))."""
+    stores (q(U1), q(S1), q(A), q(X_k), q(G), q(U2), q(S2)) plus the unrounded H1 / H2 of the forward; y is q(dropout(LN(H2))).
+    ln_from_stored: the block's LayerNorm runs as a separate pass over the stored gate inputs (more than 448 nodes: ln_norm_kernel)
+    instead of inside tc2_ln_fwd_kernel, which normalises the values it still holds in registers."""
     c0, c1, c2 = channels
     W1, b1 = fold_tconv(bp["tc1_w"], bp["tc1_b"], bp["tc1_aw"], bp["tc1_ab"], c_in, c0, Kt)
     U1, S1, H1 = tconv_fwd(x, W1, b1, Kt, c0, act, q)
@@ -306,7 +323,8 @@ def stblock_fwd(x, gso, bp, Kt, c_in, channels, graph_conv_type="cheb_graph_conv
     G = _q(q, G)
     W2, b2 = fold_tconv(bp["tc2_w"], bp["tc2_b"], bp["tc2_aw"], bp["tc2_ab"], c1, c2, Kt)
     U2, S2, H2 = tconv_fwd(G, W2, b2, Kt, c2, act, q)
-    y, mean, rstd = ln_dropout_fwd(H2, bp["ln_w"], bp["ln_b"], keep, p_drop)
+    Hn = _gate(q(U2), q(S2), act) if (q is not None and ln_from_stored) else None
+    y, mean, rstd = ln_dropout_fwd(H2, bp["ln_w"], bp["ln_b"], keep, p_drop, H_norm=Hn)
     y = _q(q, y)
     if q is not None:
         # backward of a bf16 block works on the STORED gate inputs -- except the cheap first conv (Kt*c_in <= 16), whose U1 / S1 are
@@ -373,7 +391,8 @@ def outblock_fwd(x, hp, Ko, c_in, channels, act="glu", keep=None, p_drop=0.0, q=
     c0, c1 = channels
     W, b = fold_tconv(hp["tc_w"], hp["tc_b"], hp["tc_aw"], hp["tc_ab"], c_in, c0, Ko)
     U, S, H = tconv_fwd(x, W, b, Ko, c0, act, q)
-    yln, mean, rstd = ln_dropout_fwd(H, hp["ln_w"], hp["ln_b"], None, 0.0)
+    Hn = None if q is None else _gate(q(U), q(S), act)      # the head's LayerNorm runs in the fc kernel's staging, on the stored gate inputs
+    yln, mean, rstd = ln_dropout_fwd(H, hp["ln_w"], hp["ln_b"], None, 0.0, H_norm=Hn)
     W1 = hp["fc1_w"]                                                   # (c1, c0)
     h1 = _q(q, yln) @ _q(q, W1).T
     if hp["fc1_b"] is not None:

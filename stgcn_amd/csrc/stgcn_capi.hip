@@ -398,6 +398,7 @@ int launch_gso_gemm_ntw(const char* label, GsoGemmArgs g, hipStream_t st) {
 }
 int launch_gso_gemm(const char* label, const float* M, const float* X, float alpha, const float* Z1, float b1, const float* Z2, float b2,
                     float* out, int N, int NP, long slabs, hipStream_t st) {
+    STGCN_F32_ONLY(label);
     GsoGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.X = X; g.Z1 = Z1; g.Z2 = Z2; g.out = out; g.alpha = alpha; g.b1 = b1; g.b2 = b2;
@@ -430,8 +431,8 @@ inline OperandBuf operand_buf(float* XT, int which, long CP, int NP) {
     return OperandBuf{base, base + (size_t)CP * LD / 2};
 }
 int launch_pack_operand(const float* X, int N, int NP, long slabs, OperandBuf o, hipStream_t st) {
-    STGCN_LAUNCH("gc_pack_operand", st, gc_pack_operand_kernel, dim3((unsigned)cdiv(NP, 256), (unsigned)slabs), dim3(256), 256 * 17 * sizeof(float),
-                 X, N, NP, gc_plane_ld(NP), o.hi, o.lo);
+    STGCN_LAUNCH_ET("gc_pack_operand", st, (gc_pack_operand_kernel<ET>), dim3((unsigned)cdiv(NP, 256), (unsigned)slabs), dim3(256), 256 * 17 * sizeof(float),
+                    X, N, NP, gc_plane_ld(NP), o.hi, o.lo);
     return STGCN_OK;
 }
 int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, float alpha, const float* Z1, float b1, const float* Z2, float b2,
@@ -451,21 +452,21 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     // depth of a pipeline step: 32 (more workgroups per CU) or 64 bf16 (half as many barriers); STGCN_GEMM_BF16_BK forces one
     static const int force_bk = getenv("STGCN_GEMM_BF16_BK") ? atoi(getenv("STGCN_GEMM_BF16_BK")) : 0;
     const int bk = force_bk == 32 || force_bk == 64 ? force_bk : kGbDefaultBK;
-    const int split = g_gc_precision == 1;
+    const int split = g_gc_precision == 1 && !g_bf16;   // (bf16 activations: operands are bf16 numbers already, one MFMA per product)
     const size_t lds = gb_lds_floats(split, bk) * sizeof(float);
-    if (split && bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 64>), grid, dim3(256), lds, g);
-    else if (split) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 32>), grid, dim3(256), lds, g);
-    else if (bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0, 64>), grid, dim3(256), lds, g);
-    else STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<0, 32>), grid, dim3(256), lds, g);
+    if (split && bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 64, float>), grid, dim3(256), lds, g);
+    else if (split) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 32, float>), grid, dim3(256), lds, g);
+    else if (bk == 64) STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_kernel<0, 64, ET>), grid, dim3(256), lds, g);
+    else STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_kernel<0, 32, ET>), grid, dim3(256), lds, g);
     return STGCN_OK;
 }
 
 int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
-    STGCN_F32_ONLY("tiled graph conv");
     if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
     if (a.Ks > 1 && !a.Xk) return fail(STGCN_ERR_INVALID, "tiled graph conv needs the X_k buffers");
-    const long ks = a.slabs * a.N * 16;
-    const bool bf = g_gc_precision > 0 && a.Ks > 1;
+    const long ks = a.slabs * a.N * 16;                 // elements per term
+    const long ksf = g_bf16 ? ks / 2 : ks;              // ... in the 4-byte units of the float* slots
+    const bool bf = (g_gc_precision > 0 || g_bf16) && a.Ks > 1;   // bf16 activations: the operator products run on the bf16 matrix cores
     if (bf && !a.XT) return fail(STGCN_ERR_INVALID, "tiled graph conv (bf16 operator products) needs the operand workspace");
     const long CP = gc_operand_cols(a.slabs);
     if (bf) {
@@ -474,15 +475,16 @@ int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
     }
     // X_1 = L X_0 ; X_k = 2 L X_{k-1} - X_{k-2}   (layers.py:153-161; GraphConv: X_1 = A_hat X_0, layers.py:198)
     for (int k = 1; k < a.Ks; ++k) {
-        const float* Xm1 = k == 1 ? a.A : a.Xk + (size_t)(k - 2) * ks;
-        const float* Xm2 = k == 1 ? nullptr : (k == 2 ? a.A : a.Xk + (size_t)(k - 3) * ks);
-        float* out = a.Xk + (size_t)(k - 1) * ks;
+        const float* Xm1 = k == 1 ? a.A : a.Xk + (size_t)(k - 2) * ksf;
+        const float* Xm2 = k == 1 ? nullptr : (k == 2 ? a.A : a.Xk + (size_t)(k - 3) * ksf);
+        float* out = a.Xk + (size_t)(k - 1) * ksf;
         int rc;
         if (bf) {
             const OperandBuf next = operand_buf(a.XT, k & 1, CP, a.NP);   // term k reads buffer (k - 1) & 1
             rc = launch_gso_gemm_bf16("gso_gemm_fwd", a.Lp, operand_buf(a.XT, (k - 1) & 1, CP, a.NP), k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f,
                                       out, k + 1 < a.Ks ? &next : nullptr, a.N, a.NP, a.slabs, st);
         } else {
+            (void)Xm1;
             rc = launch_gso_gemm("gso_gemm_fwd", a.Lp, Xm1, k == 1 ? 1.f : 2.f, Xm2, -1.f, nullptr, 0.f, out, a.N, a.NP, a.slabs, st);
         }
         if (rc) return rc;
@@ -492,26 +494,26 @@ int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
     r.X0 = a.A; r.Xk = a.Xk; r.W = a.W; r.bias = a.bias; r.G = a.G; r.rows = a.slabs * a.N; r.kstride = ks; r.terms = a.Ks; r.kipf = a.kipf;
     const long tiles = (r.rows + 15) / 16;
     const long wgs = (tiles + 3) / 4;
-    STGCN_LAUNCH("gconv_rows_fwd", st, gconv_rows_fwd_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, r);
+    STGCN_LAUNCH_ET("gconv_rows_fwd", st, (gconv_rows_fwd_kernel<ET>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, r);
     return STGCN_OK;
 }
 // backward: row pass (g_k, parameter-gradient partials), then dA = sum_k T_k(L^T) g_k by the Clenshaw recurrence
 //     b_K = g_K ; b_k = g_k + 2 L^T b_{k+1} - b_{k+2} (in place over g_k) ; dA = g_0 + L^T b_1 - b_2
 int launch_gconv_bwd_tiled(const GconvBwdArgs& a, hipStream_t st) {
-    STGCN_F32_ONLY("tiled graph conv");
     if (a.Ks > kGcMaxTerms) return fail(STGCN_ERR_UNSUPPORTED, "tiled graph conv with %d terms (supported: up to %d)", a.Ks, kGcMaxTerms);
     if (!a.Gk || a.wgs < 1 || a.tiles_per_wg < 1) return fail(STGCN_ERR_INVALID, "tiled graph-conv backward: missing workspace / geometry");
-    const long ks = a.slabs * a.N * 16;
+    const long ks = a.slabs * a.N * 16;                 // elements per term
+    const long ksf = g_bf16 ? ks / 2 : ks;              // ... in the 4-byte units of the float* slots
     const int K = a.Ks - 1;
     GcRowsBwdArgs r;
     memset(&r, 0, sizeof(r));
     r.dY = a.dY; r.X0 = a.X0; r.Xk = a.Xk; r.W = a.W; r.part = a.part; r.rows = a.slabs * a.N; r.kstride = ks; r.gstride = ks;
     r.Gk = K == 0 ? a.dA : a.Gk;   // a single term: g_0 (+ dY) is dA itself
     r.terms = a.Ks; r.kipf = a.kipf; r.tiles_per_wg = a.tiles_per_wg;
-    STGCN_LAUNCH("gconv_rows_bwd", st, gconv_rows_bwd_kernel, dim3((unsigned)a.wgs), dim3(256), (size_t)4 * (a.Ks + 1) * 256 * sizeof(float), r);
+    STGCN_LAUNCH_ET("gconv_rows_bwd", st, (gconv_rows_bwd_kernel<ET>), dim3((unsigned)a.wgs), dim3(256), (size_t)4 * (a.Ks + 1) * 256 * sizeof(float), r);
     if (K == 0) return STGCN_OK;
-    auto gk = [&](int k) { return a.Gk + (size_t)k * ks; };
-    if (g_gc_precision > 0) {   // bf16 / bf16x3 products: b_{k+1} travels in operand form from epilogue to epilogue
+    auto gk = [&](int k) { return a.Gk + (size_t)k * ksf; };
+    if (g_gc_precision > 0 || g_bf16) {   // bf16 / bf16x3 products: b_{k+1} travels in operand form from epilogue to epilogue
         if (!a.XT) return fail(STGCN_ERR_INVALID, "tiled graph-conv backward (bf16 operator products) needs the operand workspace");
         const long CP = gc_operand_cols(a.slabs);
         int cur = 0;
@@ -841,7 +843,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_dA = take(act(v.rows1 * d->c1));
     p->ws_dZ1 = take(act(v.rows1 * v.NC1));
     p->tiled_gc = v.tiled;
-    p->ws_Gk = take(v.tiled ? (int64_t)v.terms * v.rows1 * d->c1 : 0);
+    p->ws_Gk = take(v.tiled ? (int64_t)v.terms * act(v.rows1 * d->c1) : 0);
     p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
     p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
     p->ws_part = take(p->part_floats);

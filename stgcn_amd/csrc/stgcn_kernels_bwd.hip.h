@@ -278,7 +278,12 @@ __global__ __launch_bounds__(256) void ln_slab_consts_kernel(LnBwdArgs a) {
 // A thread owns one float4 column of the [N*C] slab and walks `spg` consecutive slabs.
 // grid = (ceil(n/4 / 256), sg); dynamic LDS: 8 + 2*spg floats
 // ================================================================================================
+template <typename ET>
 __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
+    const ET* const dy_ = et_ptr<ET>(a.dy);
+    const ET* const U_ = et_ptr<ET>(a.U);
+    const ET* const S_ = et_ptr<ET>(a.S);
+    ET* const dZ_ = et_ptr<ET>(a.dZ);
     extern __shared__ float stgcn_smem[];
     float* cs = stgcn_smem + 8;
     const int n4 = a.n >> 2;
@@ -321,14 +326,14 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
     f32x4 dy_n = zero4(), u_n = zero4(), s_n = zero4();
     if (s0 < s1) {
         const size_t base = (size_t)s0 * a.n + 4 * (size_t)q;
-        dy_n = ld4(a.dy + base); u_n = ld4(a.U + base); s_n = ld4(a.S + base);
+        dy_n = ldx4(dy_ + base); u_n = ldx4(U_ + base); s_n = ldx4(S_ + base);
     }
     for (long slab = s0; slab < s1; ++slab) {
         f32x4 dy = dy_n;
         const f32x4 u = u_n, s = s_n;
         if (slab + 1 < s1) {
             const size_t nb = (size_t)(slab + 1) * a.n + 4 * (size_t)q;
-            dy_n = ld4(a.dy + nb); u_n = ld4(a.U + nb); s_n = ld4(a.S + nb);
+            dy_n = ldx4(dy_ + nb); u_n = ldx4(U_ + nb); s_n = ldx4(S_ + nb);
         }
         const float mean = a.mean[slab], rstd = a.rstd[slab], c1 = cs[2 * (slab - s0)], c2 = cs[2 * (slab - s0) + 1];
         if (a.training) {
@@ -349,9 +354,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(LnBwdArgs a) {
             du[i] = du_;
             dq[i] = dq_;
         }
-        float* z = a.dZ + ((size_t)slab * N + node) * (2 * a.C) + 4 * c4;
-        st4_wt(z, du);
-        st4_wt(z + a.C, dq);
+        ET* z = dZ_ + ((size_t)slab * N + node) * (2 * a.C) + 4 * c4;
+        stx4_wt(z, du);
+        stx4_wt(z + a.C, dq);
     }
     st4_wt(a.dgam_part + (size_t)sg * a.n + 4 * (size_t)q, dg);
     st4_wt(a.dbet_part + (size_t)sg * a.n + 4 * (size_t)q, db);
@@ -818,8 +823,9 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
     f32x4 wpr[kThinK], wqr[kThinK];
 #pragma unroll
     for (int k = 0; k < kThinK; ++k) {
-        wpr[k] = k < K ? ld4(a.Wd + (size_t)k * NC + 4 * c4) : zero4();
-        wqr[k] = k < K ? ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4) : zero4();
+        // (bf16: the forward formed these gate inputs on the matrix cores from ROUNDED weights; the recomputation uses the same numbers)
+        wpr[k] = et_round4<ET>(k < K ? ld4(a.Wd + (size_t)k * NC + 4 * c4) : zero4());
+        wqr[k] = et_round4<ET>(k < K ? ld4(a.Wd + (size_t)k * NC + c0 + 4 * c4) : zero4());
     }
     const f32x4 bu = ld4(a.bias + 4 * c4), bqv = ld4(a.bias + c0 + 4 * c4);
     const ET* const xsrc = tap_base<ET>(a.ts);

@@ -883,6 +883,7 @@ struct LnGateBwdIn {
     const float2* rowstat;   // [slabs*N]  (sum g, sum g * xhat) per row
     float* dZ;            // [slabs*N][2C]
     float* dgam;          // [slabs][N][C]
+    float* dbet;          // [slabs][N][C] fp32 copy of dy for the dbeta reduction, or null: dbeta is reduced from the fp32 dy tensor itself
     int N, C, act;
 };
 struct Tconv4Args {
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                     stx4_wt(et_ptr<ET>(b.dZ) + (size_t)R * 2 * C + 4 * c4, du);
                     stx4_wt(et_ptr<ET>(b.dZ) + (size_t)R * 2 * C + C + 4 * c4, dq);
                     st4_wt(b.dgam + e, dg);
+                    if (b.dbet) st4_wt(b.dbet + e, dy);
                 }
             }
             for (int idx = tid; idx < TR * 2 * c4n; idx += THREADS) {   // rows past the end of the last tile

@@ -165,7 +165,12 @@ struct GcRowsFwdArgs {
     int terms, kipf;
 };
 
+template <typename ET>
 __global__ __launch_bounds__(256) void gconv_rows_fwd_kernel(GcRowsFwdArgs a) {
+    typedef Mma<ET> MM;
+    const ET* const X0_ = et_ptr<ET>(a.X0);
+    const ET* const Xk_ = et_ptr<ET>(a.Xk);
+    ET* const G_ = et_ptr<ET>(a.G);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     f32x4 wf[kGcMaxTerms];   // B[kk = c = 4g + s][col = j = l15] = W_k[c][j]
 #pragma unroll
@@ -186,16 +191,15 @@ __global__ __launch_bounds__(256) void gconv_rows_fwd_kernel(GcRowsFwdArgs a) {
 #pragma unroll
         for (int k = 0; k < kGcMaxTerms; ++k) {
             if (k < a.terms && !(a.kipf && k == 0)) {
-                const float* Xs = k == 0 ? a.X0 : a.Xk + (size_t)(k - 1) * a.kstride;
-                const f32x4 xa = in ? ld4(Xs + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][c = 4g + s]
-#pragma unroll
-                for (int s = 0; s < 4; ++s) y = mfma4(xa[s], wf[k][s], y);
+                const ET* Xs = k == 0 ? X0_ : Xk_ + (size_t)(k - 1) * a.kstride;
+                const f32x4 xa = in ? ldx4(Xs + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][c = 4g + s]
+                y = MM::mma(MM::cvt(xa), MM::cvt(wf[k]), y);
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long rr = row0 + 4 * g + r;   // D[row = 4g + r][j = l15]
-            if (rr < a.rows) a.G[(size_t)rr * 16 + l15] = fmaxf(y[r] + bb + a.X0[(size_t)rr * 16 + l15], 0.f);
+            if (rr < a.rows) stx1(G_ + (size_t)rr * 16 + l15, fmaxf(y[r] + bb + ldx1(X0_ + (size_t)rr * 16 + l15), 0.f));
         }
     }
 }
@@ -219,7 +223,13 @@ struct GcRowsBwdArgs {
     int terms, kipf, tiles_per_wg;
 };
 
+template <typename ET>
 __global__ __launch_bounds__(256) void gconv_rows_bwd_kernel(GcRowsBwdArgs a) {
+    typedef Mma<ET> MM;
+    const ET* const dY_ = et_ptr<ET>(a.dY);
+    const ET* const X0_ = et_ptr<ET>(a.X0);
+    const ET* const Xk_ = et_ptr<ET>(a.Xk);
+    ET* const Gk_ = et_ptr<ET>(a.Gk);
     extern __shared__ float stgcn_smem[];   // [4][(terms + 1) * 256]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int terms = a.terms, PS = (terms + 1) * 256;
@@ -237,32 +247,33 @@ __global__ __launch_bounds__(256) void gconv_rows_bwd_kernel(GcRowsBwdArgs a) {
     if (t1 > tiles) t1 = tiles;
     for (long tile = t0 + w; tile < t1; tile += 4) {
         const long row0 = tile << 4, row = row0 + l15;
-        const f32x4 ya = row < a.rows ? ld4(a.dY + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][j = 4g + s]
-        float yb[4];                                                                       // B[kk = row 4g + s][col = j = l15]
+        const f32x4 ya = row < a.rows ? ldx4(dY_ + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][j = 4g + s]
+        f32x4 yb;                                                                          // B[kk = row 4g + s][col = j = l15]
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const long rr = row0 + 4 * g + s;
-            yb[s] = rr < a.rows ? a.dY[(size_t)rr * 16 + l15] : 0.f;
+            yb[s] = rr < a.rows ? ldx1(dY_ + (size_t)rr * 16 + l15) : 0.f;
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) db = mfma4(1.0f, yb[s], db);
+        const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+        const typename MM::frag fya = MM::cvt(ya), fyb = MM::cvt(yb);
+        db = MM::mma(MM::cvt(ones), fyb, db);
 #pragma unroll
         for (int k = 0; k < kGcMaxTerms; ++k) {
             if (k < terms) {
-                const float* Xs = k == 0 ? a.X0 : a.Xk + (size_t)(k - 1) * a.kstride;
-                f32x4 gk = zero4();
+                const ET* Xs = k == 0 ? X0_ : Xk_ + (size_t)(k - 1) * a.kstride;
+                f32x4 xa;                                                                  // A[i = l15][kk = row 4g + s]
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const long rr = row0 + 4 * g + s;
-                    const float xa = rr < a.rows ? Xs[(size_t)rr * 16 + l15] : 0.f;   // A[i = l15][kk = row 4g + s]
-                    dw[k] = mfma4(xa, yb[s], dw[k]);
-                    gk = mfma4(ya[s], wt[k][s], gk);
+                    xa[s] = rr < a.rows ? ldx1(Xs + (size_t)rr * 16 + l15) : 0.f;
                 }
-                float* Go = a.Gk + (size_t)k * a.gstride;
+                f32x4 gk = zero4();
+                MM::mma_2x(MM::cvt(xa), fyb, dw[k], fya, MM::cvt(wt[k]), gk);
+                ET* Go = Gk_ + (size_t)k * a.gstride;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long rr = row0 + 4 * g + r;   // D[row = 4g + r][i = l15]
-                    if (rr < a.rows) Go[(size_t)rr * 16 + l15] = gk[r] + (k == 0 ? yb[r] : 0.f);
+                    if (rr < a.rows) stx1(Go + (size_t)rr * 16 + l15, gk[r] + (k == 0 ? yb[r] : 0.f));
                 }
             }
         }
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(256) void gso_bf16_kernel(const float* L, int N, in
 }
 
 // X [slabs][N][16] fp32 -> operand form (hi, lo) [CP][NP]; grid = (ceil(NP / 256), slabs), 256 nodes of one slab per workgroup
+template <typename ET>
 __global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, int N, int NP, int LD, float* Oh, float* Ol) {
     extern __shared__ float stgcn_smem[];   // [256][17]
     const int tid = threadIdx.x, m0 = (int)blockIdx.x * 256;
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256) void gc_pack_operand_kernel(const float* X, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, node = f >> 2, c4 = f & 3, m = m0 + node;
-        const f32x4 v = m < N ? ld4(X + ((size_t)slab * N + m) * 16 + c4 * 4) : zero4();
+        const f32x4 v = m < N ? ldx4(et_ptr<ET>(X) + ((size_t)slab * N + m) * 16 + c4 * 4) : zero4();
 #pragma unroll
         for (int j = 0; j < 4; ++j) stgcn_smem[node * 17 + c4 * 4 + j] = v[j];
     }
@@ -401,7 +413,7 @@ struct GsoGemmBfArgs {
 // Same 128 x 128 workgroup tile and 2 x 2 waves of 64 x 64 as gso_gemm_kernel; per BK-deep step a wave issues BK/2 (bf16) or
 // 3 BK/2 (bf16x3) MFMAs of 16 cycles.  BK = 32 halves the LDS footprint (32 / 64 KB): three (bf16) / two (bf16x3) workgroups
 // per CU instead of two / one, i.e. more independent waves to fill the copy / barrier / fragment-read gaps of each other.
-template <int SPLIT, int BK>
+template <int SPLIT, int BK, typename ET>
 __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
     extern __shared__ float stgcn_smem[];
     constexpr int NPL = SPLIT ? 2 : 1;              // planes per operand
@@ -497,9 +509,9 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
                     if (nb + r < N) {
                         const size_t o = ((size_t)slab * N + nb + r) * 16 + ch;
                         float t = a.alpha * acc[mt][nt][r];
-                        if (a.Z1) t += a.b1 * a.Z1[o];
-                        if (a.Z2) t += a.b2 * a.Z2[o];
-                        a.out[o] = t;
+                        if (a.Z1) t += a.b1 * ldx1(et_ptr<ET>(a.Z1) + o);
+                        if (a.Z2) t += a.b2 * ldx1(et_ptr<ET>(a.Z2) + o);
+                        stx1(et_ptr<ET>(a.out) + o, t);
                         v[r] = t;
                     }
                 }

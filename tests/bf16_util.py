@@ -50,8 +50,9 @@ def err_stored(got, ref):
                 mismatch=float((d > 0).mean()))
 
 
-def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, seed=99, offset=3, pdrop=0.5):
-    """Returns ({name: stored-tensor error dict}, {name: relative-to-max error of an fp32 output})."""
+def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, seed=99, offset=3, pdrop=0.5, gc_form=None):
+    """Returns ({name: stored-tensor error dict}, {name: relative-to-max error of an fp32 output}).
+    gc_form: "poly" (slab-resident graph conv) / "recursion" (tiled path); None = whichever the plan selects."""
     L = _lib.lib()
     cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
     if gso is None:
@@ -78,15 +79,14 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
         keep = (ks > 0).astype(np.float64)
     g64 = gso.astype(np.float64)
     bp = st.block_params_np(p, "st_blocks.0.", gct, np.float64)
-    y_ref, sv = st.stblock_fwd(cl(x_np), g64, bp, Kt, c_in, channels, gct, act, keep, pdrop, q=Q, gc_form="poly")
-    stages = {}
-    dx_ref, g_ref = st.stblock_bwd(cl(dy_np), sv, g64, bp, Kt, c_in, channels, gct, act, pdrop, need_dx=c_in > 1, q=Q, gc_form="poly",
-                                   stages=stages)
+    desc = ops.make_desc(bcfg, B, T, training, c_in > 1, dtype=torch.bfloat16)
+    plan = ops.query_plan(desc)
+    if gc_form is None:
+        gc_form = "recursion" if plan.tiled_gc else "poly"
+    y_ref, sv = st.stblock_fwd(cl(x_np), g64, bp, Kt, c_in, channels, gct, act, keep, pdrop, q=Q, gc_form=gc_form, ln_from_stored=N > 448)
     # the same block in the fp64 statement: how far the bf16 configuration is from the reference arithmetic (reported, loosely bounded)
     y64, sv64 = st.stblock_fwd(cl(x_np), g64, bp, Kt, c_in, channels, gct, act, keep, pdrop)
 
-    desc = ops.make_desc(bcfg, B, T, training, c_in > 1, dtype=torch.bfloat16)
-    plan = ops.query_plan(desc)
     ws = wsc.buf.cpu().numpy()
     saved = torch.empty(plan.saved_floats, device=dev)
     y2 = torch.empty(B, T2, N, channels[2], dtype=torch.bfloat16, device=dev)
@@ -118,6 +118,22 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     f32["fwd.mean"] = float(np.abs(svn[plan.sv_mean:plan.sv_mean + B * T2].reshape(B, T2) - sv["mean"]).max() / max(1e-30, np.abs(sv["mean"]).max() + 1e-3))
     f32["fwd.rstd"] = float(np.abs(svn[plan.sv_rstd:plan.sv_rstd + B * T2].reshape(B, T2) / sv["rstd"] - 1).max())
     f32["fwd.y_repeat_bitwise"] = float((y2.view(torch.int16) != y.detach().permute(0, 2, 3, 1).contiguous().view(torch.int16)).sum().item())
+    # Backward: checked on the HIP path's OWN saved tensors ("teacher forcing").  ReLU is discontinuous: where a stored G sits on the
+    # rounding boundary next to zero the two forwards may disagree about the mask, and a flipped mask changes the gradient entering the
+    # graph conv by O(1) in that element -- a property of the forward's rounding, not of the backward kernels under test.
+    svh = dict(sv)
+    if not plan.recompute_tc1:
+        svh["U1"], svh["S1"] = seg_bf16(svn, plan.sv_U1, (B, T1, N, c0)), seg_bf16(svn, plan.sv_S1, (B, T1, N, c0))
+        svh["H1"] = st._gate(svh["U1"], svh["S1"], act)
+    svh["A"] = seg_bf16(svn, plan.sv_A, (B, T1, N, c1))
+    svh["Xs"] = [svh["A"]] + [seg_bf16(svn, plan.sv_Xk + (k - 1) * per, (B, T1, N, c1)) for k in range(1, terms)]
+    svh["G"] = seg_bf16(svn, plan.sv_G, (B, T1, N, c1))
+    svh["U2"], svh["S2"] = seg_bf16(svn, plan.sv_U2, (B, T2, N, c2)), seg_bf16(svn, plan.sv_S2, (B, T2, N, c2))
+    svh["mean"] = svn[plan.sv_mean:plan.sv_mean + B * T2].reshape(B, T2).astype(np.float64)
+    svh["rstd"] = svn[plan.sv_rstd:plan.sv_rstd + B * T2].reshape(B, T2).astype(np.float64)
+    stages = {}
+    dx_ref, g_ref = st.stblock_bwd(cl(dy_np), svh, g64, bp, Kt, c_in, channels, gct, act, pdrop, need_dx=c_in > 1, q=Q, gc_form=gc_form,
+                                   stages=stages)
     stored["bwd.dYg"] = err_stored(seg_bf16(ws, plan.ws_dYg, (B, T1, N, c1)), stages["dYg"])
     stored["bwd.dA"] = err_stored(seg_bf16(ws, plan.ws_dA, (B, T1, N, c1)), stages["dA"])
     if c_in > 1:
@@ -148,3 +164,46 @@ def assert_bf16_errors(stored, f32):
         if not (v <= tol):
             bad[k] = v
     assert not bad, f"out of tolerance: {bad}\nstored: {stored}\nf32: {f32}"
+
+
+def run_head_case_bf16(dev, N, B, c_in=64, channels=(128, 128), Ko=4, act="glu", training=True, seed=5, offset=9, pdrop=0.5):
+    """The output head with bf16 activations against outblock_fwd / outblock_bwd of the stage oracle (q = QuantBf16)."""
+    from oracle import stgcn_oracle as orc
+    cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=12, act_func=act, graph_conv_type="cheb_graph_conv", droprate=pdrop,
+                           blocks=[[1], [64, 16, 64], [64, 16, c_in], list(channels), [1]])
+    full = orc.random_params(cfg, N, seed=3, dtype=torch.float32)
+    p = {k: v for k, v in full.items() if k.startswith("output.")}
+    names = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight", "tmp_conv1.align.align_conv.bias",
+             "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    params = [p["output." + n].clone().to(dev).requires_grad_(True) for n in names]
+    rs = np.random.RandomState(4)
+    x_np = Q(rs.standard_normal((B, c_in, Ko, N)))
+    dout_np = rs.standard_normal((B, 1, 1, N)).astype(np.float32)
+    hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=c_in, channels=tuple(channels), end_channel=1, act_func=act, droprate=pdrop)
+    x = bf16_tensor(x_np, dev).requires_grad_(True)
+    wsc = ops.WorkspaceCache()
+    out = ops.output_block(x, hcfg, params, training, seed, offset, wsc)
+    assert out.dtype == torch.float32 and out.shape == (B, 1, 1, N)
+    out.backward(torch.from_numpy(dout_np).to(dev))
+    if str(dev).startswith("cuda"):
+        torch.cuda.synchronize()
+    cl = lambda a: np.ascontiguousarray(a.transpose(0, 2, 3, 1)).astype(np.float64)
+    keep = None
+    c0, c1 = channels
+    if training:
+        ks = ops.dropout_mask(B * N * c1, pdrop, seed, offset, dev).cpu().numpy().reshape(B, 1, N, c1)
+        keep = (ks > 0).astype(np.float64)
+    hp = st.head_params_np(p, np.float64)
+    out_ref, sv = st.outblock_fwd(cl(x_np), hp, Ko, c_in, channels, act, keep, pdrop, q=Q)
+    dx_ref, g_ref = st.outblock_bwd(dout_np[:, 0].astype(np.float64), sv, hp, Ko, c_in, channels, act, pdrop, True, q=Q)
+    rel = lambda got, ref: float(np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()))
+    stored = {"head.dx": err_stored(cl(bf16_numpy(x.grad)), dx_ref)}
+    f32 = {"head.out": rel(out.detach().cpu().numpy()[:, 0].astype(np.float64), out_ref)}
+    keys = ["tc_w", "tc_b", "tc_aw", "tc_ab", "ln_w", "ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+    for k, prm in zip(keys, params):
+        ref = g_ref[k]
+        if ref is None:
+            f32["grad_none_ok.head." + k] = 0.0 if prm.grad is None else 1.0
+        else:
+            f32["grad.head." + k] = rel(prm.grad.cpu().numpy().astype(np.float64), np.asarray(ref).reshape(prm.shape)) if prm.grad is not None else float("inf")
+    return stored, f32

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import stblock_stages as st
-from tests.bf16_util import Q, assert_bf16_errors, run_block_case_bf16
+from stgcn_amd import ops
+from tests.bf16_util import Q, assert_bf16_errors, run_block_case_bf16, run_head_case_bf16
 from tests.emu_util import bind_emulator
 
 CASES = [
@@ -31,3 +32,76 @@ def test_block_bf16_matches_bf16_oracle(c_in, channels, Kt, Ks, gct, act, N, B, 
     bind_emulator()
     stored, f32 = run_block_case_bf16("cpu", c_in, channels, Kt, Ks, gct, act, N, B, T, training)
     assert_bf16_errors(stored, f32)
+
+
+@pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T,training", [
+    (64, (64, 16, 64), 3, 5, "cheb_graph_conv", "glu", 37, 2, 6, True),       # Ks = 5 like configs[4]
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 150, 1, 7, True),
+    (64, (64, 16, 64), 3, 3, "graph_conv", "glu", 20, 1, 5, False),
+])
+def test_tiled_block_bf16_matches_bf16_oracle(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
+    """The tiled graph conv (BASELINE.json configs[4]: 8192 nodes) with bf16 activations: operand-form GEMMs on the bf16 matrix cores, the
+    recursion / Clenshaw recurrence on STORED bf16 terms (oracle: gc_form "recursion")."""
+    bind_emulator()
+    prev = ops.set_gc_tiled_min_nodes(1)
+    try:
+        stored, f32 = run_block_case_bf16("cpu", c_in, channels, Kt, Ks, gct, act, N, B, T, training)
+    finally:
+        ops.set_gc_tiled_min_nodes(prev)
+    assert_bf16_errors(stored, f32)
+
+
+@pytest.mark.parametrize("N,B,training", [(21, 3, True), (40, 2, False)])
+def test_head_bf16_matches_bf16_oracle(N, B, training):
+    bind_emulator()
+    stored, f32 = run_head_case_bf16("cpu", N, B, training=training)
+    assert_bf16_errors(stored, f32)
+
+
+def test_model_bf16_tracks_the_reference_goldens():
+    """Whole drop-in model with bf16 activations (model.set_compute_dtype) against the fixture the reference itself produced in fp32:
+    bf16 storage and bf16 matrix products are ~2^-9 per element, so the bars are bf16-sized (eval output <= 3e-2 of its range, loss
+    <= 2 %, gradient sums <= 10 %: this fixture has 2 windows x 20 nodes, a 16-element bias gradient averages over few rows); the tight comparison is the stage-level one above, against the bf16 statement of the oracle."""
+    from tests.test_emu_model import _build
+    fx, model, x, y = _build("tiny_cheb_f32")
+    model.set_compute_dtype(torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert out.dtype == torch.float32 and out.shape == fx["eval.out"].shape
+    ref = fx["eval.out"]
+    assert float(np.abs(out.numpy() - ref).max()) <= 3e-2 * float(np.abs(ref).max())
+    model.train()
+    model.zero_grad()
+    loss = torch.nn.MSELoss()(model(x).view(len(x), -1), y)
+    loss.backward()
+    assert abs(loss.item() - float(fx["train.loss"])) <= 2e-2 * abs(float(fx["train.loss"]))
+    nograd = set(str(s) for s in fx["nograd"])
+    for k, prm in model.named_parameters():
+        if k in nograd:
+            assert prm.grad is None, k
+            continue
+        assert prm.grad is not None and prm.grad.dtype == torch.float32, k
+        r = fx["gradsum." + k]
+        assert abs(float(prm.grad.double().abs().sum()) - r[1]) <= 1e-1 * r[1] + 1e-9, k
+
+
+def test_fused_train_step_bf16_runs_and_tracks_fp32():
+    """The fused step tail (GradSink flush + AdamW in one launch) with bf16 activations: parameters, gradients and optimizer state stay fp32."""
+    from stgcn_amd.layers import DropoutStream
+    from stgcn_amd.train import GradArena, fused_train_step, make_optimizer, train_step
+    from tests.test_emu_model import _build
+    losses = {}
+    for dt in (torch.float32, torch.bfloat16):
+        fx, model, x, y = _build("tiny_cheb_f32")
+        model.set_compute_dtype(dt)
+        model.train()
+        DropoutStream.manual_seed(5)
+        opt = make_optimizer(model, lr=1e-3, weight_decay=1e-3)
+        train_step(model, opt, x, y)                                   # plain step: shows which parameters are live
+        arena = GradArena([p for p in model.parameters() if p.grad is not None])
+        ls = [float(fused_train_step(model, opt, x, y, arena)) for _ in range(3)]
+        assert all(np.isfinite(ls)) and all(p.dtype == torch.float32 for p in model.parameters())
+        losses[dt] = ls
+    for a, b in zip(losses[torch.float32], losses[torch.bfloat16]):
+        assert abs(a - b) <= 6e-2 * abs(a), losses      # (3 steps of a 2-window model with dropout: the trajectories drift apart by a few percent)
