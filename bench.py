@@ -6,13 +6,16 @@ A "step" is the reference's loop body (main.py:165-169): zero_grad -> forward ->
 (weak scaling: global batch = 32 * n_gpus, BASELINE.json configs[3] at 8 GPUs).  Inputs are resident in
 HBM before the timed region.  Prints ONE JSON line (rank 0).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--dtype f32|bf16]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 --config (default c2 = the headline; the others are the remaining single-GPU entries of BASELINE.json `configs`):
   c2  METR-LA, 207 nodes, ChebConv Ks=3, bs 32, 12->12, fp32                      (configs[1] / [3])
-  c3  PEMS-BAY, 325 nodes, ChebConv Ks=3, bs 64                                   (configs[2]; quoted in bf16, this library stores fp32)
-  c5  synthetic dense 8192-node graph, ChebConv Ks=5, bs 16, tiled graph conv     (configs[4]; --gc-precision selects the operator products)
+  c3  PEMS-BAY, 325 nodes, ChebConv Ks=3, bs 64                                   (configs[2]; quoted in bf16: default --dtype bf16)
+  c5  synthetic dense 8192-node graph, ChebConv Ks=5, bs 16, tiled graph conv     (configs[4]; quoted in bf16: default --dtype bf16;
+                                                                                    with --dtype f32, --gc-precision selects the operator products)
+--dtype: storage / arithmetic type of the activations (default: what BASELINE.json quotes the config in).  bf16 = bf16 activations and
+saved tensors, bf16 matrix cores with fp32 accumulation; parameters, LayerNorm statistics, gradients, AdamW stay fp32.
 """
 import argparse
 import ctypes as C
@@ -29,17 +32,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 (~2.5 PF)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 N_HIS, KT = 12, 3
 BLOCKS = [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]]
 CONFIGS = {
     "c2": dict(N=207, Ks=3, B=32, n_pred=12, gso="metr_la.cheb_sym_norm_lap", metric="training windows/sec, METR-LA ChebConv K=3 bs=32",
-               workload="C2: METR-LA 207 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=32 per GPU, fp32, dropout 0.5, AdamW lr 1e-3 wd 1e-3; "
+               dtype="f32", compulsory_bytes={"f32": 82_000_000, "bf16": 41_000_000},
+               workload="C2: METR-LA 207 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=32 per GPU, {dtype}, dropout 0.5, AdamW lr 1e-3 wd 1e-3; "
                         "full step zero_grad+fwd+MSE+bwd+opt"),
     "c3": dict(N=325, Ks=3, B=64, n_pred=12, gso="pems_bay.cheb_sym_norm_lap", metric="training windows/sec, PEMS-BAY ChebConv K=3 bs=64",
-               workload="C3: PEMS-BAY 325 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=64, fp32 storage and arithmetic (BASELINE.json quotes "
-                        "this config in bf16: no 16-bit path exists in this library), dropout 0.5, AdamW; full step"),
+               dtype="bf16", compulsory_bytes={"bf16": 129_000_000, "f32": 258_000_000},
+               workload="C3: PEMS-BAY 325 nodes, STGCNChebGraphConv Ks=3 Kt=3, n_his=12, bs=64, {dtype} activations, dropout 0.5, AdamW; full step"),
     "c5": dict(N=8192, Ks=5, B=16, n_pred=12, gso=None, metric="training windows/sec, synthetic 8192-node dense graph ChebConv K=5 bs=16",
-               workload="C5: synthetic dense 8192-node graph, STGCNChebGraphConv Ks=5 Kt=3, n_his=12, bs=16, fp32 storage, tiled graph conv, "
+               dtype="bf16", compulsory_bytes={"bf16": 1_350_000_000, "f32": 2_700_000_000},
+               workload="C5: synthetic dense 8192-node graph, STGCNChebGraphConv Ks=5 Kt=3, n_his=12, bs=16, {dtype} activations, tiled graph conv, "
                         "dropout 0.5, AdamW; full step"),
 }
 PMC_TRAFFIC_FILE = "r2-39_pmc_traffic.json"          # (named explicitly: it has to be re-measured whenever a kernel's traffic changes)
@@ -83,6 +90,36 @@ def block_flops(B, c_in, T, N, Ks, need_dx):
             "tc2_bwd": 2 * F_tc2, "tc1_bwd": (2 * F_tc1 if need_dx else F_tc1) + 2 * F_al,
             "gso_gemm_fwd": F_L / max(Ks - 1, 1), "gso_gemm_bwd": F_L / max(Ks - 1, 1),
             "_total": (F_tc1 + F_al + F_L + F_W + F_tc2) + (F_tc1 if need_dx else 0) + F_tc1 + 2 * (F_al + F_W + F_tc2) + F_L}
+
+
+def block_bytes(B, c_in, T, N, Ks, need_dx, e, part):
+    """Algorithmic HBM bytes of ONE launch by kernel label: every tensor the kernel must read or write once (activation elements x
+    element size e; fp32 LayerNorm parameters / weight-gradient partials `part[label]` in floats), no re-reads -- the figure
+    `roofline.achieved` is priced with when a kernel is HBM-bound (SURVEY.md section 8d convention, per kernel instead of per block)."""
+    c0, c1, c2 = 64, 16, 64
+    T1, T2 = T - KT + 1, T - 2 * (KT - 1)
+    r0, r1, r2 = B * T * N, B * T1 * N, B * T2 * N
+    ln = 2 * N * c2 * 4
+    recompute = KT * c_in <= 16
+    return {"tconv_fwd.tc1": e * (r0 * c_in + (0 if recompute else 2 * r1 * c0) + r1 * c1),
+            "gconv_fwd": e * (r1 * c1 * (Ks + 1)),
+            "tc2_ln_fwd": e * (r1 * c1 + 3 * r2 * c2) + ln,
+            "tc2_bwd": e * (3 * r2 * c2 + 2 * r1 * c1) + ln // 2 + 4 * part.get("tc2_bwd", 0),
+            "gconv_bwd": e * (r1 * c1 * (Ks + 2)) + 4 * part.get("gconv_bwd", 0),
+            "tc1_bwd": e * (r1 * c1 + 2 * r1 * c0 + (2 if need_dx else 1) * r0 * c_in + (2 * r0 * c_in if need_dx else 0)) + 4 * part.get("tc1_bwd", 0),
+            "align_gate_bwd": e * (r1 * c1 + r0 * c_in) + 4 * part.get("align_gate_bwd", 0)}
+
+
+def stblock_bytes_by_label(B, N, Ks, e):
+    tot = {}
+    nt = (N + 15) // 16
+    for blk, (c_in, T, need_dx) in enumerate(((1, N_HIS, False), (64, N_HIS - 2 * (KT - 1), True))):
+        T1 = T - KT + 1
+        part = {"tc2_bwd": B * nt * (KT * 16 * 128 + 128) + 2 * B * N * 64, "gconv_bwd": B * T1 * (Ks + 1) * 256,
+                "tc1_bwd": 256 * (KT * c_in * 128 + 128 + 64 * 16 + 16), "align_gate_bwd": 512 * (64 * 16 + 16 + 16 * 128 + 128)}
+        for k, v in block_bytes(B, c_in, T, N, Ks, need_dx, e, part).items():
+            tot[f"{k}@{blk}"] = v
+    return tot
 
 
 def stblock_flops_by_label(B, N, Ks=3):
@@ -177,6 +214,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="activation storage / arithmetic (default: the config's own: c2 f32, c3 / c5 bf16)")
     ap.add_argument("--gc-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"], help="operator products of the graph conv: tiled path (c5) all modes; slab path (c2, c3) fp32 or bf16x3 (forward only, opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
@@ -187,7 +225,9 @@ def main():
     ap.add_argument("--chains", type=int, default=int(os.environ.get("STGCN_CHAINS", "1")),
                     help="micro-batch chains of the minibatch run concurrently on separate HIP streams (train.chained_fwd_bwd)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    DTYPE = args.dtype or cfg["dtype"]
+    cfg["workload"] = cfg["workload"].format(dtype="fp32" if DTYPE == "f32" else "bf16")
     B_LOCAL = int(B_OVERRIDE) if B_OVERRIDE else cfg["B"]
     N_PRED, KS = cfg["n_pred"], cfg["Ks"]
 
@@ -216,6 +256,8 @@ def main():
     gso_t = torch.from_numpy(gso_np).to(dev)
     torch.manual_seed(42)                       # identical replicas on every rank
     model = models.STGCNChebGraphConv(make_args(gso_t, KS), BLOCKS, N).to(dev)
+    if DTYPE == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
     DropoutStream.manual_seed(1234 + rank)      # independent dropout streams per rank
     use_graph = not args.no_graph
     opt = make_optimizer(model, lr=1e-3, weight_decay=1e-3, capturable=use_graph)
@@ -290,12 +332,12 @@ def main():
     out = {"metric": cfg["metric"], "value": round(B_LOCAL * world * args.steps / el, 2),
            "unit": "windows/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": cfg["workload"], "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
                       "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
                       "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err,
                       "chains": args.chains if use_graph else 1,
-                      "operator_products": args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32",
+                      "operator_products": ("bf16" if DTYPE == "bf16" else args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32"),
                       "input": (f"device-side windows (n_his 12, n_pred {N_PRED}) of a resident (time, N) series, batch position on the device"
                                 if (resident and use_graph) else "(num, 1, n_his, N) window tensors, one batch copied per step")}}
 
@@ -337,15 +379,18 @@ def main():
         dom = max(mfma_kernels, key=mfma_kernels.get)          # the kernel label (@ block) that costs most per step
         calls_per_step = prof[dom]["calls"] / ksteps
         dur_ms = prof[dom]["total_ms"] / prof[dom]["calls"]
-        peak = PEAK_FP32_MFMA_TFLOPS * (16 if (dom.startswith("gso_gemm") and args.gc_precision != "fp32") else 1)
+        bf_mm = DTYPE == "bf16" or (dom.startswith("gso_gemm") and args.gc_precision != "fp32")
+        peak = PEAK_BF16_MFMA_TFLOPS if bf_mm else PEAK_FP32_MFMA_TFLOPS
         ach = flops[dom] / (dur_ms * 1e-3) / 1e12
         tot_ms = sum(v for k, v in per_step.items() if not k.startswith(("head.", "adamw")))
         traffic, traffic_src = pmc_traffic()
-        if args.config != "c2":
+        if args.config != "c2" or DTYPE != "f32":
             traffic, traffic_src = {}, None
         st_labels = [k for k in per_step if not k.startswith(("head.", "adamw", "prepack", "mse", "reduce"))]
         st_traffic = sum(traffic.get(k, 0) * prof[k]["calls"] / ksteps for k in st_labels) if traffic else None
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+        nbytes = stblock_bytes_by_label(B_LOCAL, N, KS, 2 if DTYPE == "bf16" else 4) if N <= 512 else {}
+        out["roofline"] = {"bound": "mfma", "timing_source": "hipEvent pairs around every launch, second (eager) pass over the same steps; the timed "
+                                                             "value above is the hipGraph replay", "kernel": dom, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic.get(dom), "traffic_unit": "bytes/launch",
                            "traffic_source": traffic_src,
                            "avg_launch_us": round(dur_ms * 1e3, 2), "launches_per_step": calls_per_step, "flops_per_launch": int(flops[dom]),
@@ -353,14 +398,29 @@ def main():
                            "stblock_fwd_bwd_frac": round(stblock_total / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                            "stblock_flops_per_step": int(stblock_total),
                            "stblock_traffic_bytes": None if st_traffic is None else int(st_traffic),
-                           "stblock_compulsory_bytes": 82_000_000 if args.config == "c2" else None,
+                           "stblock_compulsory_bytes": cfg["compulsory_bytes"]["f32"],
                            "stblock_launches_per_step": int(round(sum(v["calls"] for k, v in prof.items()
                                                                         if not k.startswith(("head.", "adamw", "prepack", "mse", "reduce"))) / ksteps)),
                            "per_kernel_us_per_step": {k: round(v * 1e3, 2) for k, v in sorted(per_step.items())}}
+        if dom in nbytes:      # the same launch against the HBM roofline; the bound is whichever limit is the slower one for this kernel
+            gbs = nbytes[dom] / (dur_ms * 1e-3) / 1e9
+            rl = out["roofline"]
+            rl["algorithmic_bytes_per_launch"] = int(nbytes[dom])
+            rl["hbm_gbs"], rl["hbm_frac"], rl["mfma_frac"] = round(gbs, 1), round(gbs / PEAK_HBM_GBS, 4), rl["frac"]
+            if nbytes[dom] / (PEAK_HBM_GBS * 1e9) > flops[dom] / (peak * 1e12):
+                rl.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+        if DTYPE == "bf16":
+            rl = out["roofline"]
+            comp = cfg["compulsory_bytes"]["bf16"]
+            rl["stblock_compulsory_bytes"] = comp
+            rl["stblock_fwd_bwd_frac"] = round(stblock_total / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+            rl["stblock_hbm_frac"] = round(comp / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     if rank == 0 and world == 1 and not args.no_gpu_baseline:
         out["gpu_baseline"] = gpu_baseline(model, gso_t, cfg, B_LOCAL, N, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and N <= 1024:
         out["cpu_baseline"] = cpu_baseline(gso_np, cfg, B_LOCAL)
+        out["cpu_baseline"]["reference_published"] = {"value": {"c2": 159.2, "c3": 79.5}.get(args.config), "unit": "windows/s",
+                                                      "source": "BASELINE.md section 2: the unmodified reference loop on 8 vCPU (survey container), fp32"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -117,7 +117,7 @@ typedef struct stgcn_stblock_plan {
     int64_t sv_A;                     /* [rows1][c1] aligned graph-conv input X0                       */
     int64_t sv_Xk;                    /* [Ks-1][rows1][c1] Chebyshev terms X1..                        */
     int64_t sv_G;                     /* [rows1][c1] relu(graph conv + residual)                       */
-    int64_t sv_U2, sv_S2;             /* [rows2][c2]                                                   */
+    int64_t sv_U2, sv_S2;             /* [rows2][c2] gate inputs of tmp_conv2 -- only stored when stored_US2 is set (else empty)        */
     int64_t sv_mean, sv_rstd;         /* [B*T2]                                                        */
     int64_t sv_rowstat;               /* [rows2][2] per-row LayerNorm partials (mean, M2) of tmp_conv2 output */
     /* ws: packed weights */
@@ -145,6 +145,8 @@ typedef struct stgcn_stblock_plan {
     int64_t ws_W2dense;               /* [KP2][2*c2] W_eff of tmp_conv2, row major (stationary A operand of that kernel)             */
     int64_t fused_tc1_bwd;            /* 1: Align + gate backward + tmp_conv1 weight gradient + transposed conv run as ONE launch (needs
                                          need_dx); dZ1 stays on chip (ws_dZ1 is only written under stgcn_set_debug_stages)           */
+    int64_t stored_US2;               /* 1: the forward writes U2 / S2 into `saved` (LayerNorm as a separate pass, the stage-per-launch
+                                         backward, or stgcn_set_debug_stages); 0: tc2_bwd_kernel recomputes them from G               */
 } stgcn_stblock_plan;
 
 int stgcn_version(void);
@@ -211,34 +213,37 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* desc, const stgcn_stblock_pa
                           const float* gso_pad, float* y, float* saved, float* ws, uint64_t seed, uint64_t offset,
                           const uint64_t* offset_dev, void* stream);
 
-/* dy: (B, T2, N, c2); dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the matching
+/* dy: (B, T2, N, c2); y: the output the matching forward wrote (read only when desc.dy_rowstats_ready == 0: the LayerNorm-backward row
+ * partials are then formed from dy and y); dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the matching
  * forward call filled; seed/offset must be the forward's.                                            */
 int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
-                           const float* gso_t_pad, const float* dy, const float* saved, float* ws,
+                           const float* gso_t_pad, const float* dy, const float* y, const float* saved, float* ws,
                            const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
                            const uint64_t* offset_dev, void* stream);
 
 /* ---- LayerNorm-backward row partials in the PRODUCER of dy.  The backward of `Dropout(LayerNorm(h))` (layers.py:255-256) needs the
  *      per-slab means of g = mask * dy * gamma and g * xhat before it can touch a single element; the per-row sums they are built
  *      from can be formed by whichever kernel produces dy (the next module's input gradient) while the row is still on chip.
- *      stgcn_stblock_ln_hook describes the LayerNorm of a block's forward call (same desc / params / saved / ws / seed / offset as that
- *      call); hand it to the backward call of the module that consumed the block's output (..._backward_hook below) and set
- *      desc.dy_rowstats_ready = 1 in the block's own backward call.  A NULL hook reproduces stgcn_*_backward.                     */
+ *      With g = mask * dy * gamma and y = mask * (xhat * gamma + beta) (the block's output) the sums need nothing of the forward but y:
+ *          sum g = sum mask dy gamma ,   sum g xhat = sum_kept dy (y - beta / (1 - p))
+ *      and y is the consumer's own input.  stgcn_stblock_ln_hook describes the LayerNorm of a block's forward call (same desc / params /
+ *      y / ws / seed / offset as that call); hand it to the backward call of the module that consumed the block's output
+ *      (..._backward_hook below) and set desc.dy_rowstats_ready = 1 in the block's own backward call.  A NULL hook reproduces
+ *      stgcn_*_backward.                                                                                                        */
 typedef struct stgcn_ln_hook {
     float* rowstat;            /* [B*T2*N][2] destination (inside the block's ws)                                     */
-    const float *U, *S;        /* [B*T2*N][c2] saved gate inputs of tmp_conv2                                         */
-    const float *gamma;        /* tc2_ln.weight (N, c2)                                                               */
-    const float *mean, *rstd;  /* [B*T2]                                                                              */
-    int32_t N, C, act, training;
+    const float* y;            /* [B*T2*N][c2] the block's output (dtype below)                                       */
+    const float *gamma, *beta; /* tc2_ln.weight / .bias (N, c2)                                                       */
+    int32_t N, C, reserved, training;
     float droprate;
     int32_t dtype;             /* STGCN_DTYPE_* of U / S: must equal the dtype of the call the hook is handed to      */
     uint64_t seed, offset;
     const uint64_t* offset_dev;
 } stgcn_ln_hook;
-int stgcn_stblock_ln_hook(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* saved, float* ws, uint64_t seed,
+int stgcn_stblock_ln_hook(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* y, float* ws, uint64_t seed,
                           uint64_t offset, const uint64_t* offset_dev, stgcn_ln_hook* hook);
 int stgcn_stblock_backward_hook(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
-                                const float* gso_t_pad, const float* dy, const float* saved, float* ws,
+                                const float* gso_t_pad, const float* dy, const float* y, const float* saved, float* ws,
                                 const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
                                 const uint64_t* offset_dev, const stgcn_ln_hook* dx_hook, void* stream);
 

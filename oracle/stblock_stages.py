@@ -277,14 +277,22 @@ def ln_dropout_fwd(H, gamma, beta, keep, p, eps=1e-12, H_norm=None):
     return y, mean[..., 0, 0], rstd[..., 0, 0]
 
 
-def ln_dropout_bwd(dy, H, gamma, mean, rstd, keep, p):
+def ln_dropout_bwd(dy, H, gamma, mean, rstd, keep, p, y_stored=None, beta=None):
     """dH = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy_m * gamma;
-    dgamma = sum_{b,t} dy_m * xhat; dbeta = sum_{b,t} dy_m."""
+    dgamma = sum_{b,t} dy_m * xhat; dbeta = sum_{b,t} dy_m.
+    y_stored / beta (bf16 statement): the slab constant mean(g * xhat) is formed the way the HIP path forms it, from the block's STORED
+    output y = mask * (xhat * gamma + beta) instead of from xhat:  sum g xhat = sum_kept dy (y - beta / (1 - p))  (stgcn_ln_hook);
+    exact for the unrounded y, and the one place where the rounding of y enters the backward."""
     dym = dy if keep is None else dy * keep * (1.0 / (1.0 - p))
     xhat = (H - mean[..., None, None]) * rstd[..., None, None]
     g = dym * gamma
     c1 = g.mean(axis=(2, 3), keepdims=True)
-    c2 = (g * xhat).mean(axis=(2, 3), keepdims=True)
+    if y_stored is None:
+        c2 = (g * xhat).mean(axis=(2, 3), keepdims=True)
+    else:
+        ks = 1.0 if keep is None else 1.0 / (1.0 - p)
+        kept = 1.0 if keep is None else keep
+        c2 = (dy * kept * (y_stored - ks * beta)).mean(axis=(2, 3), keepdims=True)
     dH = rstd[..., None, None] * (g - c1 - xhat * c2)
     return dH, (dym * xhat).sum(axis=(0, 1)), dym.sum(axis=(0, 1))
 
@@ -310,7 +318,8 @@ def stblock_fwd(x, gso, bp, Kt, c_in, channels, graph_conv_type="cheb_graph_conv
                 keep=None, p_drop=0.0, q=None, gc_form="poly", ln_from_stored=False):
     """x channels-last (B,T,N,c_in).  Returns (y (B,T2,N,c2), saved dict).
     ``q``: rounding rule of the bf16 configurations (QuantBf16; x must then hold bf16 values): `saved` carries what the HIP path
-    stores (q(U1), q(S1), q(A), q(X_k), q(G), q(U2), q(S2)) plus the unrounded H1 / H2 of the forward; y is q(dropout(LN(H2))).
+    stores (q(U1), q(S1), q(A), q(X_k), q(G)) plus the unrounded H1 / U2 / S2 / H2 of the forward (the backward recomputes the gate inputs
+    of tmp_conv2 from G); y is q(dropout(LN(H2))).
     ln_from_stored: the block's LayerNorm runs as a separate pass over the stored gate inputs (more than 448 nodes: ln_norm_kernel)
     instead of inside tc2_ln_fwd_kernel, which normalises the values it still holds in registers."""
     c0, c1, c2 = channels
@@ -332,9 +341,9 @@ def stblock_fwd(x, gso, bp, Kt, c_in, channels, graph_conv_type="cheb_graph_conv
         if Kt * c_in > 16:
             U1, S1 = q(U1), q(S1)
             H1 = _gate(U1, S1, act)
-        U2, S2 = q(U2), q(S2)
+        # (U2 / S2 are not stored: tc2_bwd_kernel recomputes them from the stored G with the same rounded operands -> unrounded values)
     saved = dict(x=x, W1=W1, U1=U1, S1=S1, H1=H1, Wa=Wa, Xs=Xs, G=G, Wk=Wk, W2=W2, U2=U2, S2=S2, H2=H2,
-                 mean=mean, rstd=rstd, keep=keep, A=A)
+                 mean=mean, rstd=rstd, keep=keep, A=A, y=y)
     return y, saved
 
 
@@ -345,7 +354,8 @@ def stblock_bwd(dy, sv, gso, bp, Kt, c_in, channels, graph_conv_type="cheb_graph
     receives the stored intermediate gradients (dYg, dA) for stage-level comparisons."""
     c0, c1, c2 = channels
     H2 = sv["H2"] if q is None else _gate(sv["U2"], sv["S2"], act)      # bf16: xhat is rebuilt from the stored gate inputs
-    dH2, dgamma, dbeta = ln_dropout_bwd(dy, H2, bp["ln_w"], sv["mean"], sv["rstd"], sv["keep"], p_drop)
+    dH2, dgamma, dbeta = ln_dropout_bwd(dy, H2, bp["ln_w"], sv["mean"], sv["rstd"], sv["keep"], p_drop,
+                                        y_stored=None if q is None else sv["y"], beta=bp["ln_b"])
     dZ2 = gate_bwd(dH2, sv["U2"], sv["S2"], act)
     dW2, db2 = tconv_bwd_weight(sv["G"], dZ2, Kt, q)
     dG = tconv_bwd_data(dZ2, sv["W2"], Kt, c1, q)

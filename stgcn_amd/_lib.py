@@ -33,8 +33,8 @@ class StblockDesc(C.Structure):
 
 
 class LnHook(C.Structure):            # stgcn_ln_hook
-    _fields_ = [("rowstat", C.c_void_p), ("U", C.c_void_p), ("S", C.c_void_p), ("gamma", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
-                ("N", C.c_int32), ("C", C.c_int32), ("act", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float), ("dtype", C.c_int32),
+    _fields_ = [("rowstat", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("N", C.c_int32), ("C", C.c_int32), ("reserved", C.c_int32), ("training", C.c_int32), ("droprate", C.c_float), ("dtype", C.c_int32),
                 ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p)]
 
 
@@ -54,7 +54,7 @@ PLAN_FIELDS = ["T1", "T2", "rows1", "rows2", "NP", "y_floats", "saved_floats", "
                "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd", "sv_rowstat",
                "ws_W1p", "ws_W1d", "ws_b1", "ws_Wap", "ws_WaT", "ws_ba", "ws_W2p", "ws_W2d", "ws_b2", "ws_W1dense", "recompute_tc1", "ws_WaDense", "thin_tc1",
                "ws_rowstat_b", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats",
-               "tiled_gc", "ws_Gk", "ws_XT", "fused_tc2_bwd", "ws_W2dense", "fused_tc1_bwd"]
+               "tiled_gc", "ws_Gk", "ws_XT", "fused_tc2_bwd", "ws_W2dense", "fused_tc1_bwd", "stored_US2"]
 
 
 class StblockPlan(C.Structure):
@@ -153,10 +153,10 @@ class _Lib:
         d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
                                              C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward_hook.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
-                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(StblockGrads), C.c_void_p,
                                                   C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(LnHook), C.c_void_p]
         d.stgcn_stblock_ln_hook.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                             C.c_void_p, C.POINTER(LnHook)]

@@ -746,8 +746,8 @@ LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
     LnRowstatOut o;
     memset(&o, 0, sizeof(o));
     if (!h || !h->rowstat) return o;
-    o.rowstat = reinterpret_cast<float2*>(h->rowstat); o.U = h->U; o.S = h->S; o.gamma = h->gamma; o.mean = h->mean; o.rstd = h->rstd;
-    o.N = h->N; o.C = h->C; o.act = h->act; o.training = h->training && h->droprate > 0.f;
+    o.rowstat = reinterpret_cast<float2*>(h->rowstat); o.y = h->y; o.gamma = h->gamma; o.beta = h->beta;
+    o.N = h->N; o.C = h->C; o.training = h->training && h->droprate > 0.f;
     o.keep_scale = 1.0f / (1.0f - h->droprate); o.thresh = drop_thresh(h->droprate); o.seed = h->seed; o.offset = h->offset;
     o.offset_dev = h->offset_dev;
     return o;
@@ -813,8 +813,10 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->sv_A = take(act(v.rows1 * d->c1));
     p->sv_Xk = take((int64_t)(v.terms - 1) * act(v.rows1 * d->c1));
     p->sv_G = take(act(v.rows1 * d->c1));
-    p->sv_U2 = take(act(v.rows2 * d->c2));
-    p->sv_S2 = take(act(v.rows2 * d->c2));
+    const BwdGeom bgs = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
+    p->stored_US2 = (!tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N) || !bgs.k1 || g_debug_stages) ? 1 : 0;
+    p->sv_U2 = take(act(p->stored_US2 ? v.rows2 * d->c2 : 0));
+    p->sv_S2 = take(act(p->stored_US2 ? v.rows2 * d->c2 : 0));
     p->sv_mean = take(v.slabs2);
     p->sv_rstd = take(v.slabs2);
     p->sv_rowstat = take(2 * v.rows2);
@@ -948,16 +950,15 @@ int stgcn_dropout_mask(float* out, int64_t n, float droprate, uint64_t seed, uin
     return STGCN_OK;
 }
 
-int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* saved, float* ws, uint64_t seed, uint64_t offset,
+int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* y, float* ws, uint64_t seed, uint64_t offset,
                           const uint64_t* offset_dev, stgcn_ln_hook* h) {
     stgcn_stblock_plan pl;
     int rc = stgcn_stblock_plan_query(d, &pl);
     if (rc) return rc;
-    if (!P || !P->ln_w || !saved || !ws || !h) return fail(STGCN_ERR_INVALID, "stgcn_stblock_ln_hook: NULL argument");
+    if (!P || !P->ln_w || !P->ln_b || !y || !ws || !h) return fail(STGCN_ERR_INVALID, "stgcn_stblock_ln_hook: NULL argument");
     memset(h, 0, sizeof(*h));
-    h->rowstat = ws + pl.ws_rowstat_b; h->U = saved + pl.sv_U2; h->S = saved + pl.sv_S2; h->gamma = P->ln_w;
-    h->mean = saved + pl.sv_mean; h->rstd = saved + pl.sv_rstd;
-    h->N = d->N; h->C = d->c2; h->act = d->act; h->training = d->training; h->droprate = d->droprate; h->dtype = d->dtype;
+    h->rowstat = ws + pl.ws_rowstat_b; h->y = y; h->gamma = P->ln_w; h->beta = P->ln_b;
+    h->N = d->N; h->C = d->c2; h->training = d->training; h->droprate = d->droprate; h->dtype = d->dtype;
     h->seed = seed; h->offset = offset; h->offset_dev = offset_dev;
     return STGCN_OK;
 }
@@ -1029,7 +1030,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         Tc2LnFwdArgs f;
         memset(&f, 0, sizeof(f));
         f.G = saved + pl.sv_G; f.Wp = ws + pl.ws_W2p; f.bias = ws + pl.ws_b2; f.gamma = P->ln_w; f.beta = P->ln_b;
-        f.U = saved + pl.sv_U2; f.S = saved + pl.sv_S2; f.y = y; f.mean = saved + pl.sv_mean; f.rstd = saved + pl.sv_rstd;
+        f.U = pl.stored_US2 ? saved + pl.sv_U2 : nullptr; f.S = pl.stored_US2 ? saved + pl.sv_S2 : nullptr;
+        f.y = y; f.mean = saved + pl.sv_mean; f.rstd = saved + pl.sv_rstd;
         f.T1 = v.T1; f.T2 = v.T2; f.N = d->N; f.NPR = (int)rup(d->N, 16); f.act = d->act; f.training = d->training && d->droprate > 0.f;
         f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
         f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;

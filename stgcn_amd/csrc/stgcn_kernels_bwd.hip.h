@@ -53,7 +53,7 @@ inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
 inline bool tc1_fwd_shape_ok(int c_in, int c0, int c1, int Kt) { return (fuse_mask() & FUSE_TC1_FWD) && tc1_ts_shape(c_in, c0, c1, Kt); }
 inline bool tc2_bwd_fused_ok(int c1, int c2, int Kt, int T1, int T2) {
     return (fuse_mask() & FUSE_TC2_BWD) && c1 == 16 && ((c2 == 64 && Kt >= 2 && Kt <= 4) || (c2 == 128 && Kt == 3)) && T1 <= kTsMaxT &&
-           tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 64 * 1024;
+           tc2_bwd_lds_bytes(c2, Kt, T1, T2) <= 80 * 1024;
 }
 
 // ---- which graph-conv implementation a block uses (host side; plan, launchers and stgcn_gso_prepare must agree) -------
@@ -203,6 +203,8 @@ inline int64_t bwd_partial_floats(int B, int T, int N, int c_in, int c0, int c1,
 // ================================================================================================
 struct LnBwdArgs {
     const float* dy;     // [slabs][n]
+    const float* y;      // ln_bwd_rowstats_kernel only: [slabs][n] the LayerNorm's OUTPUT (after dropout), or null: form xhat from U, S below
+    const float* beta;   // [n] (with y)
     const float* U;
     const float* S;
     const float* gamma;
@@ -233,20 +235,30 @@ __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
     if (valid) {
         const size_t base = (size_t)slab * a.n + 4 * (size_t)q;
         f32x4 dy = ldx4(et_ptr<ET>(a.dy) + base);
-        const f32x4 u = ldx4(et_ptr<ET>(a.U) + base), s = ldx4(et_ptr<ET>(a.S) + base), ga = ld4(a.gamma + 4 * q);
-        const float mean = a.mean[slab], rstd = a.rstd[slab];
+        const f32x4 ga = ld4(a.gamma + 4 * q);
+        f32x4 k = {1.f, 1.f, 1.f, 1.f};
         if (a.training) {
             const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+            k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
         }
+        if (a.y) {   // (uniform) from the LayerNorm output: sum g = sum mask dy gamma ; sum g xhat = sum_kept dy (y - keep_scale * beta)
+            const f32x4 y = ldx4(et_ptr<ET>(a.y) + base), be = ld4(a.beta + 4 * q);
+            const float ks = a.training ? a.keep_scale : 1.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xh = (gate_fwd(u[i], s[i], a.act) - mean) * rstd;
-            const float gg = dy[i] * ga[i];
-            s1 += gg;
-            s2 += gg * xh;
+            for (int i = 0; i < 4; ++i) {
+                s1 += dy[i] * k[i] * ga[i];
+                if (k[i] > 0.f) s2 += dy[i] * (y[i] - ks * be[i]);
+            }
+        } else {
+            const f32x4 u = ldx4(et_ptr<ET>(a.U) + base), s = ldx4(et_ptr<ET>(a.S) + base);
+            const float mean = a.mean[slab], rstd = a.rstd[slab];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (gate_fwd(u[i], s[i], a.act) - mean) * rstd;
+                const float gg = dy[i] * k[i] * ga[i];
+                s1 += gg;
+                s2 += gg * xh;
+            }
         }
     }
     for (int m = c4n >> 1; m >= 1; m >>= 1) {   // the c4n lanes of one row are contiguous and aligned

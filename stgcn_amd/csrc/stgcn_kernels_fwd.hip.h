@@ -823,7 +823,11 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd3_kernel(TconvFwdArgs a, 
 // ================================================================================================
 struct LnRowstatOut {
     float2* rowstat;      // [slabs*N] (sum g, sum g*xhat) per row; null = epilogue disabled
-    const float* U;       // [slabs*N][C] saved gate inputs of the layer in front of the LayerNorm
+    // two ways to form g * xhat: from the LayerNorm's OUTPUT y = mask * (xhat * gamma + beta) (ST blocks: nothing of the forward has to be
+    // kept for it, y is the consumer's own input) -- or from the saved gate inputs U, S with the slab statistics (the head's LayerNorm)
+    const float* y;       // [slabs*N][C] or null
+    const float* beta;    // [N][C] (with y)
+    const float* U;       // [slabs*N][C] saved gate inputs of the layer in front of the LayerNorm (y == null)
     const float* S;
     const float* gamma;   // [N][C]
     const float* mean;    // [slabs]
@@ -838,16 +842,27 @@ struct LnRowstatOut {
 template <typename ET = float>
 __device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, f32x4 dy, long slab, int node, int c) {
     const size_t e = ((size_t)slab * o.N + node) * o.C + c;
-    const f32x4 u = ldx4(et_ptr<ET>(o.U) + e), s = ldx4(et_ptr<ET>(o.S) + e), ga = ld4(o.gamma + (size_t)node * o.C + c);
-    const float mean = o.mean[slab], rstd = o.rstd[slab];
+    const f32x4 ga = ld4(o.gamma + (size_t)node * o.C + c);
+    f32x4 k = {1.f, 1.f, 1.f, 1.f};
     if (o.training) {
         const uint64_t off = o.offset + (o.offset_dev ? *o.offset_dev : 0);
-        const f32x4 k = dropout_scale4((uint64_t)slab * (((uint64_t)o.N * o.C) >> 2) + (((uint64_t)node * o.C + c) >> 2), o.seed, off, o.thresh,
-                                       o.keep_scale);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+        k = dropout_scale4((uint64_t)slab * (((uint64_t)o.N * o.C) >> 2) + (((uint64_t)node * o.C + c) >> 2), o.seed, off, o.thresh, o.keep_scale);
     }
     float s1 = 0.f, s2 = 0.f;
+    if (o.y) {   // (uniform) sum g = sum mask dy gamma ; sum g xhat = sum_kept dy (y - keep_scale * beta)
+        const f32x4 y = ldx4(et_ptr<ET>(o.y) + e), be = ld4(o.beta + (size_t)node * o.C + c);
+        const float ks = o.training ? o.keep_scale : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s1 += dy[i] * k[i] * ga[i];
+            if (k[i] > 0.f) s2 += dy[i] * (y[i] - ks * be[i]);
+        }
+        return make_float2(s1, s2);
+    }
+    const f32x4 u = ldx4(et_ptr<ET>(o.U) + e), s = ldx4(et_ptr<ET>(o.S) + e);
+    const float mean = o.mean[slab], rstd = o.rstd[slab];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dy[i] *= k[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float xh = (gate_fwd(u[i], s[i], o.act) - mean) * rstd;

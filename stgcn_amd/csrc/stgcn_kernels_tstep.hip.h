@@ -29,8 +29,8 @@ namespace stgcn {
 // ================================================================================================
 struct Tc2BwdArgs {
     const float* dy;          // [B][T2][N][C2]
-    const float* U;           // [B][T2][N][C2]  saved gate inputs of tmp_conv2
-    const float* S;
+    const float* Wp;          // packed W_eff2 (PK_TCONV_FWD fragments): the gate inputs U2 / S2 are RECOMPUTED from the G tiles, not read
+    const float* bias;        // b_eff2 [2*C2]
     const float* gamma;       // [N][C2]
     const float* mean;        // [B*T2]
     const float* rstd;
@@ -51,15 +51,19 @@ struct Tc2BwdArgs {
 
 constexpr int kTsMaxT = 32;   // time steps of G kept in LDS (host falls back to the unfused kernels beyond)
 inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
-    return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2) * sizeof(float);
+    return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2 + 2 * 16 * (2 * C2 + 4)) * sizeof(float);
 }
 
 // Wave specialisation: a workgroup is 8 waves = 4 "E" waves + 4 "M" waves, one of each per SIMD.
-//     E waves (VALU / memory): E(t) = dy, U, S tiles (prefetched two steps ahead) -> dZ2 tile t into ring slot t % (KT + 1), plus the
-//                              LayerNorm-parameter and bias partials;
+//     E waves (VALU / memory): E(t) = dy tile (prefetched two steps ahead) + the gate inputs of tile t from LDS -> dZ2 tile t into ring
+//                              slot t % (KT + 1), plus the LayerNorm-parameter and bias partials;
 //     M waves (matrix cores) : F(t - 1) = dYg[t - 1] from the 4 partial tiles of the previous step;
-//                              M(t) = weight-gradient MFMAs of tile t + transposed-conv MFMAs for output step t -> `red[t & 1]`.
-//   iteration t:  barrier | E waves: E(t + 1)  ||  M waves: F(t - 1), M(t)
+//                              M(t) = weight-gradient MFMAs of tile t + transposed-conv MFMAs for output step t -> `red[t & 1]`;
+//                              R(t + 2) = the gate inputs U2 = P + b, S2 = sigmoid(Q + b) of tile t + 2, RECOMPUTED from the G tiles the
+//                              workgroup holds anyway (K = KT * 16: KT product steps per 16 output channels) -> `USt[t & 1]`.  The
+//                              forward therefore stores neither U2 nor S2 (round 2 wrote them in tc2_ln_fwd and read them back here and
+//                              in the consumer's LayerNorm hook: 2 x rows2 x c2 elements written once and read twice per block).
+//   iteration t:  barrier | E waves: E(t + 1)  ||  M waves: F(t - 1), M(t), R(t + 2)
 // The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
 // walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
 // spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
@@ -67,8 +71,6 @@ template <int C2, int KT, bool TRAINING, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     typedef Mma<ET> MM;
     const ET* const dy_ = et_ptr<ET>(a.dy);
-    const ET* const U_ = et_ptr<ET>(a.U);
-    const ET* const S_ = et_ptr<ET>(a.S);
     const ET* const G_ = et_ptr<ET>(a.G);
     ET* const dYg_ = et_ptr<ET>(a.dYg);
     constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20, RING = KT + 1, RED = 4 * 16 * LDG;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     float* const GT = Zt + RING * 16 * LDZ;            // [T1][16 ch][LDG]  G tiles, transposed (GT[t][i][row])
     float* const red = GT + a.T1 * 16 * LDG;           // [2][4 waves][16 rows][LDG]  transposed-conv partials of the 4 M waves, double buffered
     float* const cs = red + 2 * RED;                   // [T2][4]: c1, c2, mean, rstd
+    float* const USt = cs + 4 * a.T2;                  // [2][16][LDZ]  recomputed gate inputs [U | S] of tiles t, t + 1 (written by the M waves)
     const bool roleE = threadIdx.x < 256;              // wave-uniform
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int b = (int)blockIdx.x / a.node_tiles, nt = (int)blockIdx.x - b * a.node_tiles, n0 = nt * 16;
@@ -89,15 +92,13 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 
     if (roleE) {
         // =========================================== E waves ===========================================================
-        struct Tile { f32x4 dy[IT], u[IT], s[IT]; };
+        struct Tile { f32x4 dy[IT]; };
         auto fetch = [&](int t2, Tile& t) {
             const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 t.dy[it] = ldx4(dy_ + e0 + 64 * it);
-                t.u[it] = ldx4(U_ + e0 + 64 * it);
-                t.s[it] = ldx4(S_ + e0 + 64 * it);
-                if (!rv) { t.dy[it] = zero4(); t.s[it] = zero4(); }   // s = 0 makes every product of the gate backward vanish
+                if (!rv) t.dy[it] = zero4();
             }
         };
         Tile p0, p1;
@@ -156,12 +157,14 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         // E(t): branch free (rows beyond N carry s = 0, dy = 0: every product vanishes)
         auto E = [&](int t, const Tile& tl) {
             float* const Zs = Zt + (t % RING) * 16 * LDZ;
+            const float* const Us = USt + (t & 1) * 16 * LDZ + r * LDZ;
             const float c1 = cs[4 * t], c2 = cs[4 * t + 1], mean = cs[4 * t + 2], rstd = cs[4 * t + 3];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 f32x4 dy = tl.dy[it];
-                const f32x4 u = tl.u[it], s = tl.s[it];
                 const int c4 = cq + 16 * it;
+                const f32x4 u = ld4(Us + 4 * c4);
+                const f32x4 s = rv ? ld4(Us + C2 + 4 * c4) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 if constexpr (TRAINING) {
                     const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             }
         };
         __syncthreads();   // (A) cs complete (written by E waves), GT complete (written by M waves)
+        __syncthreads();   // (A2) gate inputs of tile 0 recomputed
         STGCN_PHASE(8, 1);
         E(0, p0);
         p0 = p1;
@@ -236,6 +240,42 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         for (int k = 0; k < KT; ++k)
 #pragma unroll
             for (int q = 0; q < QW; ++q) Wr[k][q] = MM::cvt(ld4(a.Wd + (size_t)(k * 16 + l15) * NC + w * (NC / 4) + q * 16 + 4 * g));
+        // forward weights of this wave's output channels (P tiles w + 4j, Q tiles C2/16 further) for the recomputation of the gate inputs
+        constexpr int NTP = C2 / 64, MT = C2 / 16;
+        typename MM::frag wP[NTP][KT], wQ[NTP][KT];
+        f32x4 bp[NTP], bq[NTP];
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) {
+#pragma unroll
+            for (int kc = 0; kc < KT; ++kc) {
+                wP[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j) * KT + kc) * 64 + lane) * 4));
+                wQ[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j + MT) * KT + kc) * 64 + lane) * 4));
+            }
+            bp[j] = ld4(a.bias + 16 * (w + 4 * j) + 4 * g);
+            bq[j] = ld4(a.bias + C2 + 16 * (w + 4 * j) + 4 * g);
+        }
+        // R(t): Z^T[o][row] = W_eff2^T im2col(G)^T for tile t: A = the weights, B[k = ch 4g + s][n = row l15] from the transposed G tiles;
+        // D leaves a lane with 4 consecutive channels of row l15, P and Q of one channel in the same lane
+        auto R = [&](int t) __attribute__((always_inline)) {
+            float* const Us = USt + (t & 1) * 16 * LDZ + l15 * LDZ;
+            typename MM::frag fb[KT];
+#pragma unroll
+            for (int kc = 0; kc < KT; ++kc) fb[kc] = MM::cvt(gather4(GT + ((t + kc) * 16 + 4 * g) * LDG + l15, LDG));
+#pragma unroll
+            for (int j = 0; j < NTP; ++j) {
+                f32x4 accP = zero4(), accQ = zero4();
+#pragma unroll
+                for (int kc = 0; kc < KT; ++kc) MM::mma_a2(wP[j][kc], wQ[j][kc], fb[kc], accP, accQ);
+                f32x4 u, sg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u[e] = accP[e] + bp[j][e];
+                    sg[e] = sigmoid_f(accQ[e] + bq[j][e]);
+                }
+                st4(Us + 16 * (w + 4 * j) + 4 * g, u);
+                st4(Us + C2 + 16 * (w + 4 * j) + 4 * g, sg);
+            }
+        };
         // all G tiles of this (window, node tile), transposed
         for (int idx = tid; idx < T1 * 64; idx += 256) {
             const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
@@ -249,6 +289,9 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
         __syncthreads();   // (A)
+        R(0);
+        __syncthreads();   // (A2)
+        if (T2 > 1) R(1);
         for (int t1 = 0; t1 < T1; ++t1) {
             __syncthreads();   // (B) dZ2 tile t1 and the partial tiles of step t1 - 1 are visible
             if (t1 > 0) {      // F(t1 - 1): dYg = relu'(G) * (sum of the 4 waves' partial tiles), thread (row r, channel cq)
@@ -290,6 +333,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 }
             }
             st4(red + (t1 & 1) * RED + (w * 16 + l15) * LDG + 4 * g, accd[0] + accd[1]);   // D[m = i = 4g + r][n = row = l15]
+            if (t1 + 2 < T2) R(t1 + 2);   // slot (t1 & 1): tile t1's gate inputs were last read by E(t1), before barrier (B) of this step
         }
         __syncthreads();       // (C)
         {
@@ -365,8 +409,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     const ET* const S_ = et_ptr<ET>(a.S);
     const ET* const x_ = et_ptr<ET>(a.x);
     ET* const dx_ = et_ptr<ET>(a.dx);
-    const ET* const hU_ = et_ptr<ET>(a.rs.U);
-    const ET* const hS_ = et_ptr<ET>(a.rs.S);
+    const ET* const hy_ = et_ptr<ET>(a.rs.y);
     constexpr int NC = 2 * C0, LDZ = NC + 4, RING = KT + 1, LDX = 20, LDH = C0 + 4, LDO = CIN + 4, MI = CIN / 16, QD = NC / 16;
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
@@ -474,20 +517,23 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     st4(Ht + (t & 1) * 16 * LDH + er * LDH + 4 * ecq, h);
                 }
             };
-            // hook operands of output step t (saved U2 / S2 of the previous block's LayerNorm input, its dropout mask, the slab's mean and
-            // rstd): requested ONE STEP AHEAD of the dx tile they meet -- forming them inside F put two dependent memory round trips on
-            // the E waves' critical path of every step (phase stamps: 7-9 k cycles per step for 6.3 k cycles of MFMAs)
-            struct Hook { f32x4 u, s, k; float mean, rstd; };
+            // hook operands of output step t (the previous block's OUTPUT y = this block's x, and its dropout mask): requested ONE STEP
+            // AHEAD of the dx tile they meet -- forming them inside F put dependent memory round trips on the E waves' critical path of
+            // every step.  With g = mask * dx * gamma and y = mask * (xhat * gamma + beta) the two row sums need no xhat:
+            //     sum g = sum mask dx gamma ,   sum g xhat = sum_kept dx (y - keep_scale * beta)
+            struct Hook { f32x4 y, k; };
             const bool hk = a.rs.rowstat != nullptr;           // uniform
             const f32x4 hgam = (hk && cq < CIN / 4) ? ld4(a.rs.gamma + (size_t)rc * CIN + 4 * cq) : zero4();
+            f32x4 hbks = (hk && cq < CIN / 4) ? ld4(a.rs.beta + (size_t)rc * CIN + 4 * cq) : zero4();   // keep_scale * beta
+            if (hk && a.rs.training) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hbks[i] *= a.rs.keep_scale;
+            }
             auto hook_fetch = [&](int t, Hook& h) __attribute__((always_inline)) {
                 if (hk && cq < CIN / 4) {
                     const long slab = (long)b * T + (t < T ? t : T - 1);
                     const size_t e = ((size_t)slab * N + rc) * CIN + 4 * cq;
-                    h.u = ldx4(hU_ + e);
-                    h.s = ldx4(hS_ + e);
-                    h.mean = a.rs.mean[slab];
-                    h.rstd = a.rs.rstd[slab];
+                    h.y = ldx4(hy_ + e);
                     h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
                     if (a.rs.training) {
                         const uint64_t off = a.rs.offset + (a.rs.offset_dev ? *a.rs.offset_dev : 0);
@@ -506,10 +552,8 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                         if (rv) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const float xh = (gate_fwd(h.u[i], h.s[i], a.rs.act) - h.mean) * h.rstd;
-                                const float gg = v[i] * h.k[i] * hgam[i];
-                                p.x += gg;
-                                p.y += gg * xh;
+                                p.x += v[i] * h.k[i] * hgam[i];
+                                if (h.k[i] > 0.f) p.y += v[i] * (h.y[i] - hbks[i]);
                             }
                         }
 #pragma unroll
@@ -861,7 +905,7 @@ struct Tc2LnFwdArgs {
     const float* bias;     // b_eff2 [2*C2]
     const float* gamma;    // [N][C2]
     const float* beta;
-    float* U;              // [B*T2*N][C2]
+    float* U;              // [B*T2*N][C2]  gate inputs, or null: not stored (tc2_bwd_kernel recomputes them)
     float* S;
     float* y;              // [B*T2*N][C2]
     float* mean;           // [B*T2]
@@ -954,8 +998,10 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
                     h[i] = gate_fwd(u[i], sg[i], a.act);
                 }
                 const size_t o = ((size_t)slab * N + row) * C2 + c;
-                stx4_wt(U_ + o, u);
-                stx4_wt(S_ + o, sg);
+                if (a.U) {   // (uniform) only when a consumer of the stored gate inputs exists: the stage tests, the unfused backward
+                    stx4_wt(U_ + o, u);
+                    stx4_wt(S_ + o, sg);
+                }
                 hh[j] = h;
                 sum += (h[0] + h[1]) + (h[2] + h[3]);
                 cnt_l += 4.f;

@@ -199,6 +199,7 @@ def set_gc_ld_pad(pad: int) -> int:
 def set_debug_stages(on: bool) -> bool:
     """Stage tests only: make the fused kernels also write the intermediates they keep on chip (dZ2 -> plan.ws_dZ2);
     returns the previous setting (``stgcn_set_debug_stages``)."""
+    _plan_cache.clear()      # (the debug mode makes the forward store U2 / S2 again: another `saved` layout)
     return bool(_lib.lib().dll.stgcn_set_debug_stages(1 if on else 0))
 
 
@@ -508,11 +509,11 @@ class _STBlockFn(torch.autograd.Function):
         offer, _offer_hook_next = _offer_hook_next, False
         if offer:       # a later backward is possible: grad mode on and something upstream requires grad (decided in st_conv_block)
             hk = _lib.LnHook()
-            L.check(L.dll.stgcn_stblock_ln_hook(C.byref(desc), C.byref(pst), saved.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev),
+            L.check(L.dll.stgcn_stblock_ln_hook(C.byref(desc), C.byref(pst), y.data_ptr(), ws.data_ptr(), seed, offset, _optr(offset_dev),
                                                 C.byref(hk)), "stgcn_stblock_ln_hook")
-            ctx.own_hook = LnHookState(hk, (saved, ws, ps, offset_dev))
+            ctx.own_hook = LnHookState(hk, (ws, ps, offset_dev))      # (y itself is pinned by the _ln_hooks entry)
             _offer_ln_hook(y, ctx.own_hook)
-        ctx.save_for_backward(x_cl, saved, gso_t_pad, *[p for p in params if p is not None])
+        ctx.save_for_backward(x_cl, saved, gso_t_pad, y, *[p for p in params if p is not None])
         ctx.param_present = [p is not None for p in params]
         ctx.cfg, ctx.training, ctx.seed, ctx.offset, ctx.wsc, ctx.ws = cfg, training, seed, offset, wsc, ws
         ctx.offset_dev = offset_dev
@@ -524,7 +525,7 @@ class _STBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x_cl, saved, gso_t_pad, *present = ctx.saved_tensors
+        x_cl, saved, gso_t_pad, y, *present = ctx.saved_tensors
         it = iter(present)
         params = [next(it) if pr else None for pr in ctx.param_present]
         cfg = ctx.cfg
@@ -560,7 +561,7 @@ class _STBlockFn(torch.autograd.Function):
         gst = _param_struct(StblockGrads, grads)
         ih = ctx.in_hook if dx is not None else None
         L.check(L.dll.stgcn_stblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(),
-                                                  saved.data_ptr(), ws.data_ptr(), C.byref(gst),
+                                                  y.data_ptr(), saved.data_ptr(), ws.data_ptr(), C.byref(gst),
                                                   None if dx is None else dx.data_ptr(), ctx.seed, ctx.offset, _optr(ctx.offset_dev),
                                                   None if ih is None else C.byref(ih.hook), _stream_of(x_cl)),
                 "stgcn_stblock_backward")

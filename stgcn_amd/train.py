@@ -365,9 +365,10 @@ class GraphedTrainStep:
                 if self.fused and i > 0:
                     if self.arena is None:
                         self.arena = GradArena([p for p in model.parameters() if p.grad is not None])
-                        if world == 1:
-                            self._try_fold_counters(dev)     # (is itself one fused training step)
-                            continue
+                        # the step counters ride on the weight-pack launch for every world size: with world > 1 the second graph is then
+                        # exactly ONE launch (AdamW over the all-reduced arena), no add_ / remainder_ launches of the counters
+                        self._try_fold_counters(dev)         # (is itself one fused training step)
+                        continue
                     self._eager_fused_once()
                 else:
                     self._eager_once()
@@ -406,8 +407,9 @@ class GraphedTrainStep:
                     self.flat.mul_(1.0 / world)
                     torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
                 self.opt.step()
-                DropoutStream.advance()
-                self._advance_series()
+                if not self.fold:
+                    DropoutStream.advance()
+                    self._advance_series()
         # one full replay inside the constructor: a capture / replay problem surfaces here (where the caller can
         # still fall back to eager launches of the same kernels), not inside a timed loop
         self(x_example, y_example)
@@ -483,9 +485,10 @@ class GraphedTrainStep:
         self._fused_fwd_bwd()
         if self.world > 1:
             dist.all_reduce(self.arena.flat)
-            self.opt.step()
-            DropoutStream.advance()
-            self._advance_series()
+            self.opt.step()                  # (fold: the pack launch counted the step, trainer_owns_step keeps step() from counting again)
+            if not self.fold:
+                DropoutStream.advance()
+                self._advance_series()
         else:
             self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
             if not self.fold:

@@ -111,8 +111,9 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     for k in range(1, terms):
         stored[f"fwd.X{k}"] = err_stored(seg_bf16(svn, plan.sv_Xk + (k - 1) * per, (B, T1, N, c1)), sv["Xs"][k])
     stored["fwd.G"] = err_stored(seg_bf16(svn, plan.sv_G, (B, T1, N, c1)), sv["G"])
-    stored["fwd.U2"] = err_stored(seg_bf16(svn, plan.sv_U2, (B, T2, N, c2)), sv["U2"])
-    stored["fwd.S2"] = err_stored(seg_bf16(svn, plan.sv_S2, (B, T2, N, c2)), sv["S2"])
+    if plan.stored_US2:      # (only when LayerNorm runs as a separate pass over the stored gate inputs: more than 448 nodes)
+        stored["fwd.U2"] = err_stored(seg_bf16(svn, plan.sv_U2, (B, T2, N, c2)), Q(sv["U2"]))
+        stored["fwd.S2"] = err_stored(seg_bf16(svn, plan.sv_S2, (B, T2, N, c2)), Q(sv["S2"]))
     stored["fwd.y"] = err_stored(cl(bf16_numpy(y)), y_ref)
     stored["fwd.y_vs_fp64"] = err_stored(cl(bf16_numpy(y)), y64)          # (reported; bounded loosely below)
     f32["fwd.mean"] = float(np.abs(svn[plan.sv_mean:plan.sv_mean + B * T2].reshape(B, T2) - sv["mean"]).max() / max(1e-30, np.abs(sv["mean"]).max() + 1e-3))
@@ -128,7 +129,9 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     svh["A"] = seg_bf16(svn, plan.sv_A, (B, T1, N, c1))
     svh["Xs"] = [svh["A"]] + [seg_bf16(svn, plan.sv_Xk + (k - 1) * per, (B, T1, N, c1)) for k in range(1, terms)]
     svh["G"] = seg_bf16(svn, plan.sv_G, (B, T1, N, c1))
-    svh["U2"], svh["S2"] = seg_bf16(svn, plan.sv_U2, (B, T2, N, c2)), seg_bf16(svn, plan.sv_S2, (B, T2, N, c2))
+    svh["U2"], svh["S2"], svh["H2"] = st.tconv_fwd(svh["G"], sv["W2"], st.fold_tconv(bp["tc2_w"], bp["tc2_b"], bp["tc2_aw"], bp["tc2_ab"], c1, c2, Kt)[1],
+                                                   Kt, c2, act, Q)      # what tc2_bwd_kernel recomputes from the stored G
+    svh["y"] = cl(bf16_numpy(y))
     svh["mean"] = svn[plan.sv_mean:plan.sv_mean + B * T2].reshape(B, T2).astype(np.float64)
     svh["rstd"] = svn[plan.sv_rstd:plan.sv_rstd + B * T2].reshape(B, T2).astype(np.float64)
     stages = {}
@@ -160,7 +163,8 @@ def assert_bf16_errors(stored, f32):
         if not (e["rms"] <= RMS_TOL and e["max"] <= MAX_TOL):
             bad[k] = e
     for k, v in f32.items():
-        tol = 0.0 if (k.startswith("grad_none_ok") or k.endswith("bitwise")) else (1e-4 if k in ("fwd.mean", "fwd.rstd") else F32_TOL)
+        # (LayerNorm statistics are fp32 sums, but of values downstream of bf16 tensors in which a few elements differ by one ulp)
+        tol = 0.0 if (k.startswith("grad_none_ok") or k.endswith("bitwise")) else (1e-3 if k in ("fwd.mean", "fwd.rstd") else F32_TOL)
         if not (v <= tol):
             bad[k] = v
     assert not bad, f"out of tolerance: {bad}\nstored: {stored}\nf32: {f32}"

@@ -25,6 +25,7 @@ CASES = [
 @pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T", CASES)
 def test_block_forward_stages(c_in, channels, Kt, Ks, gct, act, N, B, T):
     L = bind_emulator()
+    ops.set_debug_stages(True)      # the forward stores U2 / S2 only for the stage tests (tc2_bwd_kernel recomputes them)
     cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
     gso = nonsym_gso(N, 5)
     rs = np.random.RandomState(11)

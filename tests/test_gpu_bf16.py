@@ -1,0 +1,142 @@
+"""-m gpu: the bf16 configurations (BASELINE.json configs[2] PEMS-BAY 325 nodes bs 64 bf16, configs[4] 8192 nodes Ks 5 bf16) on a real
+MI355X, through the C ABI: bf16 storage of every activation / saved tensor / activation gradient, v_mfma_f32_16x16x16_bf16 temporal and
+graph convolutions (v_mfma_f32_16x16x32_bf16 operator GEMMs on the tiled path), fp32 accumulation / LayerNorm statistics / parameters.
+Checked against the bf16 statement of the stage oracle (oracle/stblock_stages.py QuantBf16; tolerances: tests/bf16_util.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import real_gso
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 21, 2, 7, True),
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 6, True),
+    (64, (64, 16, 64), 3, 3, "graph_conv", "gtu", 35, 1, 5, False),
+    (32, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 40, 1, 7, True),
+    (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 300, 1, 5, False),
+]
+
+
+def _bind():
+    from tests.gpu_util import bind_hip
+    return bind_hip()
+
+
+@pytest.mark.parametrize("c_in,channels,Kt,Ks,gct,act,N,B,T,training", SMALL)
+def test_small_cases_bf16(c_in, channels, Kt, Ks, gct, act, N, B, T, training):
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, channels, Kt, Ks, gct, act, N, B, T, training))
+
+
+@pytest.mark.parametrize("blk", [0, 1])
+def test_c3_full_size_bf16(blk):
+    """BASELINE.json configs[2] at full size: PEMS-BAY 325 nodes (the real operator), bs 64, bf16, both ST blocks, dropout on."""
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    gso = real_gso("pems_bay.cheb_sym_norm_lap")
+    c_in, T = ((1, 12), (64, 8))[blk]
+    assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 325, 64, T, True, gso=gso))
+
+
+def test_c3_head_bf16():
+    """The output head at the C3 size (B 64, N 325) with bf16 activations."""
+    from tests.bf16_util import assert_bf16_errors, run_head_case_bf16
+    _bind()
+    assert_bf16_errors(*run_head_case_bf16("cuda:0", 325, 64))
+
+
+@pytest.mark.parametrize("blk", [0, 1])
+def test_c5_graph_8192_nodes_bf16(blk):
+    """BASELINE.json configs[4] graph size (8192 nodes, dense operator, ChebConv Ks = 5) at batch 1 with bf16 activations: operand-form
+    GEMMs on the bf16 matrix cores, recursion / Clenshaw recurrence on stored bf16 terms, LayerNorm as a separate pass."""
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    from tests.emu_util import big_gso
+    _bind()
+    c_in, T = ((1, 6), (64, 5))[blk]
+    assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, (64, 16, 64), 3, 5, "cheb_graph_conv", "glu", 8192, 1, T, True, gso=big_gso(8192, 3)))
+
+
+def test_tiled_small_graph_bf16():
+    from stgcn_amd import ops
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    prev = ops.set_gc_tiled_min_nodes(1)
+    try:
+        res = run_block_case_bf16("cuda:0", 64, (64, 16, 64), 3, 4, "cheb_graph_conv", "glu", 150, 3, 7, True)
+    finally:
+        ops.set_gc_tiled_min_nodes(prev)
+    assert_bf16_errors(*res)
+
+
+def test_c3_model_bf16_vs_reference_golden():
+    """Whole model at the C3 size with bf16 activations against the fixture the reference produced in fp32 at bs 64: bf16-sized bars
+    (the tight comparison is stage-level, above)."""
+    import types
+    from stgcn_amd import models
+    from tests.helpers import cfg_from_fixture, fixture_gso, fixture_params, load_fixture
+    _bind()
+    name = "pemsbay_c3_b64_f32"
+    fx = load_fixture(name)
+    cfg = cfg_from_fixture(fx)
+    dev = "cuda:0"
+    gso = torch.from_numpy(fixture_gso(name, fx)).to(dev)
+    args = types.SimpleNamespace(Kt=cfg.Kt, Ks=cfg.Ks, act_func=cfg.act_func, graph_conv_type=cfg.graph_conv_type, gso=gso,
+                                 enable_bias=True, droprate=cfg.droprate, n_his=cfg.n_his)
+    model = models.STGCNChebGraphConv(args, cfg.blocks, int(fx["n_vertex"]))
+    model.load_state_dict(fixture_params(fx, cfg, torch.float32), strict=True)
+    model = model.to(dev).set_compute_dtype(torch.bfloat16)
+    rs = np.random.RandomState(int(fx["seed"]) + 1)
+    B, N = int(fx["B"]), int(fx["n_vertex"])
+    x = torch.from_numpy(rs.standard_normal((B, 1, cfg.n_his, N))).float().to(dev)
+    y = torch.from_numpy(rs.standard_normal((B, N))).float().to(dev)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    ref = fx["eval.out"]
+    err = float(np.abs(out.cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+    assert out.dtype == torch.float32 and err <= 3e-2, err
+    model.train()
+    model.zero_grad()
+    loss = torch.nn.MSELoss()(model(x).view(len(x), -1), y)
+    loss.backward()
+    assert abs(loss.item() - float(fx["train.loss"])) <= 1e-2 * abs(float(fx["train.loss"]))
+    nograd = set(str(s) for s in fx["nograd"])
+    for k, prm in model.named_parameters():
+        if k in nograd:
+            assert prm.grad is None, k
+            continue
+        r = fx["gradsum." + k]
+        if prm.numel() == 1:      # fc2.bias: d loss / d b = (2 / n) sum(pred - y), a difference of large sums -- absolute bar
+            assert abs(float(prm.grad.double().sum()) - r[0]) <= 5e-3, k
+            continue
+        assert abs(float(prm.grad.double().abs().sum()) - r[1]) <= 5e-2 * r[1] + 1e-9, k
+
+
+def test_graph_replay_bf16_matches_eager():
+    """The captured training step (hipGraph, device-side windows of a resident series, fused step tail) with bf16 activations: finite,
+    decreasing-ish losses, and the parameters stay fp32."""
+    import types
+    from stgcn_amd import DropoutStream, models
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer
+    _bind()
+    dev = torch.device("cuda", 0)
+    N, B = 207, 32
+    gso = torch.from_numpy(real_gso("metr_la.cheb_sym_norm_lap")).to(dev)
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True, droprate=0.5, n_his=12)
+    torch.manual_seed(0)
+    model = models.STGCNChebGraphConv(args, [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]], N).to(dev).set_compute_dtype(torch.bfloat16)
+    model.train()
+    DropoutStream.manual_seed(3)
+    opt = make_optimizer(model, capturable=True)
+    g = torch.Generator().manual_seed(1)
+    series = torch.randn(8 * B + 24, N, generator=g).to(dev)
+    x0 = torch.zeros(B, 1, 12, N, device=dev)
+    y0 = torch.zeros(B, N, device=dev)
+    with GraphedTrainStep(model, opt, x0, y0, series=series, n_his=12, n_pred=12) as step:
+        losses = [float(step()) for _ in range(12)]
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[6:]) < losses[0], losses
+    assert all(p.dtype == torch.float32 for p in model.parameters())
