@@ -615,6 +615,30 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     const int HT = a.NP / 16;
     int pf = 0, pb = 1;
     gc_parts_override(pf, pb);
+    {   // round 3: slab split over parts, parameter-gradient jobs on their own waves (gconv_bwd2_kernel); STGCN_GCBWD2=0: the one-workgroup-per-slab kernel
+        static const int off = getenv("STGCN_GCBWD2") ? atoi(getenv("STGCN_GCBWD2")) == 0 : 0;
+        static const int force_parts = getenv("STGCN_GCBWD2_PARTS") ? atoi(getenv("STGCN_GCBWD2_PARTS")) : 0;
+        // One node tile per tile wave (<= 8 tile waves per workgroup), and the whole grid resident in ONE round: every part re-stages the
+        // slab's dY and re-forms all G_k, so a grid that needs more rounds than the slab kernel costs more than it returns (measured at
+        // the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
+        const size_t lds2 = ((size_t)(a.Ks - 1) * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
+        if (!off && lds2 <= 150 * 1024 && HT <= 64) {
+            int best = 0;
+            for (int parts = (HT + 7) / 8; parts <= HT; ++parts) {
+                const int per = (HT + parts - 1) / parts, njw = (a.Ks + 1 + parts - 1) / parts;
+                if (per < 4 && parts > (HT + 7) / 8 && !force_parts) break;     // keep >= 4 tile waves per workgroup
+                const int cap = STGCN_ET_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, (per + njw) * 64, lds2));
+                if (force_parts ? parts == force_parts : a.slabs * parts <= cap) best = parts;
+                if (force_parts && parts == force_parts) break;
+            }
+            if (best > 0) {
+                const int per = (HT + best - 1) / best, njw = (a.Ks + 1 + best - 1) / best;
+                a.parts = best;
+                STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), dim3((unsigned)(a.slabs * best)), dim3((per + njw) * 64), lds2, a, per);
+                return STGCN_OK;
+            }
+        }
+    }
     const GcGeom g = gc_geom(HT, pb);
     a.parts = g.parts;
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
@@ -814,7 +838,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->sv_Xk = take((int64_t)(v.terms - 1) * act(v.rows1 * d->c1));
     p->sv_G = take(act(v.rows1 * d->c1));
     const BwdGeom bgs = bwd_geom(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
-    p->stored_US2 = (!tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N) || !bgs.k1 || g_debug_stages) ? 1 : 0;
+    p->stored_US2 = (!tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N) || !bgs.k1 || g_debug_stages || !tc2_recompute(bf)) ? 1 : 0;
     p->sv_U2 = take(act(p->stored_US2 ? v.rows2 * d->c2 : 0));
     p->sv_S2 = take(act(p->stored_US2 ? v.rows2 * d->c2 : 0));
     p->sv_mean = take(v.slabs2);

@@ -46,6 +46,12 @@ inline int device_cus() {
     }
     return cus;
 }
+// tc2_bwd_kernel recomputes the gate inputs of tmp_conv2 (and the forward does not store them) for bf16 activations, reads the stored
+// ones for fp32 (see the kernel's header comment for the measurement); STGCN_TC2_RECOMP=0/1 forces one
+inline bool tc2_recompute(int dtype_bf16) {
+    static const int force = getenv("STGCN_TC2_RECOMP") ? atoi(getenv("STGCN_TC2_RECOMP")) : -1;
+    return force >= 0 ? force != 0 : dtype_bf16 != 0;
+}
 inline bool tc1_ts_shape(int c_in, int c0, int c1, int Kt) { return c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64); }
 inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
     return (fuse_mask() & FUSE_TC1_BWD) && tc1_ts_shape(c_in, c0, c1, Kt) && tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
@@ -645,6 +651,153 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = GT0[(4 * g + r) * LDX + h] + (acc1[q][r] + acc2[q][r]) + y[r];
+            stx4_wt(et_ptr<ET>(a.dA) + ((size_t)slab * N + h) * 16 + 4 * g, o);
+        }
+    }
+}
+
+// ================================================================================================
+// B3 (round 3): the same backward with the slab split over `parts` workgroups and the parameter-gradient jobs on their own waves.
+// The one-workgroup-per-slab kernel above walks four serial phases (stage dY and Ks terms of X, dW jobs on 4 of its 13 waves,
+// G_k on all tiles, the operator products) on 192 - 320 workgroups: at the C2 size its duration does not depend on the batch size
+// (19 us from bs 4 to bs 32 for the second block, profiles/r2-40_batch_sweep.log).  Here
+//   * waves 0 .. nwa-1 of part p own the node tiles p + parts * (w + nwa * q): they stage dY (all rows: G_k is the K dimension of the
+//     operator products), form G_k = dY W_k^T for k >= 1 on all tiles into LDS ([c][node], the A operand) and G_0^T for their own tiles
+//     in registers (W_0 as the A operand, dY rows as B: the D layout of the operator products), then run the products and write dA;
+//   * the remaining waves ("job waves") form the slab's parameter gradients dW_k = X_k^T dY (k = part + parts * j) and db straight from
+//     global memory -- no LDS, no staging of X_k -- concurrently with the operator products of the other waves.
+// LDS holds dY and Ks - 1 terms only (44 KB at 207 nodes, Ks = 3: three workgroups per CU instead of two).
+// grid = slabs * parts, block = (nwa + njw) * 64 with njw = ceil((Ks + 1) / parts).
+// ================================================================================================
+template <int MAXQ, typename ET>
+__global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa) {
+    typedef Mma<ET> MM;
+    extern __shared__ float stgcn_smem[];
+    const int THREADS = blockDim.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int P = a.parts, prt = (int)(blockIdx.x % (unsigned)P);
+    const long slab = blockIdx.x / (unsigned)P;
+    const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, LDY = 20, Ks = a.Ks;
+    float* const GTk = stgcn_smem;                         // GT(k) = GTk + (k - 1)*16*LDX for k >= 1, transposed [c][node]
+    float* const dYs = stgcn_smem + (Ks - 1) * 16 * LDX;   // [NP][LDY] row major
+    const ET* const dYsl = et_ptr<ET>(a.dY) + (size_t)slab * N * 16;
+
+    // ---- every wave: stage dY (row major) ------------------------------------------------------------------------------------
+    for (int idx = tid; idx < NP * 4; idx += THREADS) {
+        const int n = idx >> 2, c4 = idx & 3;
+        st4(dYs + n * LDY + c4 * 4, n < N ? ldx4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
+    }
+    __syncthreads();   // (1)
+
+    if (w >= nwa) {
+        // =========================================== job waves: parameter-gradient partials ======================================
+        __syncthreads();   // (2) (nothing to wait for: keeps the barrier count of the workgroup)
+        float* part = a.part + (size_t)slab * (Ks + 1) * 256;
+        for (int kk = prt + P * (w - nwa); kk <= Ks; kk += P * ((THREADS >> 6) - nwa)) {
+            // job kk < Ks: dW_kk = X_kk^T dY (A[m = c][k = node] straight from memory, 64-byte segments) ; kk == Ks: db via A = 1
+            const ET* Xsl = kk < Ks ? (kk == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(kk - 1) * a.slabs * N * 16) + (size_t)slab * N * 16 : nullptr;
+            auto fetchA = [&](int kc) __attribute__((always_inline)) {
+                f32x4 v = {1.f, 1.f, 1.f, 1.f};
+                if (Xsl) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int n = kc * 16 + 4 * g + s;
+                        v[s] = n < N ? ldx1(Xsl + (size_t)n * 16 + l15) : 0.f;
+                    }
+                }
+                return v;
+            };
+            f32x4 c0 = zero4(), c1 = zero4();
+            f32x4 an = fetchA(0);
+            for (int kc = 0; kc < KCH; ++kc) {
+                const f32x4 af = an;
+                if (kc + 1 < KCH) an = fetchA(kc + 1);
+                MM::mma_split(MM::cvt(af), MM::cvt(gather4(dYs + (kc * 16 + 4 * g) * LDY + l15, LDY)), c0, c1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[kk * 256 + (4 * g + r) * 16 + l15] = c0[r] + c1[r];
+        }
+        return;
+    }
+
+    // =============================================== tile waves ==============================================================
+    const int wave = prt + P * w, WAVES = P * nwa;   // owned node tiles: wave + WAVES * q
+    // G_k = dY W_k^T, k >= 1, on ALL node tiles (the K dimension of the products below)
+    for (int k = 1; k < Ks; ++k) {
+        const typename MM::frag wf = MM::cvt(ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g));   // B[kk = j][col = i] = W_k[i = l15][j = 4g + s]
+        for (int ht = w; ht < HT; ht += nwa) {
+            const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
+            st4(GTk + ((k - 1) * 16 + l15) * LDX + ht * 16 + 4 * g, MM::mma(MM::cvt(af), wf, zero4()));   // D[h = 4g + r][i = l15]
+        }
+    }
+    // G_0^T of the owned tiles in the D layout of the operator products: A[m = i = l15][k = j] = W_0[i][j], B[k = j][n = h = l15] = dY[h][j]
+    f32x4 g0[MAXQ];
+    {
+        const typename MM::frag w0 = MM::cvt(a.kipf ? zero4() : ld4(a.W + l15 * 16 + 4 * g));
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            g0[q] = ht < HT ? MM::mma(w0, MM::cvt(ld4(dYs + (ht * 16 + l15) * LDY + 4 * g)), zero4()) : zero4();
+        }
+    }
+    __syncthreads();   // (2) every G_k complete
+
+    const size_t MSZ = (size_t)NP * NP;
+    f32x4 acc1[MAXQ], acc2[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        acc1[q] = zero4();
+        acc2[q] = zero4();
+    }
+    for (int k0 = 1; k0 < Ks; k0 += 2) {
+        const bool two = k0 + 1 < Ks;
+        const float* T1 = a.LTp + (size_t)(k0 - 1) * MSZ;
+        const float* T2 = T1 + MSZ;
+        const float* G1 = GTk + (k0 - 1) * 16 * LDX;
+        const float* G2 = G1 + 16 * LDX;
+        f32x4 p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // operator fragments one (p) and two (n) chunks ahead
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
+            const bool in = ht < HT;
+            p1[q] = in ? ld4(T1 + o) : zero4();
+            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
+            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
+            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
+        }
+        for (int kc = 0; kc < KCH; ++kc) {
+            const typename MM::frag af1 = MM::cvt(ld4(G1 + l15 * LDX + kc * 16 + 4 * g));
+            const typename MM::frag af2 = MM::cvt(two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4());
+            f32x4 b1[MAXQ], b2[MAXQ];
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                b1[q] = p1[q]; b2[q] = p2[q];
+                p1[q] = n1[q]; p2[q] = n2[q];
+                const int ht = wave + WAVES * q;
+                if (kc + 2 < KCH && ht < HT) {
+                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
+                    n1[q] = ld4(T1 + o);
+                    if (two) n2[q] = ld4(T2 + o);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                if (wave + WAVES * q < HT) {
+                    if (two) MM::mma_2x(af1, MM::cvt(b1[q]), acc1[q], af2, MM::cvt(b2[q]), acc2[q]);
+                    else acc1[q] = MM::mma(af1, MM::cvt(b1[q]), acc1[q]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int ht = wave + WAVES * q;
+        const int h = ht * 16 + l15;
+        if (ht < HT && h < N) {
+            const f32x4 y = ld4(dYs + h * LDY + 4 * g);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = g0[q][r] + (acc1[q][r] + acc2[q][r]) + y[r];
             stx4_wt(et_ptr<ET>(a.dA) + ((size_t)slab * N + h) * 16 + 4 * g, o);
         }
     }

@@ -29,7 +29,9 @@ namespace stgcn {
 // ================================================================================================
 struct Tc2BwdArgs {
     const float* dy;          // [B][T2][N][C2]
-    const float* Wp;          // packed W_eff2 (PK_TCONV_FWD fragments): the gate inputs U2 / S2 are RECOMPUTED from the G tiles, not read
+    const float* U;           // [B][T2][N][C2]  saved gate inputs of tmp_conv2 (RECOMP = false)
+    const float* S;
+    const float* Wp;          // packed W_eff2 (PK_TCONV_FWD fragments; RECOMP = true: the gate inputs are RECOMPUTED from the G tiles, not read)
     const float* bias;        // b_eff2 [2*C2]
     const float* gamma;       // [N][C2]
     const float* mean;        // [B*T2]
@@ -50,8 +52,8 @@ struct Tc2BwdArgs {
 };
 
 constexpr int kTsMaxT = 32;   // time steps of G kept in LDS (host falls back to the unfused kernels beyond)
-inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
-    return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2 + 2 * 16 * (2 * C2 + 4)) * sizeof(float);
+inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2, bool recomp = true) {
+    return ((size_t)(Kt + 1) * 16 * (2 * C2 + 4) + (size_t)T1 * 16 * 20 + 2 * 4 * 16 * 20 + 4 * (size_t)T2 + (recomp ? 2 * 16 * (2 * C2 + 4) : 0)) * sizeof(float);
 }
 
 // Wave specialisation: a workgroup is 8 waves = 4 "E" waves + 4 "M" waves, one of each per SIMD.
@@ -60,17 +62,22 @@ inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2) {
 //     M waves (matrix cores) : F(t - 1) = dYg[t - 1] from the 4 partial tiles of the previous step;
 //                              M(t) = weight-gradient MFMAs of tile t + transposed-conv MFMAs for output step t -> `red[t & 1]`;
 //                              R(t + 2) = the gate inputs U2 = P + b, S2 = sigmoid(Q + b) of tile t + 2, RECOMPUTED from the G tiles the
-//                              workgroup holds anyway (K = KT * 16: KT product steps per 16 output channels) -> `USt[t & 1]`.  The
-//                              forward therefore stores neither U2 nor S2 (round 2 wrote them in tc2_ln_fwd and read them back here and
-//                              in the consumer's LayerNorm hook: 2 x rows2 x c2 elements written once and read twice per block).
+//                              workgroup holds anyway (K = KT * 16: KT product steps per 16 output channels) -> `USt[t & 1]` (RECOMP).
+//                              The forward then stores neither U2 nor S2 (2 x rows2 x c2 elements written once and read once per block).
 //   iteration t:  barrier | E waves: E(t + 1)  ||  M waves: F(t - 1), M(t), R(t + 2)
+// RECOMP costs KT more product steps per 16 output channels and step: + 50 % matrix work in this kernel.  Measured on MI355X
+// (profiles/r3-02_*): with fp32 products the CUs that hold two workgroups become MFMA-bound (C2: 27.3 -> 34.0 us, 18.2 -> 21.6 us per
+// launch, more than tc2_ln_fwd and the hooks gain), with bf16 products the step gains 5 % (C3: 0.790 -> 0.753 ms).  The host therefore
+// recomputes for bf16 activations and reads the stored gate inputs for fp32 (STGCN_TC2_RECOMP=0/1 overrides).
 // The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
 // walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
 // spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
-template <int C2, int KT, bool TRAINING, int ACT, typename ET>
+template <int C2, int KT, bool TRAINING, int ACT, bool RECOMP, typename ET>
 __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     typedef Mma<ET> MM;
     const ET* const dy_ = et_ptr<ET>(a.dy);
+    const ET* const U_ = et_ptr<ET>(a.U);
+    const ET* const S_ = et_ptr<ET>(a.S);
     const ET* const G_ = et_ptr<ET>(a.G);
     ET* const dYg_ = et_ptr<ET>(a.dYg);
     constexpr int NC = 2 * C2, LDZ = NC + 4, NTW = NC / 64, QW = NC / 64, IT = C2 / 64, LDG = 20, RING = KT + 1, RED = 4 * 16 * LDG;
@@ -92,13 +99,17 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 
     if (roleE) {
         // =========================================== E waves ===========================================================
-        struct Tile { f32x4 dy[IT]; };
+        struct Tile { f32x4 dy[IT], u[IT], s[IT]; };
         auto fetch = [&](int t2, Tile& t) {
             const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 t.dy[it] = ldx4(dy_ + e0 + 64 * it);
                 if (!rv) t.dy[it] = zero4();
+                if constexpr (!RECOMP) {
+                    t.u[it] = ldx4(U_ + e0 + 64 * it);
+                    t.s[it] = rv ? ldx4(S_ + e0 + 64 * it) : zero4();   // s = 0 makes every product of the gate backward vanish
+                }
             }
         };
         Tile p0, p1;
@@ -163,8 +174,14 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             for (int it = 0; it < IT; ++it) {
                 f32x4 dy = tl.dy[it];
                 const int c4 = cq + 16 * it;
-                const f32x4 u = ld4(Us + 4 * c4);
-                const f32x4 s = rv ? ld4(Us + C2 + 4 * c4) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
+                f32x4 u, s;
+                if constexpr (RECOMP) {
+                    u = ld4(Us + 4 * c4);
+                    s = rv ? ld4(Us + C2 + 4 * c4) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
+                } else {
+                    u = tl.u[it];
+                    s = tl.s[it];
+                }
                 if constexpr (TRAINING) {
                     const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             }
         };
         __syncthreads();   // (A) cs complete (written by E waves), GT complete (written by M waves)
-        __syncthreads();   // (A2) gate inputs of tile 0 recomputed
+        if constexpr (RECOMP) __syncthreads();   // (A2) gate inputs of tile 0 recomputed
         STGCN_PHASE(8, 1);
         E(0, p0);
         p0 = p1;
@@ -244,15 +261,17 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         constexpr int NTP = C2 / 64, MT = C2 / 16;
         typename MM::frag wP[NTP][KT], wQ[NTP][KT];
         f32x4 bp[NTP], bq[NTP];
+        if constexpr (RECOMP) {
 #pragma unroll
-        for (int j = 0; j < NTP; ++j) {
+            for (int j = 0; j < NTP; ++j) {
 #pragma unroll
-            for (int kc = 0; kc < KT; ++kc) {
-                wP[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j) * KT + kc) * 64 + lane) * 4));
-                wQ[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j + MT) * KT + kc) * 64 + lane) * 4));
+                for (int kc = 0; kc < KT; ++kc) {
+                    wP[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j) * KT + kc) * 64 + lane) * 4));
+                    wQ[j][kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + 4 * j + MT) * KT + kc) * 64 + lane) * 4));
+                }
+                bp[j] = ld4(a.bias + 16 * (w + 4 * j) + 4 * g);
+                bq[j] = ld4(a.bias + C2 + 16 * (w + 4 * j) + 4 * g);
             }
-            bp[j] = ld4(a.bias + 16 * (w + 4 * j) + 4 * g);
-            bq[j] = ld4(a.bias + C2 + 16 * (w + 4 * j) + 4 * g);
         }
         // R(t): Z^T[o][row] = W_eff2^T im2col(G)^T for tile t: A = the weights, B[k = ch 4g + s][n = row l15] from the transposed G tiles;
         // D leaves a lane with 4 consecutive channels of row l15, P and Q of one channel in the same lane
@@ -289,9 +308,11 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
         __syncthreads();   // (A)
-        R(0);
-        __syncthreads();   // (A2)
-        if (T2 > 1) R(1);
+        if constexpr (RECOMP) {
+            R(0);
+            __syncthreads();   // (A2)
+            if (T2 > 1) R(1);
+        }
         for (int t1 = 0; t1 < T1; ++t1) {
             __syncthreads();   // (B) dZ2 tile t1 and the partial tiles of step t1 - 1 are visible
             if (t1 > 0) {      // F(t1 - 1): dYg = relu'(G) * (sum of the 4 waves' partial tiles), thread (row r, channel cq)
@@ -333,7 +354,9 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 }
             }
             st4(red + (t1 & 1) * RED + (w * 16 + l15) * LDG + 4 * g, accd[0] + accd[1]);   // D[m = i = 4g + r][n = row = l15]
-            if (t1 + 2 < T2) R(t1 + 2);   // slot (t1 & 1): tile t1's gate inputs were last read by E(t1), before barrier (B) of this step
+            if constexpr (RECOMP) {
+                if (t1 + 2 < T2) R(t1 + 2);   // slot (t1 & 1): tile t1's gate inputs were last read by E(t1), before barrier (B) of this step
+            }
         }
         __syncthreads();       // (C)
         {

@@ -63,11 +63,12 @@ def _worker(rank, world, port, out):
     # device-side windows of the resident series: rank r takes windows [k*BG + r*bl, ... + bl) of global step k
     x0, y0 = _windows(series, rank * bl, bl)
     gs = GraphedTrainStep(model, opt, x0, y0, world=world, warmup=2, series=series, n_his=N_HIS, n_pred=N_PRED, rank=rank)
-    assert gs.fused and gs.g2 is not None and not gs.fold
+    assert gs.fused and gs.g2 is not None and gs.fold      # the step counters ride on the pack launch for world > 1 as well
     for _ in range(3):
         gs()
     torch.cuda.synchronize()
-    assert int(gs.index.item()) == 6 * BG + rank * bl
+    # 6 global steps ran (k = 0 .. 5); with the counters on the pack launch the index is advanced BEFORE each step: it holds step 5's position
+    assert int(gs.index.item()) == 5 * BG + rank * bl
     if rank == 0:
         torch.save({k: v.cpu() for k, v in model.state_dict().items()}, out)
     dist.barrier()
