@@ -49,7 +49,7 @@ CONFIGS = {
                workload="C5: synthetic dense 8192-node graph, STGCNChebGraphConv Ks=5 Kt=3, n_his=12, bs=16, {dtype} activations, tiled graph conv, "
                         "dropout 0.5, AdamW; full step"),
 }
-PMC_TRAFFIC_FILE = "r2-39_pmc_traffic.json"          # (named explicitly: it has to be re-measured whenever a kernel's traffic changes)
+PMC_TRAFFIC_FILE = "r3-06_pmc_traffic.json"          # (named explicitly: it has to be re-measured whenever a kernel's traffic changes)
 B_OVERRIDE = os.environ.get("STGCN_BENCH_B")       # (env: batch-size sweeps of tools/, not the headline)
 
 

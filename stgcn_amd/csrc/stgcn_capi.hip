@@ -336,11 +336,25 @@ inline bool tconv4_ok(const TconvFwdArgs& a) {
     return !off && a.Cout == 128 && (a.ts.C & 3) == 0 && a.KCH * 16 == a.ts.taps * a.ts.C && !a.Wap && !a.H &&
            (size_t)tconv2_lds_floats(a.KCH * 16, 256, 32) * sizeof(float) <= 64 * 1024;
 }
+// Rows of a head tile.  The C2 head has B * N = 6624 rows: 207 tiles of 32 rows leave 49 CUs idle and give every other CU ONE workgroup.
+// Measured (profiles/r3-05_head_tile_ab.txt): 16-row tiles take the two fc kernels from 18.5 / 16.9 to 15.7 / 13.8 us and the conv from
+// 18.6 to 20.4 us (its 256 KB weight stream per workgroup does not shrink with the tile) -- so the fc kernels default to 16 rows, the
+// conv / transposed conv to 32.  STGCN_HEAD_FC_TILE / STGCN_HEAD_TILE = 16 | 32 override.
+inline int head_tile_rows() {
+    static const int t = getenv("STGCN_HEAD_TILE") ? atoi(getenv("STGCN_HEAD_TILE")) : 32;
+    return t == 16 ? 16 : 32;
+}
+inline int head_fc_tile_rows() {
+    static const int t = getenv("STGCN_HEAD_FC_TILE") ? atoi(getenv("STGCN_HEAD_FC_TILE")) : 16;
+    return t == 32 ? 32 : 16;
+}
 template <bool PLAIN>
 int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {
-    constexpr int TM = 2, KC = 4;
-    const size_t lds = (size_t)(tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TM) + 16) * sizeof(float);   // + 16: reduction words of the fused staging
-    STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<TM, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 16 * TM)), dim3(512), lds, aa);
+    constexpr int KC = 4;
+    const int TMr = head_tile_rows() / 16;
+    const size_t lds = (size_t)(tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TMr) + 16) * sizeof(float);   // + 16: reduction words of the fused staging
+    if (TMr == 1) STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<1, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 16)), dim3(512), lds, aa);
+    else STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<2, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 32)), dim3(512), lds, aa);
     return STGCN_OK;
 }
 int launch_tconv_fwd(const char* label, const TconvFwdArgs& a, hipStream_t st) {
@@ -624,17 +638,20 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
         const size_t lds2 = ((size_t)(a.Ks - 1) * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
         if (!off && lds2 <= 150 * 1024 && HT <= 64) {
             int best = 0;
-            for (int parts = (HT + 7) / 8; parts <= HT; ++parts) {
+            for (int parts = (HT + 7) / 8; parts <= HT && !force_parts; ++parts) {
                 const int per = (HT + parts - 1) / parts, njw = (a.Ks + 1 + parts - 1) / parts;
-                if (per < 4 && parts > (HT + 7) / 8 && !force_parts) break;     // keep >= 4 tile waves per workgroup
+                if (per < 4 && parts > (HT + 7) / 8) break;     // keep >= 4 tile waves per workgroup
                 const int cap = STGCN_ET_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, (per + njw) * 64, lds2));
-                if (force_parts ? parts == force_parts : a.slabs * parts <= cap) best = parts;
-                if (force_parts && parts == force_parts) break;
+                if (a.slabs * parts <= cap) best = parts;
             }
+            if (force_parts > 0 && force_parts <= HT && (HT + force_parts - 1) / force_parts <= 24) best = force_parts;   // (tuning: up to 3 tiles per wave)
             if (best > 0) {
-                const int per = (HT + best - 1) / best, njw = (a.Ks + 1 + best - 1) / best;
+                const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = (a.Ks + 1 + best - 1) / best;
                 a.parts = best;
-                STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), dim3((unsigned)(a.slabs * best)), dim3((per + njw) * 64), lds2, a, per);
+                const dim3 grid2((unsigned)(a.slabs * best)), blk2((nwa + njw) * 64);
+                if (maxq <= 1) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), grid2, blk2, lds2, a, nwa);
+                else if (maxq <= 2) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<2, ET>), grid2, blk2, lds2, a, nwa);
+                else STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<3, ET>), grid2, blk2, lds2, a, nwa);
                 return STGCN_OK;
             }
         }
