@@ -199,6 +199,13 @@ int stgcn_set_gc_precision(int32_t mode);
  * calls.  Returns the previous mode; a mode outside 0..1 only queries.                                                       */
 int stgcn_set_slab_gc_precision(int32_t mode);
 
+/* Matrix products of the BACKWARD kernels of fp32 blocks (dtype STGCN_DTYPE_F32; bf16 blocks are unaffected): 0 = exact fp32 MFMAs
+ * (default), 1 = "bf16x3": every operand is split into two bf16 where it enters the matrix cores and a product is formed from three bf16
+ * MFMAs with fp32 accumulation (~2^-16 relative per product: inside the 1e-3 gradient bar of the fp32 configurations, but not fp32
+ * arithmetic -- an opt-in, reported as such by bench.py; the forward always keeps exact fp32 products).  Returns the previous mode; a mode
+ * outside 0..1 only queries.                                                                                                          */
+int stgcn_set_bwd_precision(int32_t mode);
+
 /* Tuning knob: extra bf16 elements (multiple of 8) between consecutive rows of every 16-bit plane of the tiled graph conv
  * (operator hi / lo planes, activation operand form), so that the rows of a tile do not all start in the same L2 channel
  * when NP is a power of two.  Changes the sizes stgcn_gso_layout / stgcn_stblock_plan_query report: set it before preparing

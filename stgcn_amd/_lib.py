@@ -140,6 +140,8 @@ class _Lib:
         d.stgcn_outblock_backward_loss.argtypes = [C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p, C.POINTER(HeadLoss), C.c_void_p,
                                                    C.c_void_p, C.POINTER(OutblockGrads), C.c_void_p, C.POINTER(LnHook), C.c_void_p]
         d.stgcn_outblock_backward_loss.restype = C.c_int
+        d.stgcn_set_bwd_precision.argtypes = [C.c_int32]
+        d.stgcn_set_bwd_precision.restype = C.c_int
         d.stgcn_set_slab_gc_precision.argtypes = [C.c_int32]
         d.stgcn_set_slab_gc_precision.restype = C.c_int
         d.stgcn_set_tc1_bwd_wgs.argtypes = [C.c_int32]
@@ -228,4 +230,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
                     "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
-                    "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss"]
+                    "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss", "stgcn_set_bwd_precision"]

@@ -94,6 +94,21 @@ inline void launch_log(const char* label, const char* kernel, dim3 grid, dim3 bl
             STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
         }                                                                                         \
     } while (0)
+// the same for BACKWARD kernels: fp32 blocks take ET = f32x (bf16x3 products) when stgcn_set_bwd_precision(1) is in force
+#define STGCN_LAUNCH_ETB(label, st, kernel, grid, block, lds, ...)                                \
+    do {                                                                                          \
+        if (g_bf16) {                                                                             \
+            using ET = bf16;                                                                      \
+            STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
+        } else if (g_bwd_precision == 1) {                                                        \
+            using ET = f32x;                                                                      \
+            STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
+        } else {                                                                                  \
+            using ET = float;                                                                     \
+            STGCN_LAUNCH(label, st, kernel, grid, block, lds, __VA_ARGS__);                       \
+        }                                                                                         \
+    } while (0)
+#define STGCN_ETB_VALUE(expr) (g_bf16 ? [&] { using ET = bf16; return (expr); }() : g_bwd_precision == 1 ? [&] { using ET = f32x; return (expr); }() : [&] { using ET = float; return (expr); }())
 // value of an expression that mentions ET (e.g. wg_capacity of a kernel instantiation)
 #define STGCN_ET_VALUE(expr) (g_bf16 ? [&] { using ET = bf16; return (expr); }() : [&] { using ET = float; return (expr); }())
 // stage-per-launch kernels of round 1 that have no bf16 variant (the bf16 configurations run the fused paths)
@@ -353,6 +368,11 @@ int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {
     constexpr int KC = 4;
     const int TMr = head_tile_rows() / 16;
     const size_t lds = (size_t)(tconv2_lds_floats(aa.f.KCH * 16, 256, 16 * TMr) + 16) * sizeof(float);   // + 16: reduction words of the fused staging
+    if constexpr (PLAIN) {   // the head's transposed conv: a backward kernel
+        if (TMr == 1) STGCN_LAUNCH_ETB(label, st, (tconv_fwd4_kernel<1, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 16)), dim3(512), lds, aa);
+        else STGCN_LAUNCH_ETB(label, st, (tconv_fwd4_kernel<2, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 32)), dim3(512), lds, aa);
+        return STGCN_OK;
+    }
     if (TMr == 1) STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<1, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 16)), dim3(512), lds, aa);
     else STGCN_LAUNCH_ET(label, st, (tconv_fwd4_kernel<2, KC, PLAIN, ET>), dim3(cdiv(aa.f.ts.rows, 32)), dim3(512), lds, aa);
     return STGCN_OK;
@@ -641,7 +661,7 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
             for (int parts = (HT + 7) / 8; parts <= HT && !force_parts; ++parts) {
                 const int per = (HT + parts - 1) / parts, njw = (a.Ks + 1 + parts - 1) / parts;
                 if (per < 4 && parts > (HT + 7) / 8) break;     // keep >= 4 tile waves per workgroup
-                const int cap = STGCN_ET_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, (per + njw) * 64, lds2));
+                const int cap = STGCN_ETB_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, (per + njw) * 64, lds2));
                 if (a.slabs * parts <= cap) best = parts;
             }
             if (force_parts > 0 && force_parts <= HT && (HT + force_parts - 1) / force_parts <= 24) best = force_parts;   // (tuning: up to 3 tiles per wave)
@@ -649,9 +669,9 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
                 const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = (a.Ks + 1 + best - 1) / best;
                 a.parts = best;
                 const dim3 grid2((unsigned)(a.slabs * best)), blk2((nwa + njw) * 64);
-                if (maxq <= 1) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), grid2, blk2, lds2, a, nwa);
-                else if (maxq <= 2) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<2, ET>), grid2, blk2, lds2, a, nwa);
-                else STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd2_kernel<3, ET>), grid2, blk2, lds2, a, nwa);
+                if (maxq <= 1) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), grid2, blk2, lds2, a, nwa);
+                else if (maxq <= 2) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<2, ET>), grid2, blk2, lds2, a, nwa);
+                else STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<3, ET>), grid2, blk2, lds2, a, nwa);
                 return STGCN_OK;
             }
         }
@@ -661,10 +681,10 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     const size_t lds = ((size_t)a.Ks * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
     if (lds > 160 * 1024) return fail(STGCN_ERR_UNSUPPORTED, "graph-conv backward needs %zu bytes of LDS (N=%d, terms=%d)", lds, a.N, a.Ks);
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
-    if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<1, 16, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<2, 8, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<3, 8, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 4) STGCN_LAUNCH_ET("gconv_bwd", st, (gconv_bwd_kernel<4, 8, ET>), grid, blk, lds, a);
+    if (g.maxq <= 1) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd_kernel<1, 16, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd_kernel<2, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd_kernel<3, 8, ET>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd_kernel<4, 8, ET>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }
@@ -672,6 +692,7 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
 template <int MTW>
 int launch_bwd_weight_n(const char* label, const TconvBwdWeightArgs& a, const WgradGeom& w, hipStream_t st) {
     const dim3 grid(w.chunks, w.mchunks), blk(kThreads * kWgradGroups);   // (16-byte im2col loads: c_in % 4 == 0, checked by the caller)
+    // (exact fp32 products in every backward-precision mode: only the paired head launch below takes the bf16x3 form)
     if (a.NC == 128) STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<MTW, 2, true, ET>), grid, blk, wgrad_lds_bytes(MTW, 2), a);
     else STGCN_LAUNCH_ET(label, st, (tconv_bwd_weight_kernel<MTW, 4, true, ET>), grid, blk, wgrad_lds_bytes(MTW, 4), a);
     return STGCN_OK;
@@ -701,7 +722,7 @@ int launch_wgrad_pair(const char* label, const TconvBwdWeightArgs& a1, const Wgr
                       hipStream_t st) {
     const int n1 = w1.chunks * w1.mchunks, n2 = w2.chunks * w2.mchunks;
     const size_t l1 = wgrad_lds_bytes(4, 4), l2 = wgrad_lds_bytes(4, 2);
-    STGCN_LAUNCH_ET(label, st, (wgrad_pair_kernel<4, 4, 4, 2, ET>), dim3((unsigned)(n1 + n2)), dim3(kThreads * kWgradGroups), l1 > l2 ? l1 : l2, a1, n1,
+    STGCN_LAUNCH_ETB(label, st, (wgrad_pair_kernel<4, 4, 4, 2, ET>), dim3((unsigned)(n1 + n2)), dim3(kThreads * kWgradGroups), l1 > l2 ? l1 : l2, a1, n1,
                     w1.mchunks, a2, n2, w2.mchunks);
     return STGCN_OK;
 }
@@ -921,6 +942,12 @@ int stgcn_set_gc_ld_pad(int32_t pad) {
 int stgcn_set_gc_precision(int32_t mode) {
     const int prev = g_gc_precision;
     if (mode >= 0 && mode <= 2) g_gc_precision = mode;
+    return prev;
+}
+
+int stgcn_set_bwd_precision(int32_t mode) {
+    const int prev = g_bwd_precision;
+    if (mode >= 0 && mode <= 1) g_bwd_precision = mode;
     return prev;
 }
 

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -112,6 +113,13 @@ __device__ __forceinline__ f32x4 zero4() {
 // them in 4-byte units) and are re-typed with et_ptr<ET>() at the top of the kernel.
 // ================================================================================================
 struct bf16 { unsigned short v; };
+// float storage, "bf16x3" matrix products: every operand is split x = hi + lo into two bf16 where it enters the matrix cores and a product
+// is formed as hi*hi + hi*lo + lo*hi (three v_mfma_f32_16x16x16_bf16, fp32 accumulation; the dropped lo*lo term and the split residual
+// are ~2^-16 relative to the product).  Three bf16 MFMAs of 17.5 cycles replace four fp32-input MFMAs of 32 cycles
+// (profiles/r3-04_mfma_issue_rate.txt): 2.4 x fewer matrix-pipe cycles.  Used for the BACKWARD kernels of the fp32 configurations only
+// (stgcn_set_bwd_precision): their parity bar is 1e-3 relative on gradients, 50 x above this error; the forward (1e-4 absolute on
+// activations) keeps exact fp32 products.
+struct f32x { float v; };
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -151,6 +159,10 @@ template <typename ET> __device__ __forceinline__ ET* et_ptr(float* p) { return 
 
 // 4 consecutive elements <-> f32x4 (16-byte / 8-byte accesses), one element <-> float
 __device__ __forceinline__ f32x4 ldx4(const float* p) { return ld4(p); }
+__device__ __forceinline__ f32x4 ldx4(const f32x* p) { return ld4(reinterpret_cast<const float*>(p)); }
+__device__ __forceinline__ void stx4(f32x* p, f32x4 v) { st4(reinterpret_cast<float*>(p), v); }
+__device__ __forceinline__ float ldx1(const f32x* p) { return p->v; }
+__device__ __forceinline__ void stx1(f32x* p, float v) { p->v = v; }
 __device__ __forceinline__ f32x4 ldx4(const bf16* p) { return unpack_bf16x4(*reinterpret_cast<const u32x2_t*>(p)); }
 __device__ __forceinline__ void stx4(float* p, f32x4 v) { st4(p, v); }
 __device__ __forceinline__ void stx4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2_t*>(p) = pack_bf16x4(v); }
@@ -160,6 +172,8 @@ __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stx1(bf16* p, float v) { p->v = (unsigned short)bf16_bits_rne(v); }
 // write-through variants (see st4_wt)
 __device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { st4_wt(p, v); }
+__device__ __forceinline__ void stx4_wt(f32x* p, f32x4 v) { st4_wt(reinterpret_cast<float*>(p), v); }
+__device__ __forceinline__ void stx4_wt2(f32x* p, f32x4 v) { st4_wt2(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ void stx4_wt(bf16* p, f32x4 v) {
     const u32x2_t r = pack_bf16x4(v);
 #if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)
@@ -269,7 +283,7 @@ template <> struct Mma<bf16> {
 // sees its 4 MFMAs WM * NT issue slots apart)
 template <typename ET, int WM, int NT>
 __device__ __forceinline__ void mma_tile(f32x4 (&acc)[WM][NT], const f32x4 (&a)[WM], const f32x4 (&b)[NT]) {
-    if constexpr (sizeof(ET) == 4) {
+    if constexpr (std::is_same<ET, float>::value) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -288,6 +302,56 @@ __device__ __forceinline__ void mma_tile(f32x4 (&acc)[WM][NT], const f32x4 (&a)[
             for (int j = 0; j < NT; ++j) acc[i][j] = Mma<ET>::mma(fa[i], fb[j], acc[i][j]);
     }
 }
+template <> struct Mma<f32x> {
+    struct frag { s16x4 h, l; };
+    static __device__ __forceinline__ frag cvt(f32x4 v) {
+        const u32x2_t hp = pack_bf16x4(v);
+        const f32x4 hv = unpack_bf16x4(hp);
+        frag f;
+        f.h = __builtin_bit_cast(s16x4, hp);
+        f.l = __builtin_bit_cast(s16x4, pack_bf16x4(v - hv));
+        return f;
+    }
+    static __device__ __forceinline__ f32x4 mma(const frag& a, const frag& b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.l, b.h, c, 0, 0, 0);   // (small terms first)
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b.l, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b.h, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_b2(const frag& a, const frag& b0, const frag& b1, f32x4& c0, f32x4& c1) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.l, b0.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.l, b1.h, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b0.l, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b1.l, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b0.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b1.h, c1, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_a2(const frag& a0, const frag& a1, const frag& b, f32x4& c0, f32x4& c1) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.l, b.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.l, b.h, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.h, b.l, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.h, b.l, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.h, b.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.h, b.h, c1, 0, 0, 0);
+    }
+    // one product spread over two accumulators: the two small terms in c1, the main term in c0
+    static __device__ __forceinline__ void mma_split(const frag& a, const frag& b, f32x4& c0, f32x4& c1) {
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.l, b.h, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.h, b.l, c1, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_2x(const frag& a0, const frag& b0, f32x4& c0, const frag& a1, const frag& b1, f32x4& c1) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.l, b0.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.l, b1.h, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.h, b0.l, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.h, b1.l, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0.h, b0.h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1.h, b1.h, c1, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_ab2(const frag& a0, const frag& b0, const frag& a1, const frag& b1, f32x4& c) {
+        c = mma(a0, b0, c);
+        c = mma(a1, b1, c);
+    }
+};
 // four scalars gathered into a fragment (strided LDS reads)
 __device__ __forceinline__ f32x4 gather4(const float* p, int stride) {
     f32x4 v;

@@ -8,6 +8,7 @@
 //   partials --[reduce_kernel]--> parameter gradients in the reference's layouts
 #pragma once
 #include <stdlib.h>
+#include <string.h>
 #include "stgcn_device.hip.h"
 #include "stgcn_kernels_fwd.hip.h"
 #include "stgcn_kernels_gctile.hip.h"
@@ -72,6 +73,9 @@ inline int g_gc_tiled_min_n = 513;
 inline int g_gc_precision = 0;
 // operator products of the slab-resident graph conv (N <= 512): 0 exact fp32 MFMAs, 1 bf16x3 (stgcn_kernels_gcslab16.hip.h)
 inline int g_slab_gc_precision = 0;
+// matrix products of the BACKWARD kernels of fp32 blocks: 0 exact fp32 MFMAs (default), 1 "bf16x3" (Mma<f32x>: split operands, three bf16
+// MFMAs per product, ~2^-16 relative -- inside the 1e-3 gradient bar, outside "exact fp32"; stgcn_set_bwd_precision)
+inline int g_bwd_precision = (getenv("STGCN_BWD_PRECISION") && !strcmp(getenv("STGCN_BWD_PRECISION"), "bf16x3")) ? 1 : 0;
 inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
 // Leading dimension (bf16 elements) of every 16-bit plane (operator hi / lo, operand form).  NP itself is a power-of-two
 // multiple of 128 for the sizes that matter (8192 nodes: 16 KiB rows), so the 128 rows of a tile would all start in the same
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rbase = i * 16 + 4 * g;
-            if constexpr (sizeof(ET) == 4) {
+            if constexpr (std::is_same<ET, float>::value) {
 #pragma unroll
                 for (int sx = 0; sx < 4; ++sx) {
                     const int row = rbase + sx;
@@ -1279,7 +1283,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
         // g = 0..3 read rows 4 apart, which the LDC/LDZ = 4 (mod 8) padding spreads over distinct banks
 #pragma unroll 1
         for (int k16 = 0; k16 < SR / 16; ++k16) {
-            if constexpr (sizeof(ET) == 4) {
+            if constexpr (std::is_same<ET, float>::value) {
 #pragma unroll
                 for (int sx = 0; sx < 4; ++sx) {
                     const int row = k16 * 16 + 4 * g + sx;

@@ -168,6 +168,14 @@ def set_slab_gc_precision(mode) -> str:
     return names[int(_lib.lib().dll.stgcn_set_slab_gc_precision(m))]
 
 
+def set_bwd_precision(mode) -> str:
+    """Matrix products of the backward kernels of fp32 blocks: "fp32" (exact, default) or "bf16x3" (split operands, three bf16 MFMAs per
+    product, ~2^-16 relative: inside the 1e-3 gradient bar, an explicit opt-in); returns the previous mode (``stgcn_set_bwd_precision``)."""
+    names = ["fp32", "bf16x3"]
+    m = names.index(mode) if isinstance(mode, str) else int(mode)
+    return names[int(_lib.lib().dll.stgcn_set_bwd_precision(m))]
+
+
 def set_gc_tiled_min_nodes(n: int) -> int:
     """Graphs with at least ``n`` nodes use the tiled graph conv (default 513); returns the previous threshold.  Operators
     (``gso_prepare``) and plans made under one setting must be used under the same setting (test / tuning knob)."""

@@ -140,3 +140,28 @@ def test_graph_replay_bf16_matches_eager():
     assert all(np.isfinite(losses)), losses
     assert min(losses[6:]) < losses[0], losses
     assert all(p.dtype == torch.float32 for p in model.parameters())
+
+
+@pytest.mark.parametrize("blk", [0, 1])
+def test_c2_backward_bf16x3_products_inside_the_gradient_bar(blk):
+    """fp32 blocks with the opt-in "bf16x3" backward products (ops.set_bwd_precision) at the full C2 size: the forward is untouched, every
+    gradient stays inside the 1e-3 bar against the float64 stage oracle."""
+    from stgcn_amd import ops
+    from tests.test_emu_bwdx3 import run
+    _bind()
+    gso = real_gso("metr_la.cheb_sym_norm_lap")
+    c_in, T = ((1, 12), (64, 8))[blk]
+    prev = ops.set_bwd_precision("bf16x3")
+    try:
+        import tests.test_emu_bwdx3 as m
+        orig = m.nonsym_gso
+        m.nonsym_gso = lambda n, seed: gso
+        try:
+            err = run(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, True, dev="cuda:0")
+        finally:
+            m.nonsym_gso = orig
+    finally:
+        ops.set_bwd_precision(prev)
+    assert err.pop("fwd.y") <= 1e-4
+    assert max(err.values()) <= 1e-3, err
+    print("bf16x3 backward errors:", {k: f"{v:.2e}" for k, v in err.items()})
