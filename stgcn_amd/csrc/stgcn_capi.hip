@@ -461,8 +461,9 @@ int launch_gso_gemm(const char* label, const float* M, const float* X, float alp
 struct OperandBuf { float* hi; float* lo; };
 inline OperandBuf operand_buf(float* XT, int which, long CP, int NP) {
     const size_t LD = (size_t)gc_plane_ld(NP);
-    float* base = XT + (size_t)which * CP * LD;   // CP * LD bf16 per plane = CP * LD / 2 floats, two planes per buffer
-    return OperandBuf{base, base + (size_t)CP * LD / 2};
+    const size_t rows = (size_t)(CP + 384);        // gc_operand_alloc: slack rows behind CP for the wide column tiles
+    float* base = XT + (size_t)which * rows * LD;   // rows * LD bf16 per plane = rows * LD / 2 floats, two planes per buffer
+    return OperandBuf{base, base + rows * LD / 2};
 }
 int launch_pack_operand(const float* X, int N, int NP, long slabs, OperandBuf o, hipStream_t st) {
     STGCN_LAUNCH_ET("gc_pack_operand", st, (gc_pack_operand_kernel<ET>), dim3((unsigned)cdiv(NP, 256), (unsigned)slabs), dim3(256), 256 * 17 * sizeof(float),
@@ -487,6 +488,37 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     static const int force_bk = getenv("STGCN_GEMM_BF16_BK") ? atoi(getenv("STGCN_GEMM_BF16_BK")) : 0;
     const int bk = force_bk == 32 || force_bk == 64 ? force_bk : kGbDefaultBK;
     const int split = g_gc_precision == 1 && !g_bf16;   // (bf16 activations: operands are bf16 numbers already, one MFMA per product)
+    {   // 256 x (32 * NT) tiles, one workgroup per CU (gso_gemm_bf16_big_kernel); STGCN_GEMM_BIG=0: the 128 x 128 kernel
+        static const int off = getenv("STGCN_GEMM_BIG") ? atoi(getenv("STGCN_GEMM_BIG")) == 0 : 0;
+        static const int force_nt = getenv("STGCN_GEMM_BIG_NT") ? atoi(getenv("STGCN_GEMM_BIG_NT")) : 0;
+        if (!off && !split && NP % kGbBigBM == 0) {
+            const long CP = gc_operand_cols(slabs);
+            const int rts = NP / kGbBigBM, cus = device_cus();
+            int best = 0;
+            double best_cost = 0;
+            const int cand[5] = {10, 8, 6, 5, 4};
+            for (int i = 0; i < 5; ++i) {   // cost ~ rounds of resident workgroups x columns per tile; ties go to the wider tile
+                const int nt = cand[i];
+                const long tiles = (long)rts * cdiv(CP, 32 * nt);
+                const double cost = (double)rounds_of(tiles, cus) * nt;
+                if (force_nt ? nt == force_nt : (!best || cost < best_cost)) { best = nt; best_cost = cost; }
+            }
+            if (best) {
+                g.row_tiles = rts;
+                g.col_tiles = cdiv(CP, 32 * best);
+                const dim3 gridb((unsigned)(g.row_tiles * g.col_tiles));
+                const size_t ldsb = gb_big_lds_bytes(best);
+                switch (best) {
+                    case 10: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<10, ET>), gridb, dim3(512), ldsb, g); break;
+                    case 8: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<8, ET>), gridb, dim3(512), ldsb, g); break;
+                    case 6: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<6, ET>), gridb, dim3(512), ldsb, g); break;
+                    case 5: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<5, ET>), gridb, dim3(512), ldsb, g); break;
+                    default: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<4, ET>), gridb, dim3(512), ldsb, g); break;
+                }
+                return STGCN_OK;
+            }
+        }
+    }
     const size_t lds = gb_lds_floats(split, bk) * sizeof(float);
     if (split && bk == 64) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 64, float>), grid, dim3(256), lds, g);
     else if (split) STGCN_LAUNCH(label, st, (gso_gemm_bf16_kernel<1, 32, float>), grid, dim3(256), lds, g);
@@ -908,7 +940,7 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->ws_dZ1 = take(act(v.rows1 * v.NC1));
     p->tiled_gc = v.tiled;
     p->ws_Gk = take(v.tiled ? (int64_t)v.terms * act(v.rows1 * d->c1) : 0);
-    p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_cols(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
+    p->ws_XT = take(v.tiled && v.terms > 1 ? 2 * gc_operand_alloc(v.slabs1) * (int64_t)gc_plane_ld(v.NP) : 0);
     p->part_floats = bwd_partial_floats(d->B, d->T, d->N, d->c_in, d->c0, d->c1, d->c2, d->Kt, v.terms, d->need_dx);
     p->ws_part = take(p->part_floats);
     p->ws_floats = o;

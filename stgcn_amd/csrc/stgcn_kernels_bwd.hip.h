@@ -77,6 +77,8 @@ inline int g_slab_gc_precision = 0;
 // MFMAs per product, ~2^-16 relative -- inside the 1e-3 gradient bar, outside "exact fp32"; stgcn_set_bwd_precision)
 inline int g_bwd_precision = (getenv("STGCN_BWD_PRECISION") && !strcmp(getenv("STGCN_BWD_PRECISION"), "bf16x3")) ? 1 : 0;
 inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
+// rows ALLOCATED per operand plane: the wide column tiles of gso_gemm_bf16_big_kernel (up to 320 columns) may run past CP
+inline long gc_operand_alloc(long slabs) { return gc_operand_cols(slabs) + 384; }
 // Leading dimension (bf16 elements) of every 16-bit plane (operator hi / lo, operand form).  NP itself is a power-of-two
 // multiple of 128 for the sizes that matter (8192 nodes: 16 KiB rows), so the 128 rows of a tile would all start in the same
 // L2 channel; the pad (stgcn_set_gc_ld_pad, multiple of 8 elements) staggers them.

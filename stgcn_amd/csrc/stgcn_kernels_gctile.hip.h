@@ -527,4 +527,177 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
     }
 }
 
+
+// ================================================================================================
+// bf16 operator product on 256 x (32 * NT) workgroup tiles (round 3; the 128 x 128 kernel above moves 4 MB of operand panels per
+// workgroup through L2 for 128 x 128 x K outputs and reads each LDS byte for 32 FLOP: PMC r56 put it at 2.7 GB of L2 -> fabric reads
+// per launch against 0.18 GB of unique operands, with the LDS array as busy as the matrix pipes).
+//   * 8 waves = 4 (rows) x 2 (columns); a wave owns 64 rows x 16 * NT columns = 4 x NT accumulator tiles: per 32-deep step it reads
+//     4 + NT fragments (16 B per lane each) for 4 * NT MFMAs -- NT = 10: 40 MFMAs of 17.5 cycles per 14 KB of LDS reads, i.e. the LDS
+//     array is busy 62 % of the matrix time instead of ~100 %;
+//   * ONE workgroup per CU and a grid of (N / 256) x (columns / (32 * NT)) tiles that is a whole number of rounds: the host picks NT so
+//     that the C5 launches are exactly 256 tiles (2560 columns: NT = 10, 1536 columns: NT = 6) -- no tail round;
+//   * tiles are handed out row-major through xcd_item: the 32 workgroups of an XCD hold 4 row panels x all column panels, so every
+//     operator row panel is fetched into that XCD's L2 once per launch and every column panel 8 times in total (once per XCD):
+//     (134 + 8 x 42) MB = 0.47 GB of fabric reads at the C5 size;
+//   * staging as above: direct global -> LDS copies (global_load_lds_dwordx4), XOR-swizzled unpadded image, double buffered.
+// SPLIT-free (one MFMA per product): bf16 activations, or fp32 activations with stgcn_set_gc_precision("bf16").
+// Requires NP % 256 == 0; the operand form is allocated gc_operand_slack rows beyond CP so that the last column tile may read (and write
+// zeros) past the 128-row granularity of CP.
+// ================================================================================================
+constexpr int kGbBigBM = 256;
+constexpr int kGbBigStages = 4;   // pipeline buffers: the copies of step kb + 3 are issued while step kb computes
+inline size_t gb_big_lds_bytes(int nt) { return (size_t)kGbBigStages * (kGbBigBM + 32 * nt) * 16 * sizeof(float); }
+// wait until at most N of this wave's vector-memory operations (here: global -> LDS copies) are outstanding, WITHOUT draining the rest
+// (__syncthreads() waits for vmcnt(0): with one workgroup per CU that puts a whole HBM round trip into every pipeline step)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N >= 0 && N <= 15, "vmcnt immediates used by the pipelined GEMM");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// workgroup barrier that does not wait for outstanding memory operations of the calling wave (the emulator's copies are synchronous)
+__device__ __forceinline__ void barrier_only() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
+template <int NT, typename ET>
+__global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a) {
+    extern __shared__ float stgcn_smem[];
+    constexpr int BK = 32, LD = BK / 2, BM = kGbBigBM, BN = 32 * NT;
+    constexpr int PA = BM * LD, BUF = PA + BN * LD;   // floats: A plane, whole pipeline buffer
+    constexpr int RPI = 16;                           // rows one wave instruction of the global -> LDS copy fills (4 chunks of 16 B per row)
+    constexpr int NIA = BM / RPI, NI = NIA + BN / RPI;
+    constexpr int CNT = (NI + 7) / 8;                 // copy instructions per wave and stage (the same for every wave: slots past NI repeat the last block)
+    constexpr int ST = kGbBigStages, D = ST - 1;      // prefetch distance in pipeline steps
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wm = w & 3, wn = w >> 2;
+    const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
+    const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
+    const int n0 = rt * BM, c0 = ct * BN, N = a.N, NPH = a.LD >> 1;   // NPH: floats per 16-bit row
+    const int srow = lane >> 2, spos = lane & 3;      // this lane's slot inside a block of 16 rows
+    const int sch = (spos ^ gb_swz<BK>(srow)) << 2;   // (block starts are multiples of 16: gb_swz(row) == gb_swz(srow))
+    auto issue = [&](int kb, int buf) {
+        const int k0h = kb * (BK / 2);   // float units
+        float* base = stgcn_smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {   // (wave-uniform)
+            const int i = w + 8 * j < NI ? w + 8 * j : NI - 1;   // (a repeated block is copied twice: same bytes to the same place)
+            if (i < NIA) glds16(a.Mh + (size_t)(n0 + i * RPI + srow) * NPH + k0h + sch, base + i * RPI * LD);
+            else glds16(a.Xh + (size_t)(c0 + (i - NIA) * RPI + srow) * NPH + k0h + sch, base + PA + (i - NIA) * RPI * LD);
+        }
+    };
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero4();
+
+    const int nkb = (N + BK - 1) / BK;   // k >= N: zero operator columns, zero operand padding
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nkb) issue(s, s);
+    if (nkb >= D) wait_vmcnt_le<(D - 1) * CNT>(); else wait_vmcnt_le<0>();   // stage 0 has landed (this wave's copies; the barrier covers the others')
+    barrier_only();
+    const int co = (g ^ gb_swz<BK>(l15)) << 2;   // swizzled position of this lane group's 8 k values in a staged row
+    auto step = [&](int kb, auto issue_tag) __attribute__((always_inline)) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        const int buf = kb % ST;
+        const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * LD + co;
+        const float* Bs = stgcn_smem + buf * BUF + PA + (wn * 16 * NT + l15) * LD + co;
+        // fragment reads in two groups so that the second group's LDS reads are in flight during the first group's MFMAs (all the reads
+        // first and one lgkmcnt(0) in front of 4 * NT MFMAs left the LDS array and the matrix pipes taking turns: 2.7 k cycles per step
+        // for 1.4 k cycles of MFMAs)
+        constexpr int NH = (NT + 1) / 2;
+        bf16x8 ah[4], bh[NT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * LD));
+#pragma unroll
+        for (int t = 0; t < NH; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
+        __builtin_amdgcn_sched_barrier(0);
+        // first half of the columns; the reads of the second half are issued between its MFMAs (one LDS read per four MFMAs)
+#pragma unroll
+        for (int t = NH; t < NT; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
+#pragma unroll
+        for (int nt = 0; nt < NH; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int t = NH; t < NT; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // second half of the columns, with the global -> LDS copies of step kb + D issued between its MFMAs (a copy instruction issued
+        // among bare MFMAs costs ~60 cycles of issue, 100 - 185 in front of the LDS reads: MI355X_MICROARCH.md).  The destination buffer
+        // was last read in step kb - 1: every wave has passed that step's closing barrier.
+        if constexpr (ISSUE) issue(kb + D, (kb + D) % ST);
+#pragma unroll
+        for (int nt = NH; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        if constexpr (ISSUE) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (4 * (NT - NH)) / CNT, 1);   // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);                        // one global -> LDS copy
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // stage kb + 1 must have landed before the next step reads it: while D stages are in flight behind it, allow (D - 1) of them to
+        // stay outstanding; in the tail (nothing issued this step) drain
+        if constexpr (ISSUE) wait_vmcnt_le<(D - 1) * CNT>(); else wait_vmcnt_le<0>();
+        barrier_only();   // all waves done reading `buf`, and every wave's share of stage kb + 1 has landed
+    };
+    int kb = 0;
+    for (; kb + D < nkb; ++kb) step(kb, std::true_type());    // steady state: one stage issued per step
+    for (; kb < nkb; ++kb) step(kb, std::false_type());       // tail: nothing left to issue, drain
+    // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*16*NT + nt*16 + l15]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = c0 + wn * 16 * NT + nt * 16 + l15;
+        const long slab = col >> 4;
+        const int ch = col & 15;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int nb = n0 + wm * 64 + mt * 16 + 4 * g;
+            f32x4 v = zero4();
+            if (slab < a.slabs) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r < N) {
+                        const size_t o = ((size_t)slab * N + nb + r) * 16 + ch;
+                        float t = a.alpha * acc[mt][nt][r];
+                        if (a.Z1) t += a.b1 * ldx1(et_ptr<ET>(a.Z1) + o);
+                        if (a.Z2) t += a.b2 * ldx1(et_ptr<ET>(a.Z2) + o);
+                        stx1(et_ptr<ET>(a.out) + o, t);
+                        v[r] = t;
+                    }
+                }
+            }
+            if (a.Oh) {   // operand form of the result (zeros in the node / column padding)
+                u32x2 hi, lo;
+                bf16_split4(v, hi, lo);
+                const size_t o = ((size_t)col * a.LD + nb) >> 1;
+                *reinterpret_cast<u32x2*>(a.Oh + o) = hi;
+                *reinterpret_cast<u32x2*>(a.Ol + o) = lo;
+            }
+        }
+    }
+}
+
 }  // namespace stgcn
