@@ -491,6 +491,7 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     {   // 256 x (32 * NT) tiles, one workgroup per CU (gso_gemm_bf16_big_kernel); STGCN_GEMM_BIG=0: the 128 x 128 kernel
         static const int off = getenv("STGCN_GEMM_BIG") ? atoi(getenv("STGCN_GEMM_BIG")) == 0 : 0;
         static const int force_nt = getenv("STGCN_GEMM_BIG_NT") ? atoi(getenv("STGCN_GEMM_BIG_NT")) : 0;
+        static const int big_bk = getenv("STGCN_GEMM_BIG_BK") && atoi(getenv("STGCN_GEMM_BIG_BK")) == 32 ? 32 : 64;   // r3-17: 64-deep steps 6 % faster
         if (!off && !split && NP % kGbBigBM == 0) {
             const long CP = gc_operand_cols(slabs);
             const int rts = NP / kGbBigBM, cus = device_cus();
@@ -506,15 +507,23 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
             if (best) {
                 g.row_tiles = rts;
                 g.col_tiles = cdiv(CP, 32 * best);
+                g.Ol = nullptr;   // (no split product reads the low plane of the result)
                 const dim3 gridb((unsigned)(g.row_tiles * g.col_tiles));
-                const size_t ldsb = gb_big_lds_bytes(best);
+                const size_t ldsb = gb_big_lds_bytes(best, big_bk);
+#define STGCN_BIG_CASE(NTV) \
+    case NTV: \
+        if (big_bk == 64) STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<NTV, ET, 64>), gridb, dim3(512), ldsb, g); \
+        else STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<NTV, ET, 32>), gridb, dim3(512), ldsb, g); \
+        break;
                 switch (best) {
-                    case 10: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<10, ET>), gridb, dim3(512), ldsb, g); break;
-                    case 8: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<8, ET>), gridb, dim3(512), ldsb, g); break;
-                    case 6: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<6, ET>), gridb, dim3(512), ldsb, g); break;
-                    case 5: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<5, ET>), gridb, dim3(512), ldsb, g); break;
-                    default: STGCN_LAUNCH_ET(label, st, (gso_gemm_bf16_big_kernel<4, ET>), gridb, dim3(512), ldsb, g); break;
+                    STGCN_BIG_CASE(10)
+                    STGCN_BIG_CASE(8)
+                    STGCN_BIG_CASE(6)
+                    STGCN_BIG_CASE(5)
+                    default:
+                    STGCN_BIG_CASE(4)
                 }
+#undef STGCN_BIG_CASE
                 return STGCN_OK;
             }
         }

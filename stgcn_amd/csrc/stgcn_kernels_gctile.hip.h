@@ -546,8 +546,14 @@ __global__ __launch_bounds__(256) void gso_gemm_bf16_kernel(GsoGemmBfArgs a) {
 // zeros) past the 128-row granularity of CP.
 // ================================================================================================
 constexpr int kGbBigBM = 256;
-constexpr int kGbBigStages = 4;   // pipeline buffers: the copies of step kb + 3 are issued while step kb computes
-inline size_t gb_big_lds_bytes(int nt) { return (size_t)kGbBigStages * (kGbBigBM + 32 * nt) * 16 * sizeof(float); }
+#ifndef STGCN_GEMM_DBG
+#define STGCN_GEMM_DBG 0   // timing experiments only (wrong results): 3 = no MFMAs (the copy + fragment-read stream alone)
+#endif
+// pipeline buffers: 32-deep steps: 4 (the copies of step kb + 3 are issued while step kb computes); 64-deep steps: 2 (whole 128-B lines per
+// staged row, the copies of step kb + 1 are issued at the start of step kb)
+constexpr int kGbEpiLd = 20;   // row stride (floats) of a wave's 64 x 16 transposition tile in the epilogue of the big kernel
+constexpr int gb_big_stages(int bk) { return bk == 64 ? 2 : 4; }
+inline size_t gb_big_lds_bytes(int nt, int bk) { return (size_t)gb_big_stages(bk) * (kGbBigBM + 32 * nt) * (bk / 2) * sizeof(float); }
 // wait until at most N of this wave's vector-memory operations (here: global -> LDS copies) are outstanding, WITHOUT draining the rest
 // (__syncthreads() waits for vmcnt(0): with one workgroup per CU that puts a whole HBM round trip into every pipeline step)
 template <int N>
@@ -575,28 +581,39 @@ __device__ __forceinline__ void barrier_only() {
 #endif
 }
 
-template <int NT, typename ET>
+// orders LDS accesses between the lanes of ONE wave: a wave's LDS instructions execute in order, so the hardware needs nothing; the compiler
+// must not move LDS accesses across this point (and the emulator lets the wave's other lanes catch up here)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NT, typename ET, int BK>
 __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a) {
     extern __shared__ float stgcn_smem[];
-    constexpr int BK = 32, LD = BK / 2, BM = kGbBigBM, BN = 32 * NT;
+    constexpr int LD = BK / 2, BM = kGbBigBM, BN = 32 * NT, KS = BK / 32;
     constexpr int PA = BM * LD, BUF = PA + BN * LD;   // floats: A plane, whole pipeline buffer
-    constexpr int RPI = 16;                           // rows one wave instruction of the global -> LDS copy fills (4 chunks of 16 B per row)
+    constexpr int CPR = BK / 8, RPI = 64 / CPR;       // 16-B chunks per staged row; rows one wave instruction of the global -> LDS copy fills
     constexpr int NIA = BM / RPI, NI = NIA + BN / RPI;
     constexpr int CNT = (NI + 7) / 8;                 // copy instructions per wave and stage (the same for every wave: slots past NI repeat the last block)
-    constexpr int ST = kGbBigStages, D = ST - 1;      // prefetch distance in pipeline steps
+    constexpr int ST = gb_big_stages(BK), D = ST - 1; // prefetch distance in pipeline steps
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wm = w & 3, wn = w >> 2;
     const int item = xcd_item((int)blockIdx.x, a.row_tiles * a.col_tiles);
     const int rt = item / a.col_tiles, ct = item - rt * a.col_tiles;
     const int n0 = rt * BM, c0 = ct * BN, N = a.N, NPH = a.LD >> 1;   // NPH: floats per 16-bit row
-    const int srow = lane >> 2, spos = lane & 3;      // this lane's slot inside a block of 16 rows
-    const int sch = (spos ^ gb_swz<BK>(srow)) << 2;   // (block starts are multiples of 16: gb_swz(row) == gb_swz(srow))
-    auto issue = [&](int kb, int buf) {
+    const int srow = lane / CPR, spos = lane % CPR;   // this lane's slot inside a block of RPI rows
+    // swizzled source chunk of the slot: blocks start at multiples of RPI rows; gb_swz<32> has period 16 = RPI, gb_swz<64> period 16 = 2 RPI
+    // (the second variant serves the odd blocks)
+    const int sch0 = (spos ^ gb_swz<BK>(srow)) << 2, sch1 = (spos ^ gb_swz<BK>(srow + RPI)) << 2;
+    auto issue = [&](int kb, int buf, int j0, int j1) __attribute__((always_inline)) {   // copy instructions j0 .. j1 - 1 of stage kb
         const int k0h = kb * (BK / 2);   // float units
         float* base = stgcn_smem + buf * BUF;
 #pragma unroll
-        for (int j = 0; j < CNT; ++j) {   // (wave-uniform)
+        for (int j = j0; j < j1; ++j) {   // (wave-uniform)
             const int i = w + 8 * j < NI ? w + 8 * j : NI - 1;   // (a repeated block is copied twice: same bytes to the same place)
+            const int sch = (i & 1) ? sch1 : sch0;                // (NIA is even: the parity of a block within its plane is the parity of i)
             if (i < NIA) glds16(a.Mh + (size_t)(n0 + i * RPI + srow) * NPH + k0h + sch, base + i * RPI * LD);
             else glds16(a.Xh + (size_t)(c0 + (i - NIA) * RPI + srow) * NPH + k0h + sch, base + PA + (i - NIA) * RPI * LD);
         }
@@ -610,54 +627,87 @@ __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a)
     const int nkb = (N + BK - 1) / BK;   // k >= N: zero operator columns, zero operand padding
 #pragma unroll
     for (int s = 0; s < D; ++s)
-        if (s < nkb) issue(s, s);
+        if (s < nkb) issue(s, s, 0, CNT);
     if (nkb >= D) wait_vmcnt_le<(D - 1) * CNT>(); else wait_vmcnt_le<0>();   // stage 0 has landed (this wave's copies; the barrier covers the others')
     barrier_only();
-    const int co = (g ^ gb_swz<BK>(l15)) << 2;   // swizzled position of this lane group's 8 k values in a staged row
+    const int sw = gb_swz<BK>(l15);   // (tile rows start at multiples of 16: gb_swz(row) == gb_swz(l15))
+    // The copy instructions of a stage are spread over the MFMA groups of the step (a burst of them fills the vector-memory queue and the
+    // issuing wave's MFMAs wait behind it).  32-deep steps: both groups (the stage is needed two steps later); 64-deep steps: the first three
+    // of the four groups (the stage is read right after this step's closing barrier: the last group is its landing time).
+    constexpr int CG = BK == 64 ? 3 : 2, CQ = (CNT + CG - 1) / CG;
     auto step = [&](int kb, auto issue_tag) __attribute__((always_inline)) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr bool MM = STGCN_GEMM_DBG != 3;
+        constexpr int NH = (NT + 1) / 2, R = NT - NH;
         const int buf = kb % ST;
-        const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * LD + co;
-        const float* Bs = stgcn_smem + buf * BUF + PA + (wn * 16 * NT + l15) * LD + co;
-        // fragment reads in two groups so that the second group's LDS reads are in flight during the first group's MFMAs (all the reads
-        // first and one lgkmcnt(0) in front of 4 * NT MFMAs left the LDS array and the matrix pipes taking turns: 2.7 k cycles per step
-        // for 1.4 k cycles of MFMAs)
-        constexpr int NH = (NT + 1) / 2;
-        bf16x8 ah[4], bh[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * LD));
+        for (int ks = 0; ks < KS; ++ks) {
+            const int co = ((ks * 4 + g) ^ sw) << 2;   // swizzled position of this lane group's 8 k values in a staged row
+            const float* As = stgcn_smem + buf * BUF + (wm * 64 + l15) * LD + co;
+            const float* Bs = stgcn_smem + buf * BUF + PA + (wn * 16 * NT + l15) * LD + co;
+            // fragment reads in two groups so that the second group's LDS reads are in flight during the first group's MFMAs (all the
+            // reads first and one lgkmcnt(0) in front of 4 * NT MFMAs left the LDS array and the matrix pipes taking turns)
+            bf16x8 ah[4], bh[NT];
 #pragma unroll
-        for (int t = 0; t < NH; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
-        __builtin_amdgcn_sched_barrier(0);
-        // first half of the columns; the reads of the second half are issued between its MFMAs (one LDS read per four MFMAs)
+            for (int t = 0; t < 4; ++t) ah[t] = __builtin_bit_cast(bf16x8, ld4(As + t * 16 * LD));
 #pragma unroll
-        for (int t = NH; t < NT; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
+            for (int t = 0; t < NH; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
+            __builtin_amdgcn_sched_barrier(0);
+            // first half of the columns; between its MFMAs the reads of the second half and this group's share of the copies of step
+            // kb + D (their buffer was last read in step kb - 1: every wave has passed that step's closing barrier)
+            constexpr int G0 = 0;
+            const int ga = 2 * ks, gb = 2 * ks + 1;   // the two MFMA groups of this slice
+            const int ca0 = ga * CQ < CNT ? ga * CQ : CNT, ca1 = (ga + 1) * CQ < CNT ? (ga + 1) * CQ : CNT;
+            const int cb0 = gb * CQ < CNT ? gb * CQ : CNT, cb1 = (gb + 1) * CQ < CNT ? (gb + 1) * CQ : CNT;
+            const int na = ISSUE && ga < CG ? ca1 - ca0 : 0, nb = ISSUE && gb < CG ? cb1 - cb0 : 0;
 #pragma unroll
-        for (int nt = 0; nt < NH; ++nt)
+            for (int t = NH; t < NT; ++t) bh[t] = __builtin_bit_cast(bf16x8, ld4(Bs + t * 16 * LD));
+            if (na > 0) issue(kb + D, (kb + D) % ST, ca0, ca1);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NH; ++nt)
 #pragma unroll
-        for (int t = NH; t < NT; ++t) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 LDS read
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // second half of the columns, with the global -> LDS copies of step kb + D issued between its MFMAs (a copy instruction issued
-        // among bare MFMAs costs ~60 cycles of issue, 100 - 185 in front of the LDS reads: MI355X_MICROARCH.md).  The destination buffer
-        // was last read in step kb - 1: every wave has passed that step's closing barrier.
-        if constexpr (ISSUE) issue(kb + D, (kb + D) % ST);
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (MM) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    else asm volatile("" ::"v"(ah[mt]), "v"(bh[nt]));
+                }
 #pragma unroll
-        for (int nt = NH; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        if constexpr (ISSUE) {
-#pragma unroll
-            for (int j = 0; j < CNT; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, (4 * (NT - NH)) / CNT, 1);   // MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);                        // one global -> LDS copy
+            for (int t = 0; t < R; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, G0);   // 4 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, G0);   // 1 LDS read
             }
+            {   // (a second pipeline over the same MFMAs: mixed in one pipeline the solver clumped the reads and the copies)
+                constexpr int MPA = (4 * NH) / CQ > 0 ? (4 * NH) / CQ : 1;
+#pragma unroll
+                for (int j = 0; j < CQ; ++j) {
+                    if (j < na) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MPA, 2);   // MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);     // one global -> LDS copy
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // second half of the columns with its share of the copies (a copy instruction issued among bare MFMAs costs ~60 cycles of
+            // issue, 100 - 185 in front of the LDS reads: MI355X_MICROARCH.md)
+            if (nb > 0) issue(kb + D, (kb + D) % ST, cb0, cb1);
+#pragma unroll
+            for (int nt = NH; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (MM) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    else asm volatile("" ::"v"(ah[mt]), "v"(bh[nt]));
+                }
+            {
+                constexpr int MPC = (4 * R) / CQ > 0 ? (4 * R) / CQ : 1;
+#pragma unroll
+                for (int j = 0; j < CQ; ++j) {
+                    if (j < nb) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MPC, 1);   // MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);     // one global -> LDS copy
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         // stage kb + 1 must have landed before the next step reads it: while D stages are in flight behind it, allow (D - 1) of them to
         // stay outstanding; in the tail (nothing issued this step) drain
         if constexpr (ISSUE) wait_vmcnt_le<(D - 1) * CNT>(); else wait_vmcnt_le<0>();
@@ -666,37 +716,67 @@ __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a)
     int kb = 0;
     for (; kb + D < nkb; ++kb) step(kb, std::true_type());    // steady state: one stage issued per step
     for (; kb < nkb; ++kb) step(kb, std::false_type());       // tail: nothing left to issue, drain
-    // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*16*NT + nt*16 + l15]
+    if (STGCN_GEMM_DBG == 8) {   // timing experiment: no epilogue (one store keeps the accumulators alive)
+        f32x4 v = zero4();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) v += acc[mt][nt];
+        if (v[0] + v[1] + v[2] + v[3] == 12345.678f) stx1(et_ptr<ET>(a.out), v[0]);
+        return;
+    }
+    // acc[mt][nt][r] = (M X)[node n0 + wm*64 + mt*16 + 4g + r][column c0 + wn*16*NT + nt*16 + l15]: a lane holds ONE channel of 4 nodes,
+    // the slab layout [slab][node][16] wants 4 channels of one node per lane.  Written straight from the fragments (160 2-byte stores per
+    // lane, 320 2-byte loads of the addends) the epilogue took 66 us of a 283 us launch and 137 us with two addends (r3-19): the 64 x 16
+    // piece of every column group goes through a wave-private LDS tile (the pipeline buffers are free: every wave has passed the last
+    // step's barrier) and leaves as 8 / 16-byte accesses, 16 nodes x 32 / 64 B contiguous per wave instruction.
+    float* T = stgcn_smem + w * (64 * kGbEpiLd);
+    const int pn = lane >> 2, pc = (lane & 3) * 4;   // transposed slot: node 16 i + pn, channels pc .. pc + 3
+    const bool addends = a.Z1 || a.Z2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int col = c0 + wn * 16 * NT + nt * 16 + l15;
-        const long slab = col >> 4;
-        const int ch = col & 15;
+        const int colb = c0 + wn * 16 * NT + nt * 16;   // (wave-uniform: one slab per column group)
+        const long slab = colb >> 4;
+        const bool live = slab < a.slabs;
+        if (live) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int nb = n0 + wm * 64 + mt * 16 + 4 * g;
-            f32x4 v = zero4();
-            if (slab < a.slabs) {
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (nb + r < N) {
-                        const size_t o = ((size_t)slab * N + nb + r) * 16 + ch;
-                        float t = a.alpha * acc[mt][nt][r];
-                        if (a.Z1) t += a.b1 * ldx1(et_ptr<ET>(a.Z1) + o);
-                        if (a.Z2) t += a.b2 * ldx1(et_ptr<ET>(a.Z2) + o);
-                        stx1(et_ptr<ET>(a.out) + o, t);
-                        v[r] = t;
-                    }
+                for (int r = 0; r < 4; ++r) T[(mt * 16 + 4 * g + r) * kGbEpiLd + l15] = a.alpha * acc[mt][nt][r];
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int node = n0 + wm * 64 + 16 * i + pn;
+                float* tp = T + (16 * i + pn) * kGbEpiLd + pc;
+                f32x4 t = ld4(tp);
+                if (node < N) {
+                    const size_t o = ((size_t)slab * N + node) * 16 + pc;
+                    if (a.Z1) t += a.b1 * ldx4(et_ptr<ET>(a.Z1) + o);
+                    if (a.Z2) t += a.b2 * ldx4(et_ptr<ET>(a.Z2) + o);
+                    stx4(et_ptr<ET>(a.out) + o, t);
                 }
+                if (addends && a.Oh) st4(tp, t);   // the operand form below needs the sums in the fragment layout
             }
-            if (a.Oh) {   // operand form of the result (zeros in the node / column padding)
+            wave_lds_sync();
+        }
+        if (a.Oh) {   // operand form of the result (zeros in the node / column padding); the low plane only where a split product reads it
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int nb = n0 + wm * 64 + mt * 16 + 4 * g;
+                f32x4 v = zero4();
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < N) v[r] = addends ? T[(mt * 16 + 4 * g + r) * kGbEpiLd + l15] : a.alpha * acc[mt][nt][r];
+                }
                 u32x2 hi, lo;
                 bf16_split4(v, hi, lo);
-                const size_t o = ((size_t)col * a.LD + nb) >> 1;
+                const size_t o = ((size_t)(colb + l15) * a.LD + nb) >> 1;
                 *reinterpret_cast<u32x2*>(a.Oh + o) = hi;
-                *reinterpret_cast<u32x2*>(a.Ol + o) = lo;
+                if (a.Ol) *reinterpret_cast<u32x2*>(a.Ol + o) = lo;
             }
         }
+        wave_lds_sync();   // (the next column group overwrites the tile)
     }
 }
 

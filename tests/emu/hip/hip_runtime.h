@@ -207,6 +207,8 @@ static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned s
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::wave_barrier()   // (the point where the lanes of a wave meet: LDS exchange inside a wave)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 
 template <typename T>

@@ -1,0 +1,17 @@
+#!/bin/bash
+# pass r3-15: what bounds the big GEMM?  timing-only builds (STGCN_GEMM_DBG: 1 no copies, 2 no fragment reads, 3 no MFMAs, 4 MFMAs only) + SQ / TCC counters
+OUT=$1
+cd $GRAFT_REPO_ROOT
+for V in 0 1 2 3 4; do
+  if [ $V = 0 ]; then E=""; else E="STGCN_AMD_LIB=$GRAFT_REPO_ROOT/stgcn_amd/_dbg/libstgcn_dbg$V.so"; fi
+  env $E timeout 600 python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-gpu-baseline > $OUT/bench_c5_dbg$V.json 2> $OUT/bench_c5_dbg$V.err; echo "c5 dbg$V exit $?"
+  python -c "
+import json; d=json.load(open('$OUT/bench_c5_dbg$V.json')); r=d['roofline']; pk=r['per_kernel_us_per_step']
+print('dbg$V', d['ms_per_step'], {k:v for k,v in pk.items() if 'gso' in k})"
+done
+( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d /tmp/pmc_c5_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --no-gpu-baseline --no-profile --no-graph > $OUT/pmc_c5_sq.log 2>&1; echo "pmc sq exit $?" )
+python tools/rocpd_pmc_summary.py /tmp/pmc_c5_sq/pmc_results.db > $OUT/pmc_c5_sq.md 2>&1
+grep -E "gso_gemm|kernel" $OUT/pmc_c5_sq.md | head -6 | cut -c1-260
+( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d /tmp/pmc_c5_tcc -o pmc -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --no-gpu-baseline --no-profile --no-graph > $OUT/pmc_c5_tcc.log 2>&1; echo "pmc tcc exit $?" )
+python tools/rocpd_pmc_summary.py /tmp/pmc_c5_tcc/pmc_results.db > $OUT/pmc_c5_tcc.md 2>&1
+grep -E "gso_gemm|kernel" $OUT/pmc_c5_tcc.md | head -6 | cut -c1-260
