@@ -166,6 +166,23 @@ __device__ __forceinline__ void stx1(f32x* p, float v) { p->v = v; }
 __device__ __forceinline__ f32x4 ldx4(const bf16* p) { return unpack_bf16x4(*reinterpret_cast<const u32x2_t*>(p)); }
 __device__ __forceinline__ void stx4(float* p, f32x4 v) { st4(p, v); }
 __device__ __forceinline__ void stx4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2_t*>(p) = pack_bf16x4(v); }
+// 8 consecutive elements (16 B of bf16: one dwordx4 access; 32 B of fp32: two)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ldx8(const float* p, f32x4& a, f32x4& b) { a = ld4(p); b = ld4(p + 4); }
+__device__ __forceinline__ void stx8(float* p, f32x4 a, f32x4 b) { st4(p, a); st4(p + 4, b); }
+__device__ __forceinline__ void ldx8(const bf16* p, f32x4& a, f32x4& b) {
+    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
+    u32x2_t lo, hi;
+    lo[0] = r[0]; lo[1] = r[1]; hi[0] = r[2]; hi[1] = r[3];
+    a = unpack_bf16x4(lo);
+    b = unpack_bf16x4(hi);
+}
+__device__ __forceinline__ void stx8(bf16* p, f32x4 a, f32x4 b) {
+    const u32x2_t lo = pack_bf16x4(a), hi = pack_bf16x4(b);
+    u32x4_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = hi[0]; r[3] = hi[1];
+    *reinterpret_cast<u32x4_t*>(p) = r;
+}
 __device__ __forceinline__ float ldx1(const float* p) { return *p; }
 __device__ __forceinline__ float ldx1(const bf16* p) { return __builtin_bit_cast(float, (unsigned)p->v << 16); }
 __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }

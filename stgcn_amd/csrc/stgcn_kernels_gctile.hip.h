@@ -731,34 +731,53 @@ __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a)
     // piece of every column group goes through a wave-private LDS tile (the pipeline buffers are free: every wave has passed the last
     // step's barrier) and leaves as 8 / 16-byte accesses, 16 nodes x 32 / 64 B contiguous per wave instruction.
     float* T = stgcn_smem + w * (64 * kGbEpiLd);
-    const int pn = lane >> 2, pc = (lane & 3) * 4;   // transposed slot: node 16 i + pn, channels pc .. pc + 3
+    const int pn = lane >> 1, pc = (lane & 1) * 8;   // transposed slot: node 32 i + pn, channels pc .. pc + 7
     const bool addends = a.Z1 || a.Z2;
+    // one column group through the tile; H1 / H2: addends present (wave-uniform, resolved once per kernel: the loads of a group are issued
+    // together and nothing in the loop branches on them)
+    auto slab_pass = [&](int nt, long slab, auto h1, auto h2) __attribute__((always_inline)) {
+        constexpr bool H1 = decltype(h1)::value, H2 = decltype(h2)::value;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(mt * 16 + 4 * g + r) * kGbEpiLd + l15] = a.alpha * acc[mt][nt][r];
+        wave_lds_sync();
+        f32x4 t[2][2], z1[2][2], z2[2][2];
+        size_t o[2];
+        bool ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int node = n0 + wm * 64 + 32 * i + pn;
+            ok[i] = node < N;
+            o[i] = ((size_t)slab * N + (ok[i] ? node : N - 1)) * 16 + pc;   // (clamped: the loads below are unconditional)
+            if (H1) ldx8(et_ptr<ET>(a.Z1) + o[i], z1[i][0], z1[i][1]);
+            if (H2) ldx8(et_ptr<ET>(a.Z2) + o[i], z2[i][0], z2[i][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* tp = T + (32 * i + pn) * kGbEpiLd + pc;
+            t[i][0] = ld4(tp);
+            t[i][1] = ld4(tp + 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (H1) t[i][h] += a.b1 * z1[i][h];
+                if (H2) t[i][h] += a.b2 * z2[i][h];
+            }
+            if (ok[i]) stx8(et_ptr<ET>(a.out) + o[i], t[i][0], t[i][1]);
+            if ((H1 || H2) && a.Oh) {   // the operand form below needs the sums in the fragment layout
+                st4(tp, t[i][0]);
+                st4(tp + 4, t[i][1]);
+            }
+        }
+        wave_lds_sync();
+    };
+    auto epilogue = [&](auto h1, auto h2) __attribute__((always_inline)) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int colb = c0 + wn * 16 * NT + nt * 16;   // (wave-uniform: one slab per column group)
         const long slab = colb >> 4;
         const bool live = slab < a.slabs;
-        if (live) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[(mt * 16 + 4 * g + r) * kGbEpiLd + l15] = a.alpha * acc[mt][nt][r];
-            wave_lds_sync();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int node = n0 + wm * 64 + 16 * i + pn;
-                float* tp = T + (16 * i + pn) * kGbEpiLd + pc;
-                f32x4 t = ld4(tp);
-                if (node < N) {
-                    const size_t o = ((size_t)slab * N + node) * 16 + pc;
-                    if (a.Z1) t += a.b1 * ldx4(et_ptr<ET>(a.Z1) + o);
-                    if (a.Z2) t += a.b2 * ldx4(et_ptr<ET>(a.Z2) + o);
-                    stx4(et_ptr<ET>(a.out) + o, t);
-                }
-                if (addends && a.Oh) st4(tp, t);   // the operand form below needs the sums in the fragment layout
-            }
-            wave_lds_sync();
-        }
+        if (live) slab_pass(nt, slab, h1, h2);
         if (a.Oh) {   // operand form of the result (zeros in the node / column padding); the low plane only where a split product reads it
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -778,6 +797,11 @@ __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a)
         }
         wave_lds_sync();   // (the next column group overwrites the tile)
     }
+    };
+    if (a.Z1 && a.Z2) epilogue(std::true_type(), std::true_type());
+    else if (a.Z1) epilogue(std::true_type(), std::false_type());
+    else if (a.Z2) epilogue(std::false_type(), std::true_type());
+    else epilogue(std::false_type(), std::false_type());
 }
 
 }  // namespace stgcn

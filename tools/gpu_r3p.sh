@@ -1,5 +1,5 @@
 #!/bin/bash
-# pass r3-20: big GEMM with the LDS-transposed epilogue (default 64-deep steps); tiled / bf16 GPU tests + C5 bench + trace
+# pass r3-20 (r3-22: slab pass with batched 16-byte accesses): big GEMM with the LDS-transposed epilogue (default 64-deep steps); tiled / bf16 GPU tests + C5 bench + trace
 OUT=$GRAFT_REPO_ROOT/$1
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_gctile.py tests/test_gpu_bf16.py -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
