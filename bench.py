@@ -49,7 +49,9 @@ CONFIGS = {
                workload="C5: synthetic dense 8192-node graph, STGCNChebGraphConv Ks=5 Kt=3, n_his=12, bs=16, {dtype} activations, tiled graph conv, "
                         "dropout 0.5, AdamW; full step"),
 }
-PMC_TRAFFIC_FILE = "r3-06_pmc_traffic.json"          # (named explicitly: it has to be re-measured whenever a kernel's traffic changes)
+# (named explicitly: they have to be re-measured whenever a kernel's traffic changes; keyed by (config, dtype))
+PMC_TRAFFIC_FILES = {("c2", "f32"): "r3-06_pmc_traffic.json", ("c3", "bf16"): "r3-23_pmc_traffic_c3_bf16.json",
+                     ("c5", "bf16"): "r3-23_pmc_traffic_c5_bf16.json"}
 B_OVERRIDE = os.environ.get("STGCN_BENCH_B")       # (env: batch-size sweeps of tools/, not the headline)
 
 
@@ -196,16 +198,18 @@ def gpu_baseline(model, gso_t, cfg, B, N, dev):
             "kind": "same parameters and step through stock PyTorch-ROCm ops (MIOpen / rocBLAS / ATen), eager, same GPU"}
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch from the committed PMC summary of the current kernels (profiles/PMC_TRAFFIC_FILE, written by tools/pmc_traffic.py
+def pmc_traffic(config, dtype):
+    """HBM-side bytes per launch from the committed PMC summary of the current kernels (profiles/PMC_TRAFFIC_FILES[...], written by tools/pmc_traffic.py
     from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command: counters cannot be sampled from inside
     the process being timed).  Returns ({label: bytes}, file name) or ({}, None)."""
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+    name = PMC_TRAFFIC_FILES.get((config, dtype))
+    if name is None:
+        return {}, None
     try:
-        rec = json.load(open(path))["per_launch"]
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))["per_launch"]
     except (OSError, ValueError, KeyError):
         return {}, None
-    return {k: int(v["hbm_bytes"]) for k, v in rec.items()}, PMC_TRAFFIC_FILE
+    return {k: int(v["hbm_bytes"]) for k, v in rec.items()}, name
 
 
 def main():
@@ -413,9 +417,9 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if bf_mm else PEAK_FP32_MFMA_TFLOPS
         ach = flops[dom] / (dur_ms * 1e-3) / 1e12
         tot_ms = sum(v for k, v in per_step.items() if not k.startswith(("head.", "adamw")))
-        traffic, traffic_src = pmc_traffic()
-        if args.config != "c2" or DTYPE != "f32":
-            traffic, traffic_src = {}, None
+        traffic, traffic_src = pmc_traffic(args.config, DTYPE)
+        if args.gc_precision != "fp32" or args.bwd_precision != "fp32":
+            traffic, traffic_src = {}, None   # (the committed counters are those of the default modes)
         st_labels = [k for k in per_step if not k.startswith(("head.", "adamw", "prepack", "mse", "reduce"))]
         st_traffic = sum(traffic.get(k, 0) * prof[k]["calls"] / ksteps for k in st_labels) if traffic else None
         nbytes = stblock_bytes_by_label(B_LOCAL, N, KS, 2 if DTYPE == "bf16" else 4) if N <= 512 else {}

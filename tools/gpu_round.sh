@@ -31,7 +31,7 @@ trace)
     head -60 $OUT/kernel_stats_graph.md | cut -c1-150 ;;
 pmc)
     for C in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && export TMPDIR=/tmp && STGCN_LAUNCH_LOG=$OUT/launch_$C.log timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_${TAG}_$C -o pmc -- python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-profile --no-graph > $OUT/pmc_$C.log 2>&1; echo "pmc $C exit $?" )
+        ( cd /tmp && export TMPDIR=/tmp && STGCN_LAUNCH_LOG=$OUT/launch_$C.log timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_${TAG}_$C -o pmc -- python $REPO/bench.py --steps ${PMC_STEPS:-6} --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-profile --no-graph ${BENCH_ARGS:-} > $OUT/pmc_$C.log 2>&1; echo "pmc $C exit $?" )
         python tools/rocpd_pmc_summary.py /tmp/pmc_${TAG}_$C/pmc_results.db > $OUT/pmc_$C.md 2>&1
     done
     python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE/pmc_results.db /tmp/pmc_${TAG}_WRITE_SIZE/pmc_results.db $OUT/launch_FETCH_SIZE.log $OUT/launch_WRITE_SIZE.log > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err
