@@ -657,10 +657,20 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
         return STGCN_OK;
     }
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
-    if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<1, 16, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<3, 8, ET>), grid, blk, lds, a);
-    else if (g.maxq <= 4) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<4, 8, ET>), grid, blk, lds, a);
+    // STGCN_GC_SP=2 (opt-in): two slabs per workgroup, every operator fragment a wave loads feeds both.  Measured equal at C2 and 3 % slower at
+    // C3 (r3-26 / r3-27): the product loop was bound by the latency of its own fragment loads, not by their volume
+    static const int force_sp = getenv("STGCN_GC_SP") ? atoi(getenv("STGCN_GC_SP")) : 0;
+    const bool sp2 = a.Ks > 1 && g.maxq <= 2 && force_sp == 2;
+    if (sp2) {
+        const dim3 grid2((unsigned)(cdiv(a.slabs, 2) * g.parts));
+        if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<1, 16, ET, 2>), grid2, blk, 2 * lds, a);
+        else STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET, 2>), grid2, blk, 2 * lds, a);
+        return STGCN_OK;
+    }
+    if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<1, 16, ET, 1>), grid, blk, lds, a);
+    else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET, 1>), grid, blk, lds, a);
+    else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<3, 8, ET, 1>), grid, blk, lds, a);
+    else if (g.maxq <= 4) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<4, 8, ET, 1>), grid, blk, lds, a);
     else return fail(STGCN_ERR_UNSUPPORTED, "graph convolution with %d nodes (supported: up to 512)", a.N);
     return STGCN_OK;
 }

@@ -57,6 +57,11 @@ namespace stgcn {
 
 constexpr int kThreads = 256;   // 4 waves per workgroup, one per SIMD
 constexpr int kTileRows = 64;   // rows of a flat row tile (4 MFMA m-tiles)
+#ifndef STGCN_GC_RING1
+#define STGCN_GC_RING1 2   // r3-28: 2 / 3 / 4 chunks -> C2 gconv_bwd@0 24.8 / 27.0 / 30.5 us (registers: 7 / 6 / 5 waves per SIMD), forward equal
+#endif
+// operator-fragment chunks a wave of the slab-resident graph-conv kernels keeps in flight, by node tiles per wave (register budget)
+constexpr int gc_ring(int maxq) { return maxq <= 1 ? STGCN_GC_RING1 : 2; }
 constexpr int kSegMax = 128;    // K columns staged in LDS per segment
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

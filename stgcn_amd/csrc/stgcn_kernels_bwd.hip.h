@@ -542,6 +542,70 @@ struct GconvBwdArgs {
     int wgs;             // BwdGeom::gc_count
 };
 
+// Operator products of the slab-resident backward for one pair of terms: acc1[q] += T_k0^T x G_k0, acc2[q] += T_{k0+1}^T x G_{k0+1} on
+// the NQ node tiles of this wave (fragment offsets fo[q]), K = the KCH node chunks.  Same loop discipline as gconv_fwd_kernel: a ring of RG
+// fragment chunks in registers with static indices, no branch in the body (TWO, NQ compile-time), the refill of a slot right behind the
+// MFMAs that read it -- the p <- n <- load rotation this replaces waited for every load it had just issued.
+template <typename MM, int MAXQ, int NQ, bool TWO, int RG>
+__device__ __forceinline__ void gc_bwd_products(const float* T1, const float* T2, const float* G1, const float* G2, int LDX, int KCH, int wave, int WAVES,
+                                                int lane, f32x4 (&acc1)[MAXQ], f32x4 (&acc2)[MAXQ]) {
+    const int g = lane >> 4, l15 = lane & 15;
+    f32x4 r1[RG][NQ], r2[RG][NQ];
+    int fo[NQ];   // (floats; < 2^31: at most 7 terms of 512 x 512)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        fo[q] = ((wave + WAVES * q) * KCH * 64 + lane) * 4;
+#pragma unroll
+        for (int d = 0; d < RG; ++d) {
+            const int dc = d < KCH ? d : KCH - 1;
+            r1[d][q] = ld4(T1 + fo[q] + 256 * dc);
+            if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * dc);
+        }
+    }
+    auto chunk = [&](int kc, int d, auto load_tag) __attribute__((always_inline)) {
+        const typename MM::frag af1 = MM::cvt(ld4(G1 + l15 * LDX + kc * 16 + 4 * g));
+        const typename MM::frag af2 = MM::cvt(TWO ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4());
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (TWO) MM::mma_2x(af1, MM::cvt(r1[d][q]), acc1[q], af2, MM::cvt(r2[d][q]), acc2[q]);
+            else acc1[q] = MM::mma(af1, MM::cvt(r1[d][q]), acc1[q]);
+            if (decltype(load_tag)::value) {
+                r1[d][q] = ld4(T1 + fo[q] + 256 * (kc + RG));
+                if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * (kc + RG));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kc0 = 0;
+    for (; kc0 + 2 * RG <= KCH; kc0 += RG) {
+#pragma unroll
+        for (int d = 0; d < RG; ++d) chunk(kc0 + d, d, std::true_type());
+    }
+    for (; kc0 < KCH; kc0 += RG) {
+#pragma unroll
+        for (int d = 0; d < RG; ++d) {
+            if (kc0 + d < KCH) {
+                if (kc0 + d + RG < KCH) chunk(kc0 + d, d, std::true_type());
+                else chunk(kc0 + d, d, std::false_type());
+            }
+        }
+    }
+}
+template <typename MM, int MAXQ, int RG>
+__device__ __forceinline__ void gc_bwd_products_nq(int nq, bool two, const float* T1, const float* T2, const float* G1, const float* G2, int LDX, int KCH,
+                                                   int wave, int WAVES, int lane, f32x4 (&acc1)[MAXQ], f32x4 (&acc2)[MAXQ]) {
+#define STGCN_GCB(NQV) \
+    if (nq == NQV) { \
+        if (two) gc_bwd_products<MM, MAXQ, NQV, true, RG>(T1, T2, G1, G2, LDX, KCH, wave, WAVES, lane, acc1, acc2); \
+        else gc_bwd_products<MM, MAXQ, NQV, false, RG>(T1, T2, G1, G2, LDX, KCH, wave, WAVES, lane, acc1, acc2); \
+    }
+    STGCN_GCB(1)
+    if constexpr (MAXQ >= 2) { STGCN_GCB(2) }
+    if constexpr (MAXQ >= 3) { STGCN_GCB(3) }
+    if constexpr (MAXQ >= 4) { STGCN_GCB(4) }
+#undef STGCN_GCB
+}
+
 template <int MAXQ, int MAXW, typename ET>   // wave count = blockDim.x / 64 <= MAXW (see gconv_fwd_kernel)
 __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
     typedef Mma<ET> MM;
@@ -549,7 +613,7 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
     const int THREADS = blockDim.x, NW = THREADS >> 6, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int P = a.parts, prt = (int)(blockIdx.x % (unsigned)P);
     const long slab = blockIdx.x / (unsigned)P;
-    const int wave = prt + P * w, WAVES = P * NW;   // owned node tiles: wave + WAVES * q
+    const int wave = prt + P * __builtin_amdgcn_readfirstlane(w), WAVES = P * NW;   // owned node tiles: wave + WAVES * q (scalar: uniform branches)
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, LDY = 20, Ks = a.Ks;
     float* const GT0 = stgcn_smem;                 // GT(k) = GT0 + k*16*LDX, transposed [c][node]
     float* const dYs = stgcn_smem + Ks * 16 * LDX; // [NP][LDY] row major
@@ -607,46 +671,13 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
         acc1[q] = zero4();
         acc2[q] = zero4();
     }
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) nq += wave + WAVES * q < HT ? 1 : 0;
     for (int k0 = 1; k0 < Ks; k0 += 2) {
-        const bool two = k0 + 1 < Ks;
         const float* T1 = a.LTp + (size_t)(k0 - 1) * MSZ;
-        const float* T2 = T1 + MSZ;
         const float* G1 = GT0 + k0 * 16 * LDX;
-        const float* G2 = G1 + 16 * LDX;
-        f32x4 p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // operator fragments one (p) and two (n) chunks ahead
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
-            const bool in = ht < HT;
-            p1[q] = in ? ld4(T1 + o) : zero4();
-            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
-            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
-            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
-        }
-        for (int kc = 0; kc < KCH; ++kc) {
-            const typename MM::frag af1 = MM::cvt(ld4(G1 + l15 * LDX + kc * 16 + 4 * g));
-            const typename MM::frag af2 = MM::cvt(two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4());
-            f32x4 b1[MAXQ], b2[MAXQ];
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                b1[q] = p1[q]; b2[q] = p2[q];
-                p1[q] = n1[q]; p2[q] = n2[q];
-                const int ht = wave + WAVES * q;
-                if (kc + 2 < KCH && ht < HT) {
-                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
-                    n1[q] = ld4(T1 + o);
-                    if (two) n2[q] = ld4(T2 + o);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                if (wave + WAVES * q < HT) {
-                    if (two) MM::mma_2x(af1, MM::cvt(b1[q]), acc1[q], af2, MM::cvt(b2[q]), acc2[q]);
-                    else acc1[q] = MM::mma(af1, MM::cvt(b1[q]), acc1[q]);
-                }
-            }
-        }
+        gc_bwd_products_nq<MM, MAXQ, (MAXQ == 2 ? 4 : gc_ring(MAXQ))>(nq, k0 + 1 < Ks, T1, T1 + MSZ, G1, G1 + 16 * LDX, LDX, KCH, wave, WAVES, lane, acc1, acc2);
     }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
@@ -726,7 +757,7 @@ __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa
     }
 
     // =============================================== tile waves ==============================================================
-    const int wave = prt + P * w, WAVES = P * nwa;   // owned node tiles: wave + WAVES * q
+    const int wave = prt + P * __builtin_amdgcn_readfirstlane(w), WAVES = P * nwa;   // owned node tiles: wave + WAVES * q (scalar: uniform branches)
     // G_k = dY W_k^T, k >= 1, on ALL node tiles (the K dimension of the products below)
     for (int k = 1; k < Ks; ++k) {
         const typename MM::frag wf = MM::cvt(ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g));   // B[kk = j][col = i] = W_k[i = l15][j = 4g + s]
@@ -754,46 +785,13 @@ __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa
         acc1[q] = zero4();
         acc2[q] = zero4();
     }
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) nq += wave + WAVES * q < HT ? 1 : 0;
     for (int k0 = 1; k0 < Ks; k0 += 2) {
-        const bool two = k0 + 1 < Ks;
         const float* T1 = a.LTp + (size_t)(k0 - 1) * MSZ;
-        const float* T2 = T1 + MSZ;
         const float* G1 = GTk + (k0 - 1) * 16 * LDX;
-        const float* G2 = G1 + 16 * LDX;
-        f32x4 p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // operator fragments one (p) and two (n) chunks ahead
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int ht = wave + WAVES * q;
-            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
-            const bool in = ht < HT;
-            p1[q] = in ? ld4(T1 + o) : zero4();
-            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
-            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
-            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
-        }
-        for (int kc = 0; kc < KCH; ++kc) {
-            const typename MM::frag af1 = MM::cvt(ld4(G1 + l15 * LDX + kc * 16 + 4 * g));
-            const typename MM::frag af2 = MM::cvt(two ? ld4(G2 + l15 * LDX + kc * 16 + 4 * g) : zero4());
-            f32x4 b1[MAXQ], b2[MAXQ];
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                b1[q] = p1[q]; b2[q] = p2[q];
-                p1[q] = n1[q]; p2[q] = n2[q];
-                const int ht = wave + WAVES * q;
-                if (kc + 2 < KCH && ht < HT) {
-                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
-                    n1[q] = ld4(T1 + o);
-                    if (two) n2[q] = ld4(T2 + o);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                if (wave + WAVES * q < HT) {
-                    if (two) MM::mma_2x(af1, MM::cvt(b1[q]), acc1[q], af2, MM::cvt(b2[q]), acc2[q]);
-                    else acc1[q] = MM::mma(af1, MM::cvt(b1[q]), acc1[q]);
-                }
-            }
-        }
+        gc_bwd_products_nq<MM, MAXQ, (MAXQ == 1 ? gc_ring(1) : MAXQ == 2 ? 2 : 1)>(nq, k0 + 1 < Ks, T1, T1 + MSZ, G1, G1 + 16 * LDX, LDX, KCH, wave, WAVES, lane, acc1, acc2);
     }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {

@@ -839,13 +839,17 @@ struct LnRowstatOut {
     const uint64_t* offset_dev;
 };
 // contribution of 4 consecutive channels (c .. c+3) of row (slab, node): returns (sum g, sum g*xhat) of those 4
+// position of the hooked LayerNorm's dropout stream for this launch, read ONCE per kernel: dereferencing offset_dev where the mask is formed
+// put a dependent scalar load (and an s_waitcnt vmcnt(0) behind whatever had just been requested) into every row group / time step
+__device__ __forceinline__ uint64_t ln_rowstat_offset(const LnRowstatOut& o) {
+    return (o.rowstat && o.training) ? o.offset + (o.offset_dev ? *o.offset_dev : 0) : 0;
+}
 template <typename ET = float>
-__device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, f32x4 dy, long slab, int node, int c) {
+__device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, uint64_t off, f32x4 dy, long slab, int node, int c) {
     const size_t e = ((size_t)slab * o.N + node) * o.C + c;
     const f32x4 ga = ld4(o.gamma + (size_t)node * o.C + c);
     f32x4 k = {1.f, 1.f, 1.f, 1.f};
     if (o.training) {
-        const uint64_t off = o.offset + (o.offset_dev ? *o.offset_dev : 0);
         k = dropout_scale4((uint64_t)slab * (((uint64_t)o.N * o.C) >> 2) + (((uint64_t)node * o.C + c) >> 2), o.seed, off, o.thresh, o.keep_scale);
     }
     float s1 = 0.f, s2 = 0.f;
@@ -1045,6 +1049,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
         const int q = tid & (Q4 - 1);
         const int tap = (4 * q) / aa.outC, ci = 4 * q - tap * aa.outC;
         const RowCoord c0 = row_coord(a.ts, row0 < a.ts.rows ? row0 : 0);
+        const uint64_t hoff = ln_rowstat_offset(aa.rs);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = (tid + it * THREADS) / Q4;
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
             if (rin) stx4_wt(out_ + (((size_t)c.b * aa.outT + tap) * a.ts.N + c.n) * aa.outC + ci, v);
             if (aa.rs.rowstat) {   // uniform; the outC / 4 lanes holding one output row are consecutive and aligned
                 const long slab = (long)c.b * aa.outT + tap;
-                float2 p = rin ? ln_rowstat4<ET>(aa.rs, v, slab, c.n, ci) : make_float2(0.f, 0.f);
+                float2 p = rin ? ln_rowstat4<ET>(aa.rs, hoff, v, slab, c.n, ci) : make_float2(0.f, 0.f);
                 for (int m = aa.outC >> 3; m >= 1; m >>= 1) {
                     p.x += __shfl_xor(p.x, m);
                     p.y += __shfl_xor(p.y, m);
@@ -1126,39 +1131,49 @@ struct GconvFwdArgs {
     float* XT;           // tiled path only: two bf16 operand-form buffers (plan: ws_XT), used when g_gc_precision > 0
 };
 
-template <int MAXQ, int MAXW, typename ET>
+// SP = (b, t) slabs per workgroup (2: every operator fragment a wave loads multiplies the X chunks of two slabs; opt-in, STGCN_GC_SP=2:
+// measured equal / slower, the loop was never bound by the volume of that stream).
+template <int MAXQ, int MAXW, typename ET, int SP>
 __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int THREADS = blockDim.x, tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int P = a.parts, part = (int)(blockIdx.x % (unsigned)P);
-    const long slab = blockIdx.x / (unsigned)P;
+    const long slab0 = (long)(blockIdx.x / (unsigned)P) * SP;   // slabs slab0 .. slab0 + SP - 1 (the last group may be short)
     // node tile of (wave w, slot q) = part + P * (w + nwaves * q) = wave + WAVES * q with the two names below
-    const int wave = part + P * (tid >> 6), WAVES = P * (THREADS >> 6);
+    const int wave = part + P * __builtin_amdgcn_readfirstlane(tid >> 6), WAVES = P * (THREADS >> 6);   // (scalar: the tile tests below are branches, not exec masks)
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
     const size_t MSZ = (size_t)NP * NP;
-    float* const XT0 = stgcn_smem;   // X0 transposed: [16][LDX]
+    float* const XT0 = stgcn_smem;   // X0 transposed: [SP][16][LDX]
 
     STGCN_PHASE(4, 0);
-    const ET* Asl = et_ptr<ET>(a.A) + (size_t)slab * N * 16;
     ET* const Xk_ = et_ptr<ET>(a.Xk);
     ET* const G_ = et_ptr<ET>(a.G);
-    for (int idx = tid; idx < NP * 4; idx += THREADS) {
-        const int n = idx >> 2, c4 = idx & 3;
-        const f32x4 v = n < N ? ldx4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+    bool live[SP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) XT0[(c4 * 4 + i) * LDX + n] = v[i];
+    for (int j = 0; j < SP; ++j) {
+        live[j] = slab0 + j < a.slabs;
+        const ET* Asl = et_ptr<ET>(a.A) + (size_t)(live[j] ? slab0 + j : slab0) * N * 16;
+        for (int idx = tid; idx < NP * 4; idx += THREADS) {
+            const int n = idx >> 2, c4 = idx & 3;
+            const f32x4 v = n < N ? ldx4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) XT0[(j * 16 + c4 * 4 + i) * LDX + n] = v[i];
+        }
     }
     __syncthreads();
     STGCN_PHASE(4, 1);
 
-    f32x4 yacc[MAXQ], res[MAXQ];
+    f32x4 yacc[MAXQ][SP], res[MAXQ][SP];
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-        yacc[q] = zero4();
         const int ht = wave + WAVES * q;
-        // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
-        res[q] = ht < HT ? ld4(XT0 + l15 * LDX + ht * 16 + 4 * g) : zero4();
+#pragma unroll
+        for (int j = 0; j < SP; ++j) {
+            yacc[q][j] = zero4();
+            // residual X0[h = ht*16 + 4g + r][j = l15]  (D layout of the weight contraction)
+            res[q][j] = ht < HT ? ld4(XT0 + (j * 16 + l15) * LDX + ht * 16 + 4 * g) : zero4();
+        }
     }
     // weight fragment B[kk = c][col = j] = W_k[c = 4g + s][j = l15]
     auto wfrag = [&](int k) {
@@ -1177,66 +1192,103 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
             const int ht = wave + WAVES * q;
             if (ht < HT) {
                 const int h = ht * 16 + l15;
-                yacc[q] = MM::mma(MM::cvt(gather4(XT0 + (4 * g) * LDX + h, LDX)), wf, yacc[q]);
+#pragma unroll
+                for (int j = 0; j < SP; ++j) yacc[q][j] = MM::mma(MM::cvt(gather4(XT0 + (j * 16 + 4 * g) * LDX + h, LDX)), wf, yacc[q][j]);
             }
         }
     }
-    // terms k0, k0+1 together: acc1 = X0^T-tile products with T_k0, acc2 with T_{k0+1}
-    for (int k0 = 1; k0 < a.Ks; k0 += 2) {
-        const bool two = k0 + 1 < a.Ks;
+    // terms k0, k0+1 together: acc1 = X0^T-tile products with T_k0, acc2 with T_{k0+1}.
+    // Operator fragments: a ring of RG chunks in registers with STATIC indices, and a loop body without branches.  The former
+    // p <- n <- load rotation went through register moves behind an s_waitcnt vmcnt(0), and the tile / term tests inside the loop were
+    // branches at which the compiler's wait-count bookkeeping starts over: either way every iteration waited for the load it had just
+    // issued (2.5 k cycles per chunk for 256 cycles of MFMAs; r3-25: 15 of the 23 us of the C2 block-0 launch).  Hence TWO (both terms of
+    // the pair exist) and NQ (tiles this wave owns: slots q < NQ) are compile-time constants of the body, chosen once per wave.
+    int nq = 0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) nq += wave + WAVES * q < HT ? 1 : 0;
+    auto term_pair = [&](int k0, auto two_tag, auto nq_tag) __attribute__((always_inline)) {
+        constexpr bool TWO = decltype(two_tag)::value;
+        constexpr int NQ = decltype(nq_tag)::value;
+        constexpr int RG = MAXQ == 2 ? 4 : gc_ring(MAXQ);
         const float* T1 = a.Lp + (size_t)(k0 - 1) * MSZ;
         const float* T2 = T1 + MSZ;
-        const typename MM::frag wf1 = MM::cvt(wfrag(k0)), wf2 = MM::cvt(two ? wfrag(k0 + 1) : zero4());
+        const typename MM::frag wf1 = MM::cvt(wfrag(k0)), wf2 = MM::cvt(TWO ? wfrag(k0 + 1) : zero4());
         STGCN_PHASE(4, 2 * k0);
-        f32x4 acc1[MAXQ], acc2[MAXQ], p1[MAXQ], p2[MAXQ], n1[MAXQ], n2[MAXQ];   // fragments one (p) and two (n) chunks ahead
+        f32x4 acc1[NQ][SP], acc2[NQ][SP], r1[RG][NQ], r2[RG][NQ];
+        int fo[NQ];      // this lane's float offset into the fragments of tile q, chunk 0 (< 2^31: at most 7 terms of 512 x 512)
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            acc1[q] = zero4();
-            acc2[q] = zero4();
-            const int ht = wave + WAVES * q;
-            const size_t o = ((size_t)ht * KCH * 64 + lane) * 4;
-            const bool in = ht < HT;
-            p1[q] = in ? ld4(T1 + o) : zero4();
-            p2[q] = (in && two) ? ld4(T2 + o) : zero4();
-            n1[q] = (in && KCH > 1) ? ld4(T1 + o + 256) : zero4();
-            n2[q] = (in && two && KCH > 1) ? ld4(T2 + o + 256) : zero4();
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+                acc1[q][j] = zero4();
+                acc2[q][j] = zero4();
+            }
+            fo[q] = ((wave + WAVES * q) * KCH * 64 + lane) * 4;
+#pragma unroll
+            for (int d = 0; d < RG; ++d) {
+                const int dc = d < KCH ? d : KCH - 1;   // (graphs of fewer than RG chunks: a valid address, never used)
+                r1[d][q] = ld4(T1 + fo[q] + 256 * dc);
+                if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * dc);
+            }
         }
-        for (int kc = 0; kc < KCH; ++kc) {
-            const typename MM::frag af = MM::cvt(ld4(XT0 + l15 * LDX + kc * 16 + 4 * g));   // A[c = l15][node = kc*16 + 4g + s]
-            f32x4 b1[MAXQ], b2[MAXQ];
+        auto chunk = [&](int kc, int d, auto load_tag) __attribute__((always_inline)) {   // d = kc % RG, as a constant after unrolling
+            typename MM::frag af[SP];
 #pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                b1[q] = p1[q]; b2[q] = p2[q];
-                p1[q] = n1[q]; p2[q] = n2[q];
-                const int ht = wave + WAVES * q;
-                if (kc + 2 < KCH && ht < HT) {
-                    const size_t o = ((size_t)(ht * KCH + kc + 2) * 64 + lane) * 4;
-                    n1[q] = ld4(T1 + o);
-                    if (two) n2[q] = ld4(T2 + o);
+            for (int j = 0; j < SP; ++j) af[j] = MM::cvt(ld4(XT0 + (j * 16 + l15) * LDX + kc * 16 + 4 * g));   // A[c = l15][node = kc*16 + 4g + s]
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const typename MM::frag bf1 = MM::cvt(r1[d][q]), bf2 = MM::cvt(TWO ? r2[d][q] : zero4());
+#pragma unroll
+                for (int j = 0; j < SP; ++j) {
+                    if (TWO) MM::mma_b2(af[j], bf1, bf2, acc1[q][j], acc2[q][j]);
+                    else acc1[q][j] = MM::mma(af[j], bf1, acc1[q][j]);
+                }
+                if (decltype(load_tag)::value) {   // this slot's next occupant
+                    r1[d][q] = ld4(T1 + fo[q] + 256 * (kc + RG));
+                    if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * (kc + RG));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the refills of all RG slots to the end of the unrolled body)
+        };
+        int kc0 = 0;
+        for (; kc0 + 2 * RG <= KCH; kc0 += RG) {   // steady state: RG chunks, each refills its slot
 #pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                if (wave + WAVES * q < HT) {
-                    if (two) MM::mma_b2(af, MM::cvt(b1[q]), MM::cvt(b2[q]), acc1[q], acc2[q]);
-                    else acc1[q] = MM::mma(af, MM::cvt(b1[q]), acc1[q]);
+            for (int d = 0; d < RG; ++d) chunk(kc0 + d, d, std::true_type());
+        }
+        for (; kc0 < KCH; kc0 += RG) {             // last chunks: refill only while there is something left to fetch
+#pragma unroll
+            for (int d = 0; d < RG; ++d) {
+                if (kc0 + d < KCH) {
+                    if (kc0 + d + RG < KCH) chunk(kc0 + d, d, std::true_type());
+                    else chunk(kc0 + d, d, std::false_type());
                 }
             }
         }
         STGCN_PHASE(4, 2 * k0 + 1);
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int ht = wave + WAVES * q;
-            if (ht < HT) {
-                const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
-                if (a.Xk && h < N) {
-                    stx4_wt(Xk_ + (((size_t)(k0 - 1) * a.slabs + slab) * N + h) * 16 + 4 * g, acc1[q]);
-                    if (two) stx4_wt(Xk_ + (((size_t)k0 * a.slabs + slab) * N + h) * 16 + 4 * g, acc2[q]);
+            const int h = ht * 16 + l15;   // acc[r] = X_k[h][c = 4g + r]
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+                if (a.Xk && h < N && live[j]) {
+                    stx4_wt(Xk_ + (((size_t)(k0 - 1) * a.slabs + slab0 + j) * N + h) * 16 + 4 * g, acc1[q][j]);
+                    if (TWO) stx4_wt(Xk_ + (((size_t)k0 * a.slabs + slab0 + j) * N + h) * 16 + 4 * g, acc2[q][j]);
                 }
-                if (two) MM::mma_ab2(MM::cvt(acc1[q]), wf1, MM::cvt(acc2[q]), wf2, yacc[q]);
-                else yacc[q] = MM::mma(MM::cvt(acc1[q]), wf1, yacc[q]);
+                if (TWO) MM::mma_ab2(MM::cvt(acc1[q][j]), wf1, MM::cvt(acc2[q][j]), wf2, yacc[q][j]);
+                else yacc[q][j] = MM::mma(MM::cvt(acc1[q][j]), wf1, yacc[q][j]);
             }
         }
+    };
+    auto term_pair_nq = [&](int k0, auto two_tag) __attribute__((always_inline)) {
+        if (nq == 1) term_pair(k0, two_tag, std::integral_constant<int, 1>());
+        if constexpr (MAXQ >= 2) { if (nq == 2) term_pair(k0, two_tag, std::integral_constant<int, 2>()); }
+        if constexpr (MAXQ >= 3) { if (nq == 3) term_pair(k0, two_tag, std::integral_constant<int, 3>()); }
+        if constexpr (MAXQ >= 4) { if (nq == 4) term_pair(k0, two_tag, std::integral_constant<int, 4>()); }
+    };
+    for (int k0 = 1; k0 < a.Ks; k0 += 2) {
+        if (k0 + 1 < a.Ks) term_pair_nq(k0, std::true_type());
+        else term_pair_nq(k0, std::false_type());
     }
 
     const float bb = a.bias ? a.bias[l15] : 0.f;
@@ -1245,9 +1297,13 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         const int ht = wave + WAVES * q;
         if (ht < HT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int h = ht * 16 + 4 * g + r;
-                if (h < N) stx1(G_ + ((size_t)slab * N + h) * 16 + l15, fmaxf(yacc[q][r] + bb + res[q][r], 0.f));
+            for (int j = 0; j < SP; ++j) {
+                if (!live[j]) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int h = ht * 16 + 4 * g + r;
+                    if (h < N) stx1(G_ + ((size_t)(slab0 + j) * N + h) * 16 + l15, fmaxf(yacc[q][j][r] + bb + res[q][j][r], 0.f));
+                }
             }
         }
     }

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
                     for (int r = 0; r < 4; ++r) At[(i * 16 + 4 * g + r) * lda + col] = acc[i][j][r];
             }
             __syncthreads();
+            const uint64_t hoff = ln_rowstat_offset(a.rs);
             for (int row = rsub; row < TR; row += kThreads / c4n) {   // c4n lanes (half a wave for c0 = 128) hold one row
                 const long R = row0 + row;
                 const bool rin = R < a.rows;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(FcBwdArgs a) {
                 if (rin) stx4_wt(et_ptr<ET>(a.dyln) + (size_t)R * c0 + 4 * c4, v);
                 const long slab = rin ? R / a.rs.N : 0;
                 const int node = rin ? (int)(R - slab * a.rs.N) : 0;
-                float2 p = rin ? ln_rowstat4<ET>(a.rs, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);
+                float2 p = rin ? ln_rowstat4<ET>(a.rs, hoff, v, slab, node, 4 * c4) : make_float2(0.f, 0.f);
                 for (int m = c4n >> 1; m >= 1; m >>= 1) {
                     p.x += __shfl_xor(p.x, m);
                     p.y += __shfl_xor(p.y, m);

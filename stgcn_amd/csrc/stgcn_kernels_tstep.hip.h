@@ -478,6 +478,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         // operands use the k order j = 4g + s).  D leaves a lane with channels 16w + 4g .. + 3 of row l15 = its U / S / dZ1 quad.
         const typename MM::frag wa = MM::cvt(ld4(a.WaD + (size_t)(16 * w + l15) * 16 + 4 * g));
         f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
+        const uint64_t hoff = ln_rowstat_offset(a.rs);   // (once: inside hook_fetch it was a dependent load + s_waitcnt vmcnt(0) in every time step)
         struct Tile { f32x4 u, s; };
         STGCN_ACC_DECL();
         for (long item = item0; item <= item1 && item < items; ++item) {
@@ -559,8 +560,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     h.y = ldx4(hy_ + e);
                     h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
                     if (a.rs.training) {
-                        const uint64_t off = a.rs.offset + (a.rs.offset_dev ? *a.rs.offset_dev : 0);
-                        h.k = dropout_scale4((uint64_t)slab * (((uint64_t)N * CIN) >> 2) + (((uint64_t)rc * CIN + 4 * cq) >> 2), a.rs.seed, off,
+                        h.k = dropout_scale4((uint64_t)slab * (((uint64_t)N * CIN) >> 2) + (((uint64_t)rc * CIN + 4 * cq) >> 2), a.rs.seed, hoff,
                                              a.rs.thresh, a.rs.keep_scale);
                     }
                 }

@@ -67,3 +67,16 @@ def test_tiled_gemm_column_extents(ntw):
 def test_bf16_gemm_64_deep_steps():
     # the bf16 / bf16x3 operator GEMM with 64-deep pipeline steps (128-B LDS rows, 8-position swizzle); the default is 32
     run_subset({"STGCN_GEMM_BF16_BK": "64"}, ["tests/test_emu_gctile.py"], "rounded or (bf16x3 and graph_conv)")
+
+
+def test_graph_conv_two_slabs_per_workgroup():
+    # forward graph conv with every operator fragment feeding two (b, t) slabs (gconv_fwd_kernel<.., SP = 2>): even and odd slab counts
+    # (the last group is short), Chebyshev Ks = 3 / 5 and Kipf, two tiles per wave (300 nodes), fp32 and bf16 activations
+    run_subset({"STGCN_GC_SP": "2"}, [FWD], "17-1-6 or 35-1-5 or 9-2-5 or 300-6-12")
+    run_subset({"STGCN_GC_SP": "2"}, ["tests/test_emu_bf16.py"], "block")
+    run_subset({"STGCN_GC_SP": "1"}, [FWD], "17-1-6 or 35-1-5")
+
+
+def test_big_bf16_gemm_32_deep_steps():
+    # the 256-row-tile bf16 operator GEMM on its 4-buffer ring of 32-deep steps (the default is 64-deep steps on two buffers)
+    run_subset({"STGCN_GEMM_BIG_BK": "32"}, ["tests/test_emu_gctile.py"], "bf16_gemm or tiled_block")
