@@ -1110,7 +1110,11 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         f.U = saved + pl.sv_U1; f.S = saved + pl.sv_S1; f.A = saved + pl.sv_A;
         f.B = d->B; f.T = d->T; f.T1 = v.T1; f.N = d->N; f.node_tiles = (d->N + 15) / 16;
         const long items = (long)d->B * f.node_tiles;
-        const long want = device_cus();                                                       // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
+        // workgroups per CU: one for fp32 (its steps are bound by the fp32 matrix pipe: a second chain on the CU made it 12 % slower), two for
+        // bf16 activations (8 x cheaper MFMAs leave a latency chain: C3 34.2 -> 27.1 us, r3-31); STGCN_TC1_FWD_PER_CU forces
+        static const int force_per_cu = getenv("STGCN_TC1_FWD_PER_CU") ? atoi(getenv("STGCN_TC1_FWD_PER_CU")) : 0;
+        const int fwd_per_cu = force_per_cu > 0 ? force_per_cu : (g_bf16 ? 2 : 1);
+        const long want = (long)device_cus() * fwd_per_cu;                                    // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
         const dim3 grid((unsigned)(items < want ? items : want)), blk(512);                   // equal (item, step) ranges, one workgroup per CU
         const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \

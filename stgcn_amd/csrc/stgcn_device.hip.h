@@ -64,10 +64,26 @@ constexpr int kTileRows = 64;   // rows of a flat row tile (4 MFMA m-tiles)
 constexpr int gc_ring(int maxq) { return maxq <= 1 ? STGCN_GC_RING1 : 2; }
 constexpr int kSegMax = 128;    // K columns staged in LDS per segment
 
+#ifndef STGCN_TS_DBG
+#define STGCN_TS_DBG 0   // timing experiments only (wrong results): 1 = activation loads (ldx*) return an opaque zero, 2 = no MFMAs, 3 = no activation stores (stx*)
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#if STGCN_TS_DBG == 2
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#if STGCN_TS_DBG
+__device__ __forceinline__ f32x4 dbg_opaque4() {
+    f32x4 v;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]));
+    return v;
+}
+__device__ __forceinline__ void dbg_keep4(f32x4 v) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+#endif
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1) for bulk outputs that the same kernel never reads again.  A plain store
 // leaves its line dirty in the XCD's L2 and the kernel boundary then pays for the write-back (MI355X_MICROARCH.md "boundary": + dirty
@@ -163,14 +179,30 @@ template <typename ET> __device__ __forceinline__ const ET* et_ptr(const float* 
 template <typename ET> __device__ __forceinline__ ET* et_ptr(float* p) { return reinterpret_cast<ET*>(p); }
 
 // 4 consecutive elements <-> f32x4 (16-byte / 8-byte accesses), one element <-> float
+#if STGCN_TS_DBG == 1
+__device__ __forceinline__ f32x4 ldx4(const float* p) { (void)p; return dbg_opaque4(); }
+#else
 __device__ __forceinline__ f32x4 ldx4(const float* p) { return ld4(p); }
+#endif
 __device__ __forceinline__ f32x4 ldx4(const f32x* p) { return ld4(reinterpret_cast<const float*>(p)); }
 __device__ __forceinline__ void stx4(f32x* p, f32x4 v) { st4(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ float ldx1(const f32x* p) { return p->v; }
 __device__ __forceinline__ void stx1(f32x* p, float v) { p->v = v; }
+#if STGCN_TS_DBG == 1
+__device__ __forceinline__ f32x4 ldx4(const bf16* p) { (void)p; return dbg_opaque4(); }
+#else
 __device__ __forceinline__ f32x4 ldx4(const bf16* p) { return unpack_bf16x4(*reinterpret_cast<const u32x2_t*>(p)); }
+#endif
+#if STGCN_TS_DBG == 3
+__device__ __forceinline__ void stx4(float* p, f32x4 v) { (void)p; dbg_keep4(v); }
+#else
 __device__ __forceinline__ void stx4(float* p, f32x4 v) { st4(p, v); }
+#endif
+#if STGCN_TS_DBG == 3
+__device__ __forceinline__ void stx4(bf16* p, f32x4 v) { (void)p; dbg_keep4(v); }
+#else
 __device__ __forceinline__ void stx4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2_t*>(p) = pack_bf16x4(v); }
+#endif
 // 8 consecutive elements (16 B of bf16: one dwordx4 access; 32 B of fp32: two)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ldx8(const float* p, f32x4& a, f32x4& b) { a = ld4(p); b = ld4(p + 4); }
@@ -193,7 +225,11 @@ __device__ __forceinline__ float ldx1(const bf16* p) { return __builtin_bit_cast
 __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stx1(bf16* p, float v) { p->v = (unsigned short)bf16_bits_rne(v); }
 // write-through variants (see st4_wt)
+#if STGCN_TS_DBG == 3
+__device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { (void)p; dbg_keep4(v); }
+#else
 __device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { st4_wt(p, v); }
+#endif
 __device__ __forceinline__ void stx4_wt(f32x* p, f32x4 v) { st4_wt(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ void stx4_wt2(f32x* p, f32x4 v) { st4_wt2(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ void stx4_wt(bf16* p, f32x4 v) {
@@ -204,7 +240,11 @@ __device__ __forceinline__ void stx4_wt(bf16* p, f32x4 v) {
     *reinterpret_cast<u32x2_t*>(p) = r;
 #endif
 }
+#if STGCN_TS_DBG == 3
+__device__ __forceinline__ void stx4_wt2(float* p, f32x4 v) { (void)p; dbg_keep4(v); }
+#else
 __device__ __forceinline__ void stx4_wt2(float* p, f32x4 v) { st4_wt2(p, v); }
+#endif
 __device__ __forceinline__ void stx4_wt2(bf16* p, f32x4 v) {
     const u32x2_t r = pack_bf16x4(v);
 #if STGCN_WT_STORES >= 2 && defined(__HIP_DEVICE_COMPILE__)
