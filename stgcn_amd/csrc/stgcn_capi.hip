@@ -1162,11 +1162,14 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         const dim3 grid((unsigned)v.slabs2);
         // 16 waves (4 tile groups) when the grid leaves room for it: at most ~2 workgroups per CU (measured at C2: 25.8 -> ?? us)
         static const int hv_force = getenv("STGCN_TC2LN_HV") ? atoi(getenv("STGCN_TC2LN_HV")) : 0;
-        const bool wide = hv_force ? hv_force == 4 : (d->N <= 256 && v.slabs2 <= 2L * device_cus());
+        // (up to 384 nodes = 6 tiles per wave of a four-group workgroup: C3's 325-node slabs ran on 8 waves, one workgroup per CU, two rounds)
+        // (the 6-tile form only for bf16 activations: with fp32 fragments it needs more than the 128 registers of a 16-wave workgroup)
+        const bool wide = d->N <= (g_bf16 ? 384 : 256) && (hv_force ? hv_force == 4 : v.slabs2 <= 2L * device_cus());
         const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (wide) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4, ET>), grid, dim3(1024), lds, f);      \
+            if (wide && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4, ET>), grid, dim3(1024), lds, f); \
+            else if (wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 6, 4, bf16>), grid, dim3(1024), lds, f); \
             else if (small) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2, ET>), grid, dim3(512), lds, f); \
             else STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2, ET>), grid, dim3(512), lds, f);           \
         } while (0)

@@ -15,6 +15,7 @@ CASES = [
     (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 6, True),      # second block: all four time-stepping kernels
     (64, (64, 16, 64), 3, 3, "graph_conv", "gtu", 35, 1, 5, False),
     (32, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 40, 1, 7, True),
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 300, 1, 6, True),     # 19 row tiles: the 16-wave / 6-tile tc2_ln_fwd of 257 .. 384 nodes, two graph-conv tiles per wave
 ]
 
 
