@@ -203,6 +203,25 @@ __device__ __forceinline__ void stx4(bf16* p, f32x4 v) { (void)p; dbg_keep4(v); 
 #else
 __device__ __forceinline__ void stx4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2_t*>(p) = pack_bf16x4(v); }
 #endif
+// What a 4-element load leaves in registers, and its conversion to fp32 -- SEPARATE steps for values requested ahead of their use: ldx4
+// unpacks (bf16) at the load, and an unpack or a mask right behind a load makes the compiler wait for the load there, so a "prefetched"
+// ldx4 result is no prefetch at all (r3-33: without its activation loads the bf16 tc1_bwd launch of C3 takes 66 of 105 us).
+template <typename ET> struct Raw4 { f32x4 v; };
+template <> struct Raw4<bf16> { u32x2_t v; };
+template <typename ET> __device__ __forceinline__ Raw4<ET> ldraw4(const ET* p) {
+    Raw4<ET> r;
+    if constexpr (sizeof(ET) == 2) r.v = *reinterpret_cast<const u32x2_t*>(p);
+    else r.v = ld4(reinterpret_cast<const float*>(p));
+#if STGCN_TS_DBG == 1
+    if constexpr (sizeof(ET) == 2) { const f32x4 z = dbg_opaque4(); r.v[0] = __builtin_bit_cast(unsigned, z[0]); r.v[1] = __builtin_bit_cast(unsigned, z[1]); }
+    else r.v = dbg_opaque4();
+#endif
+    return r;
+}
+template <typename ET> __device__ __forceinline__ f32x4 cvt4(const Raw4<ET>& r) {
+    if constexpr (sizeof(ET) == 2) return unpack_bf16x4(r.v);
+    else return r.v;
+}
 // 8 consecutive elements (16 B of bf16: one dwordx4 access; 32 B of fp32: two)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ldx8(const float* p, f32x4& a, f32x4& b) { a = ld4(p); b = ld4(p + 4); }
@@ -233,6 +252,9 @@ __device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { st4_wt(p, v); }
 __device__ __forceinline__ void stx4_wt(f32x* p, f32x4 v) { st4_wt(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ void stx4_wt2(f32x* p, f32x4 v) { st4_wt2(reinterpret_cast<float*>(p), v); }
 __device__ __forceinline__ void stx4_wt(bf16* p, f32x4 v) {
+#if STGCN_TS_DBG == 3
+    (void)p; dbg_keep4(v); return;
+#endif
     const u32x2_t r = pack_bf16x4(v);
 #if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
@@ -246,6 +268,9 @@ __device__ __forceinline__ void stx4_wt2(float* p, f32x4 v) { (void)p; dbg_keep4
 __device__ __forceinline__ void stx4_wt2(float* p, f32x4 v) { st4_wt2(p, v); }
 #endif
 __device__ __forceinline__ void stx4_wt2(bf16* p, f32x4 v) {
+#if STGCN_TS_DBG == 3
+    (void)p; dbg_keep4(v); return;
+#endif
     const u32x2_t r = pack_bf16x4(v);
 #if STGCN_WT_STORES >= 2 && defined(__HIP_DEVICE_COMPILE__)
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
@@ -321,7 +346,12 @@ template <> struct Mma<bf16> {
     typedef s16x4 frag;
     static __device__ __forceinline__ frag cvt(f32x4 v) { return __builtin_bit_cast(s16x4, pack_bf16x4(v)); }
     static __device__ __forceinline__ f32x4 mma(const frag& a, const frag& b, f32x4 c) {
+        #if STGCN_TS_DBG == 2
+        asm volatile("" ::"v"(a), "v"(b));
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
     }
     static __device__ __forceinline__ void mma_b2(const frag& a, const frag& b0, const frag& b1, f32x4& c0, f32x4& c1) {
         c0 = mma(a, b0, c0);

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         const typename MM::frag wa = MM::cvt(ld4(a.WaD + (size_t)(16 * w + l15) * 16 + 4 * g));
         f32x4 dbu = zero4(), dbq = zero4(), dba = zero4();
         const uint64_t hoff = ln_rowstat_offset(a.rs);   // (once: inside hook_fetch it was a dependent load + s_waitcnt vmcnt(0) in every time step)
-        struct Tile { f32x4 u, s; };
+        struct Tile { Raw4<ET> u, s; };   // (raw: converted and masked where E consumes them)
         STGCN_ACC_DECL();
         for (long item = item0; item <= item1 && item < items; ++item) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
@@ -492,26 +492,27 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             auto fetch = [&](int t1, Tile& t) __attribute__((always_inline)) {
                 const int tc = t1 < T1 ? t1 : T1 - 1;
                 const size_t e0 = (((size_t)b * T1 + tc) * N + erc) * C0 + 4 * ecq;
-                t.u = ldx4(U_ + e0);
-                t.s = ldx4(S_ + e0);
-                if (!erv) t.s = zero4();        // s = 0 makes every product of the gate backward vanish
+                t.u = ldraw4(U_ + e0);
+                t.s = ldraw4(S_ + e0);
             };
             // dA tile t -> registers of 64 threads (row rowq >> 2, quad rowq & 3) -> ring slot t % RING; owned tiles count towards dba
+            // (the loads of the step loop are UNCONDITIONAL -- clamped addresses, the value masked afterwards: a branch around a load makes the
+            //  compiler's wait counts start over at the join, and every later use then waits for everything in flight)
             auto get_dA = [&](int t, int rowq) __attribute__((always_inline)) {
-                f32x4 v = zero4();
-                if (t < T1 && n0 + (rowq >> 2) < N) v = ldx4(dA_ + (((size_t)b * T1 + t) * N + n0 + (rowq >> 2)) * 16 + 4 * (rowq & 3));
-                return v;
+                const int tc = t < T1 ? t : T1 - 1, nr = n0 + (rowq >> 2), nc = nr < N ? nr : N - 1;
+                return ldraw4(dA_ + (((size_t)b * T1 + tc) * N + nc) * 16 + 4 * (rowq & 3));   // (masked by put_dA)
             };
-            auto put_dA = [&](int t, int rowq, f32x4 v) __attribute__((always_inline)) {
+            auto put_dA = [&](int t, int rowq, const Raw4<ET>& raw) __attribute__((always_inline)) {
+                const f32x4 v = (t < T1 && n0 + (rowq >> 2) < N) ? cvt4(raw) : zero4();
                 st4(dAe + (t % RING) * 256 + (rowq >> 2) * 16 + 4 * (rowq & 3), v);
                 if (t >= sb && t < t_hi) dba += v;
             };
-            auto get_x = [&](int xt) {
-                f32x4 v = zero4();
-                if (cq < CIN / 4 && rv && xt < T) v = ldx4(x_ + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
-                return v;
+            auto get_x = [&](int xt) __attribute__((always_inline)) {
+                const int xc = xt < T ? xt : T - 1, qc = cq < CIN / 4 ? cq : CIN / 4 - 1;
+                return ldraw4(x_ + (((size_t)b * T + xc) * N + rc) * CIN + 4 * qc);   // (masked by put_x)
             };
-            auto put_x = [&](int xt, f32x4 v) {
+            auto put_x = [&](int xt, const Raw4<ET>& raw) {
+                const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
                 if (cq < CIN / 4) {
                     float* d = XT + (size_t)(xt % RING) * CIN * LDX + (4 * cq) * LDX + r;
 #pragma unroll
@@ -523,14 +524,15 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             auto E = [&](int t, const Tile& tl) __attribute__((always_inline)) {
                 const f32x4 d4 = ld4(dAe + (t % RING) * 256 + er * 16 + 4 * g);
                 const f32x4 dh = MM::mma(wa, MM::cvt(d4), zero4());
+                const f32x4 tu = cvt4(tl.u), tsv = erv ? cvt4(tl.s) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 f32x4 du, dq, h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float du_, dq_;
-                    gate_bwd(dh[i], tl.u[i], tl.s[i], ACT, du_, dq_);
+                    gate_bwd(dh[i], tu[i], tsv[i], ACT, du_, dq_);
                     du[i] = du_;
                     dq[i] = dq_;
-                    h[i] = gate_fwd(tl.u[i], tl.s[i], ACT);
+                    h[i] = gate_fwd(tu[i], tsv[i], ACT);
                 }
                 float* const Zs = Zt + (t % RING) * 16 * LDZ + er * LDZ;
                 st4(Zs + 4 * ecq, du);
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             // AHEAD of the dx tile they meet -- forming them inside F put dependent memory round trips on the E waves' critical path of
             // every step.  With g = mask * dx * gamma and y = mask * (xhat * gamma + beta) the two row sums need no xhat:
             //     sum g = sum mask dx gamma ,   sum g xhat = sum_kept dx (y - keep_scale * beta)
-            struct Hook { f32x4 y, k; };
+            struct Hook { Raw4<ET> y; f32x4 k; };
             const bool hk = a.rs.rowstat != nullptr;           // uniform
             const f32x4 hgam = (hk && cq < CIN / 4) ? ld4(a.rs.gamma + (size_t)rc * CIN + 4 * cq) : zero4();
             f32x4 hbks = (hk && cq < CIN / 4) ? ld4(a.rs.beta + (size_t)rc * CIN + 4 * cq) : zero4();   // keep_scale * beta
@@ -553,13 +555,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hbks[i] *= a.rs.keep_scale;
             }
+            const ET* const hyp = hk ? hy_ : x_;               // (no hook: a valid address of the same shape, the value is never used)
             auto hook_fetch = [&](int t, Hook& h) __attribute__((always_inline)) {
-                if (hk && cq < CIN / 4) {
+                {
                     const long slab = (long)b * T + (t < T ? t : T - 1);
-                    const size_t e = ((size_t)slab * N + rc) * CIN + 4 * cq;
-                    h.y = ldx4(hy_ + e);
+                    const size_t e = ((size_t)slab * N + rc) * CIN + 4 * (cq < CIN / 4 ? cq : CIN / 4 - 1);
+                    h.y = ldraw4(hyp + e);
                     h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
-                    if (a.rs.training) {
+                    if (hk && a.rs.training) {
                         h.k = dropout_scale4((uint64_t)slab * (((uint64_t)N * CIN) >> 2) + (((uint64_t)rc * CIN + 4 * cq) >> 2), a.rs.seed, hoff,
                                              a.rs.thresh, a.rs.keep_scale);
                     }
@@ -573,10 +576,11 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     if (hk) {   // uniform
                         float2 p = make_float2(0.f, 0.f);
                         if (rv) {
+                            const f32x4 hy = cvt4(h.y);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 p.x += v[i] * h.k[i] * hgam[i];
-                                if (h.k[i] > 0.f) p.y += v[i] * (h.y[i] - hbks[i]);
+                                if (h.k[i] > 0.f) p.y += v[i] * (hy[i] - hbks[i]);
                             }
                         }
 #pragma unroll
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             Tile pr[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) fetch(t_lo + k, pr[k]);
-            f32x4 xs[KT];
+            Raw4<ET> xs[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) xs[k] = get_x(sb + k);
             // dA tiles t_lo .. t_lo + KT: one float4 per thread (wave k stages tile t_lo + k).  The ring is free: every E thread passed
@@ -611,40 +615,56 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             __syncthreads();   // (A0) the previous range is fully consumed (ring, H, dA, dx tiles free); the dA tiles visible
 #pragma unroll
             for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);
-            Tile p0;                   // tile min(sb, T1 - 1) + 1: the next one E will need (one of the batch when the range starts early)
-            fetch(t_lo + KT, p0);
+            // Two register sets of step operands, A for the steps sb, sb + 2, .. and B for sb + 1, sb + 3, ..: what step i consumes was
+            // requested in step i - 2 (the loop is unrolled by two, the sets are named: a rotation through copies would wait for the younger
+            // set at the copy).  One step of cover was enough for the fp32 steps (4.7 us); a bf16 step is 1 us and waited for its loads:
+            // without them the C3 launch takes 66 of its 105 us (r3-33).
+            struct Pre { Tile p; Raw4<ET> x, da; Hook h; };
+            Pre A, B;
+            fetch(t_lo + KT, A.p);     // tile min(sb, T1 - 1) + 1: the next one E will need (one of the batch when the range starts early)
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int t = t_lo + k;
                 if (t <= sb && t < T1) E(t, pr[k]);                     // uniform
-                else if (t == (sb < T1 ? sb : T1 - 1) + 1) p0 = pr[k];  // uniform
+                else if (t == (sb < T1 ? sb : T1 - 1) + 1) A.p = pr[k];  // uniform
             }
-            f32x4 x_n = get_x(sb + KT);
-            f32x4 da_n = tid < 64 ? get_dA(t_lo + KT + 1, tid) : zero4();
-            Hook h0;
-            hook_fetch(sb, h0);
+            // (requests in the order of the step loop -- all of A, then all of B, within a set p, da, x, h -- so that the wait counts the
+            //  compiler derives for the loop entry equal those of the back edge)
+            A.da = get_dA(sb + 2, tid & 63);
+            A.x = get_x(sb + KT);
+            hook_fetch(sb, A.h);       // (step sb has no F: requested for the symmetry of the counts, never read)
+            fetch(sb + 2, B.p);
+            B.da = get_dA(sb + 3, tid & 63);
+            B.x = get_x(sb + KT + 1);
+            hook_fetch(sb, B.h);       // F(sb) runs in step sb + 1
             STGCN_ACC2_END();
-            for (int i = sb; i < se; ++i) {
+            // step i: finish dx tile i - 1 (F), gate backward of tile i + 1 (E), stage dA tile i + 2 and x tile i + KT, request what step i + 2 needs
+            auto step = [&](int i, Pre& s) __attribute__((always_inline)) {
                 __syncthreads();   // (B) tile i (dZ1, H, x, dA) visible to the M waves; dx tile i - 1 visible to the E waves
                 STGCN_ACC_BEGIN();
-                if (i > sb) {
-                    F(i - 1, h0);
-                    hook_fetch(i, h0);
-                }
-                if (i + 1 < t_hi) {
-                    E(i + 1, p0);
-                    fetch(i + 2, p0);
-                }
-                if (tid < 64) {          // dA tile i + 2 -> slot (i + 2) % RING (tile i - 2 lived there: last read in step i - 2)
-                    if (i + 2 > t_lo + KT) put_dA(i + 2, tid, da_n);     // (tiles up to t_lo + KT were staged by the prologue)
-                    da_n = get_dA(i + 3, tid);
-                }
-                put_x(i + KT, x_n);      // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1; tiles beyond T are zeros
-                x_n = get_x(i + KT + 1);
+                if (i > sb) F(i - 1, s.h);
+                if (i + 1 < t_hi) E(i + 1, s.p);
+                if (tid < 64 && i + 2 > t_lo + KT) put_dA(i + 2, tid, s.da);   // slot (i + 2) % RING (tile i - 2 lived there: last read in step i - 2;
+                                                                                 //  tiles up to t_lo + KT were staged by the prologue)
+                put_x(i + KT, s.x);      // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1; tiles beyond T are zeros
+                fetch(i + 3, s.p);
+                s.da = get_dA(i + 4, tid & 63);
+                s.x = get_x(i + KT + 2);
+                hook_fetch(i + 1, s.h);
                 STGCN_ACC_END();
+            };
+            // (the first step is peeled: the loop is then entered and re-entered in the same state -- step A just done -- and the wait counts
+            //  the compiler derives at its header are the exact ones of the back edge instead of vmcnt(0))
+            int i = sb;
+            step(i, A);
+            for (++i; i + 1 < se; i += 2) {
+                step(i, B);
+                step(i + 1, A);
             }
+            if (i < se) step(i, B);
             __syncthreads();       // (C) last dx tile visible
-            F(se - 1, h0);
+            if ((se - sb) & 1) F(se - 1, B.h);
+            else F(se - 1, A.h);
         }
         STGCN_PHASE(10, 4);
         STGCN_ACC_STORE(10, 8, tid == 0);
@@ -877,10 +897,11 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             if (sb >= se) continue;
             const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
             const bool rv = n0 + r < N;
-            auto get_x = [&](int xt) {
-                f32x4 v = zero4();
-                if (cq < CIN / 4 && rv && xt < T) v = ldx4(x_ + (((size_t)b * T + xt) * N + n0 + r) * CIN + 4 * cq);
-                return v;
+            const int rc = rv ? n0 + r : N - 1;
+            auto get_x = [&](int xt) __attribute__((always_inline)) {
+                const int xc = xt < T ? xt : T - 1, qc = cq < CIN / 4 ? cq : CIN / 4 - 1;
+                const f32x4 v = ldx4(x_ + (((size_t)b * T + xc) * N + rc) * CIN + 4 * qc);
+                return (cq < CIN / 4 && rv && xt < T) ? v : zero4();
             };
             auto put_x = [&](int xt, f32x4 v) {
                 if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);

@@ -5,8 +5,8 @@ OUT=$GRAFT_REPO_ROOT/$1
 cd $GRAFT_REPO_ROOT
 for V in 0 1 2 3; do
   if [ $V = 0 ]; then E=""; else E="STGCN_AMD_LIB=$GRAFT_REPO_ROOT/stgcn_amd/_dbg/libstgcn_ts$V.so"; fi
-  env $E timeout 600 python bench.py --config c2 --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-baseline --no-secondary > $OUT/bench_c2_ts$V.json 2> $OUT/bench_c2_ts$V.err; echo "c2 ts$V exit $?"
+  env $E timeout 600 python bench.py --config ${CFG:-c2} --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-baseline --no-secondary > $OUT/bench_${CFG:-c2}_ts$V.json 2> $OUT/bench_${CFG:-c2}_ts$V.err; echo "c2 ts$V exit $?"
   python -c "
-import json; d=json.load(open('$OUT/bench_c2_ts$V.json')); r=d['roofline']; pk=r['per_kernel_us_per_step']
+import json; d=json.load(open('$OUT/bench_${CFG:-c2}_ts$V.json')); r=d['roofline']; pk=r['per_kernel_us_per_step']
 print('ts$V', d['ms_per_step'], ' '.join(f'{k}={v:.1f}' for k,v in sorted(pk.items())))"
 done
