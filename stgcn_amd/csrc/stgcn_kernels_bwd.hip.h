@@ -621,14 +621,37 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
 
     // ---- stage dY (row major) and all X_k (transposed) -----------------------------------------
     const ET* dYsl = et_ptr<ET>(a.dY) + (size_t)slab * N * 16;
-    for (int idx = tid; idx < NP * 4; idx += THREADS) {
-        const int n = idx >> 2, c4 = idx & 3;
-        st4(dYs + n * LDY + c4 * 4, n < N ? ldx4(dYsl + (size_t)n * 16 + c4 * 4) : zero4());
-        for (int k = 0; k < Ks; ++k) {
-            const ET* Xsl = (k == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(k - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
-            const f32x4 v = n < N ? ldx4(Xsl + (size_t)n * 16 + c4 * 4) : zero4();
+    // (the 1 + Ks requests of two trips in flight per thread, raw, addresses clamped: load -> LDS store pairs waited for every load in turn)
+    for (int idx0 = tid; idx0 < NP * 4; idx0 += 2 * THREADS) {
+        constexpr int KM = 8;   // terms (check_desc: Ks <= 8)
+        Raw4<ET> ry[2], rx[2][KM];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) GT0[(k * 16 + c4 * 4 + i) * LDX + n] = v[i];
+        for (int u = 0; u < 2; ++u) {
+            const int idx = idx0 + u * THREADS, n = idx >> 2, c4 = idx & 3;
+            const size_t o = (size_t)(n < N ? n : N - 1) * 16 + c4 * 4;
+            ry[u] = ldraw4(dYsl + o);
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                if (k < Ks) {   // (uniform)
+                    const ET* Xsl = (k == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(k - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
+                    rx[u][k] = ldraw4(Xsl + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = idx0 + u * THREADS, n = idx >> 2, c4 = idx & 3;
+            if (idx < NP * 4) {
+                st4(dYs + n * LDY + c4 * 4, n < N ? cvt4(ry[u]) : zero4());
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    if (k < Ks) {
+                        const f32x4 v = n < N ? cvt4(rx[u][k]) : zero4();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) GT0[(k * 16 + c4 * 4 + i) * LDX + n] = v[i];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -1184,7 +1207,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
     constexpr int NCR = (SR * (MC / 4) + kThreads - 1) / kThreads;   // float4 of the im2col tile per thread (vector path)
     constexpr int NCS = (SR * MC + kThreads - 1) / kThreads;         // scalars per thread (narrow-input path)
     constexpr int NZ = SR * NTW * 16 / kThreads;                      // SR * NC / 4 / 256 with NC = 64 * NTW
-    f32x4 creg[VEC ? NCR : 1], zreg[NZ];
+    Raw4<ET> creg[VEC ? NCR : 1], zreg[NZ];   // (raw: unpacked by store_regs -- an unpack right behind the load would wait for it there)
     float cs[VEC ? 1 : NCS];
     auto load_regs = [&](int step) {
         const long r0 = crow0 + (long)step * SR;
@@ -1193,14 +1216,15 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
             for (int i = 0; i < NCR; ++i) {
                 const int idx = tid + i * kThreads;
                 const int r = idx / (MC / 4), q = idx - r * (MC / 4);
-                f32x4 v = zero4();
+                Raw4<ET> v;
+                v.v = {};
                 if (r < SR) {
                     const long R = r0 + r;
                     const int kidx = m0 + 4 * q;
                     if (R < crow1 && kidx < K) {
                         const unsigned Ru = (unsigned)R, b = Ru / per_b, rem = Ru - b * per_b;
                         const int tap = fast_div(kidx, a.ts.C, csh), ch = kidx - tap * a.ts.C;
-                        v = ldx4(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+                        v = ldraw4(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
                     }
                 }
                 creg[i] = v;
@@ -1228,7 +1252,8 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
             const int idx = tid + z * kThreads;
             const int r = idx / (NC / 4), q = idx - r * (NC / 4);
             const long R = r0 + r;
-            zreg[z] = R < crow1 ? ldx4(dZ_ + (size_t)R * NC + 4 * q) : zero4();
+            zreg[z].v = {};
+            if (R < crow1) zreg[z] = ldraw4(dZ_ + (size_t)R * NC + 4 * q);
         }
     };
     auto store_regs = [&]() {
@@ -1237,7 +1262,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
             for (int i = 0; i < NCR; ++i) {
                 const int idx = tid + i * kThreads;
                 const int r = idx / (MC / 4), q = idx - r * (MC / 4);
-                if (r < SR) st4(ct + r * LDC + 4 * q, creg[i]);
+                if (r < SR) st4(ct + r * LDC + 4 * q, cvt4(creg[i]));
             }
         } else {
 #pragma unroll
@@ -1251,7 +1276,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
         for (int z = 0; z < NZ; ++z) {
             const int idx = tid + z * kThreads;
             const int r = idx / (NC / 4), q = idx - r * (NC / 4);
-            st4(zt + r * LDZ + 4 * q, zreg[z]);
+            st4(zt + r * LDZ + 4 * q, cvt4(zreg[z]));
         }
     };
 

@@ -1154,11 +1154,23 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     for (int j = 0; j < SP; ++j) {
         live[j] = slab0 + j < a.slabs;
         const ET* Asl = et_ptr<ET>(a.A) + (size_t)(live[j] ? slab0 + j : slab0) * N * 16;
-        for (int idx = tid; idx < NP * 4; idx += THREADS) {
-            const int n = idx >> 2, c4 = idx & 3;
-            const f32x4 v = n < N ? ldx4(Asl + (size_t)n * 16 + c4 * 4) : zero4();
+        // (four requests in flight per thread, raw, addresses clamped: one load -> four LDS stores per trip waited for every load in turn)
+        for (int idx0 = tid; idx0 < NP * 4; idx0 += 4 * THREADS) {
+            Raw4<ET> rw[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) XT0[(j * 16 + c4 * 4 + i) * LDX + n] = v[i];
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * THREADS, n = idx >> 2, c4 = idx & 3;
+                rw[u] = ldraw4(Asl + (size_t)(n < N ? n : N - 1) * 16 + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * THREADS, n = idx >> 2, c4 = idx & 3;
+                if (idx < NP * 4) {
+                    const f32x4 v = n < N ? cvt4(rw[u]) : zero4();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) XT0[(j * 16 + c4 * 4 + i) * LDX + n] = v[i];
+                }
+            }
         }
     }
     __syncthreads();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# pass r3-29 (r3-34: tc1_bwd with raw two-set prefetch): static fragment ring (depth 2) in the slab graph-conv kernels + the hooked LayerNorm's dropout offset read once per kernel
+# pass r3-29 (r3-34: tc1_bwd with raw two-set prefetch; r3-35: + raw staging registers in the weight-gradient kernels, batched staging loads in gconv_fwd / gconv_bwd): static fragment ring (depth 2) in the slab graph-conv kernels + the hooked LayerNorm's dropout offset read once per kernel
 OUT=$GRAFT_REPO_ROOT/$1
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -q --maxfail=20 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
