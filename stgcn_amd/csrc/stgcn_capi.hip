@@ -144,6 +144,33 @@ void side_join(hipStream_t st, hipStream_t sd) {
     if (hipEventRecord(g_side.join, sd) == hipSuccess) (void)hipStreamWaitEvent(st, g_side.join, 0);
 }
 
+// A second, deferred form for the head's weight-gradient launch in a fused training step (desc.defer_reduce): nothing before the step's
+// stgcn_grad_flush reads its partials, so it may run beside the WHOLE backward of the ST blocks -- one fork / join pair per step
+// instead of six.  defer_fork(st) returns the stream to launch on (st itself when off); the join happens in stgcn_grad_flush (or in the next
+// defer_fork).  STGCN_SIDE_WGRAD=0/1 forces (default: see defer_enabled).
+struct DeferStream { hipStream_t s; hipEvent_t fork, join; int state; int pending; };
+DeferStream g_defer = {nullptr, nullptr, nullptr, 0, 0};
+void defer_join(hipStream_t st) {
+    if (!g_defer.pending) return;
+    g_defer.pending = 0;
+    if (hipEventRecord(g_defer.join, g_defer.s) == hipSuccess) (void)hipStreamWaitEvent(st, g_defer.join, 0);
+}
+hipStream_t defer_fork(hipStream_t st) {
+    if (g_defer.state == 0) {
+        const char* e = getenv("STGCN_SIDE_WGRAD");
+        g_defer.state = -1;
+        if (e && atoi(e) == 1 && hipStreamCreateWithFlags(&g_defer.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&g_defer.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&g_defer.join, hipEventDisableTiming) == hipSuccess)
+            g_defer.state = 1;
+    }
+    if (g_defer.state < 0) return st;
+    defer_join(st);   // (a launch of an earlier step that nobody flushed)
+    if (hipEventRecord(g_defer.fork, st) != hipSuccess || hipStreamWaitEvent(g_defer.s, g_defer.fork, 0) != hipSuccess) return st;
+    g_defer.pending = 1;
+    return g_defer.s;
+}
+
 #define STGCN_CHECK_LAUNCH(name)                                                                  \
     do {                                                                                          \
         hipError_t e_ = hipGetLastError();                                                        \

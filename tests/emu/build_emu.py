@@ -26,13 +26,31 @@ def build(force=False):
         raise RuntimeError("host clang++ not found (needed for ext_vector_type)")
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"),
             os.path.join(ROOT, "include", "stgcn_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
+    def fresh():
+        return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs)
+
+    if not force and fresh():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
-           "-Wno-unused-value", "-Wno-vla-cxx-extension",
-           os.path.join(CSRC, "stgcn_capi.hip"), os.path.join(EMU, "emu_runtime.cpp"), "-o", OUT]
-    subprocess.run(cmd, check=True)
+    # Several processes may get here at once (the spawned ranks of tests/test_dp_gloo.py on a fresh checkout): one builds, the others wait
+    # for it; the library appears by an atomic rename, so nobody ever opens a half-written file.
+    import fcntl
+    with open(os.path.join(os.path.dirname(OUT), ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not fresh():
+                tmp = OUT + ".tmp.%d" % os.getpid()
+                cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
+                       "-Wno-unused-value", "-Wno-vla-cxx-extension",
+                       os.path.join(CSRC, "stgcn_capi.hip"), os.path.join(EMU, "emu_runtime.cpp"), "-o", tmp]
+                try:
+                    subprocess.run(cmd, check=True)
+                    os.replace(tmp, OUT)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 
