@@ -321,6 +321,12 @@ int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st
     const int n4 = ln.n / 4;
     ln.per = 1024;                                   // float4 columns per workgroup (4 per thread)
     const dim3 grid(cdiv(n4, ln.per), (unsigned)slabs), blk(kThreads);
+    ln.stats_ready = 0;
+    static const int min_chunks = getenv("STGCN_LN_STATS_MIN_CHUNKS") ? atoi(getenv("STGCN_LN_STATS_MIN_CHUNKS")) : 8;   // (test knob)
+    if ((int)grid.x >= min_chunks) {   // many chunks per slab: the statistics once per slab instead of once per chunk
+        STGCN_LAUNCH("ln_slab_stats", st, ln_slab_stats_kernel, dim3((unsigned)slabs), blk, 64, ln);
+        ln.stats_ready = 1;
+    }
     STGCN_LAUNCH_ET(label, st, (ln_norm_kernel<ET>), grid, blk, 64, ln);
     return STGCN_OK;
 }

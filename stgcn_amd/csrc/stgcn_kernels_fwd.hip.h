@@ -1453,6 +1453,7 @@ struct LnFwdArgs {
     float* mean;         // [slabs]
     float* rstd;
     int n, N, C, act, training, per;   // per = float4 columns per chunk
+    int stats_ready;     // mean / rstd already hold this launch's statistics (ln_slab_stats_kernel ran: slabs of many chunks)
     float eps, keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
@@ -1475,16 +1476,34 @@ __device__ __forceinline__ void slab_stats_from_rows(const float2* rs, int N, in
     rstd = 1.0f / sqrtf(m2 / ((float)N * (float)C) + eps);
 }
 
+// slab statistics once per slab (grid = slabs) for slabs of many chunks: every workgroup of ln_norm_kernel otherwise re-derives them from
+// all N row partials -- at 8192 nodes 64 KiB of reads and two block reductions in front of a 4-quads-per-thread payload (C5: 253 us)
+__global__ __launch_bounds__(256) void ln_slab_stats_kernel(LnFwdArgs a) {
+    extern __shared__ float stgcn_smem[];
+    const long slab = blockIdx.x;
+    float mean, rstd;
+    slab_stats_from_rows(a.rowstat + (size_t)slab * a.N, a.N, a.C, a.eps, stgcn_smem, mean, rstd);
+    if (threadIdx.x == 0) {
+        a.mean[slab] = mean;
+        a.rstd[slab] = rstd;
+    }
+}
+
 template <typename ET>
 __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
     extern __shared__ float stgcn_smem[];
     const long slab = blockIdx.y;
     const int chunk = blockIdx.x, tid = threadIdx.x, n4 = a.n >> 2;
     float mean, rstd;
-    slab_stats_from_rows(a.rowstat + (size_t)slab * a.N, a.N, a.C, a.eps, stgcn_smem, mean, rstd);
-    if (chunk == 0 && tid == 0) {
-        a.mean[slab] = mean;
-        a.rstd[slab] = rstd;
+    if (a.stats_ready) {   // (uniform)
+        mean = a.mean[slab];
+        rstd = a.rstd[slab];
+    } else {
+        slab_stats_from_rows(a.rowstat + (size_t)slab * a.N, a.N, a.C, a.eps, stgcn_smem, mean, rstd);
+        if (chunk == 0 && tid == 0) {
+            a.mean[slab] = mean;
+            a.rstd[slab] = rstd;
+        }
     }
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     const ET* U = et_ptr<ET>(a.U) + (size_t)slab * a.n;

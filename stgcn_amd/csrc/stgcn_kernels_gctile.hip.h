@@ -187,19 +187,32 @@ __global__ __launch_bounds__(256) void gconv_rows_fwd_kernel(GcRowsFwdArgs a) {
     for (long tile = (long)blockIdx.x * 4 + w; tile < tiles; tile += (long)gridDim.x * 4) {
         const long row0 = tile << 4, row = row0 + l15;
         const bool in = row < a.rows;
-        f32x4 y = zero4();
+        // (all requests of the tile first -- the terms' A fragments raw, the residual values -- then the MFMAs: a load -> unpack -> MFMA chain
+        //  per term waited for every load in turn)
+        const long rowc = in ? row : a.rows - 1;
+        Raw4<ET> xr[kGcMaxTerms];
 #pragma unroll
         for (int k = 0; k < kGcMaxTerms; ++k) {
             if (k < a.terms && !(a.kipf && k == 0)) {
                 const ET* Xs = k == 0 ? X0_ : Xk_ + (size_t)(k - 1) * a.kstride;
-                const f32x4 xa = in ? ldx4(Xs + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][c = 4g + s]
-                y = MM::mma(MM::cvt(xa), MM::cvt(wf[k]), y);
+                xr[k] = ldraw4(Xs + (size_t)rowc * 16 + 4 * g);   // A[row = l15][c = 4g + s]
             }
         }
+        float res[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long rr = row0 + 4 * g + r;   // D[row = 4g + r][j = l15]
-            if (rr < a.rows) stx1(G_ + (size_t)rr * 16 + l15, fmaxf(y[r] + bb + ldx1(X0_ + (size_t)rr * 16 + l15), 0.f));
+            res[r] = ldx1(X0_ + (size_t)(rr < a.rows ? rr : a.rows - 1) * 16 + l15);
+        }
+        f32x4 y = zero4();
+#pragma unroll
+        for (int k = 0; k < kGcMaxTerms; ++k) {
+            if (k < a.terms && !(a.kipf && k == 0)) y = MM::mma(MM::cvt(in ? cvt4(xr[k]) : zero4()), MM::cvt(wf[k]), y);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long rr = row0 + 4 * g + r;
+            if (rr < a.rows) stx1(G_ + (size_t)rr * 16 + l15, fmaxf(y[r] + bb + res[r], 0.f));
         }
     }
 }

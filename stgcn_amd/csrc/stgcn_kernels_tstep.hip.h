@@ -99,22 +99,21 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 
     if (roleE) {
         // =========================================== E waves ===========================================================
-        struct Tile { f32x4 dy[IT], u[IT], s[IT]; };
+        struct Tile { Raw4<ET> dy[IT], u[IT], s[IT]; };   // (raw: converted and masked where E consumes them, see tc1_bwd_kernel)
         auto fetch = [&](int t2, Tile& t) {
             const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                t.dy[it] = ldx4(dy_ + e0 + 64 * it);
-                if (!rv) t.dy[it] = zero4();
+                t.dy[it] = ldraw4(dy_ + e0 + 64 * it);
                 if constexpr (!RECOMP) {
-                    t.u[it] = ldx4(U_ + e0 + 64 * it);
-                    t.s[it] = rv ? ldx4(S_ + e0 + 64 * it) : zero4();   // s = 0 makes every product of the gate backward vanish
+                    t.u[it] = ldraw4(U_ + e0 + 64 * it);
+                    t.s[it] = ldraw4(S_ + e0 + 64 * it);
                 }
             }
         };
-        Tile p0, p1;
-        fetch(0, p0);
-        fetch(1, p1);
+        Tile pA, pB;   // tiles 0, 2, .. / 1, 3, ..: requested two steps ahead of the E that consumes them
+        fetch(0, pA);
+        fetch(1, pB);
         f32x4 gam[IT], dgam[IT], dbet[IT], dbu[IT], dbq[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -172,15 +171,15 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             const float c1 = cs[4 * t], c2 = cs[4 * t + 1], mean = cs[4 * t + 2], rstd = cs[4 * t + 3];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                f32x4 dy = tl.dy[it];
+                f32x4 dy = rv ? cvt4(tl.dy[it]) : zero4();
                 const int c4 = cq + 16 * it;
                 f32x4 u, s;
                 if constexpr (RECOMP) {
                     u = ld4(Us + 4 * c4);
                     s = rv ? ld4(Us + C2 + 4 * c4) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 } else {
-                    u = tl.u[it];
-                    s = tl.s[it];
+                    u = cvt4(tl.u[it]);
+                    s = rv ? cvt4(tl.s[it]) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 }
                 if constexpr (TRAINING) {
                     const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
@@ -209,17 +208,23 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         __syncthreads();   // (A) cs complete (written by E waves), GT complete (written by M waves)
         if constexpr (RECOMP) __syncthreads();   // (A2) gate inputs of tile 0 recomputed
         STGCN_PHASE(8, 1);
-        E(0, p0);
-        p0 = p1;
-        fetch(2, p1);
-        for (int t1 = 0; t1 < T1; ++t1) {
+        E(0, pA);
+        fetch(2, pA);
+        // step t1: gate / LayerNorm backward of tile t1 + 1 from the set that holds it, then that set's next request (unconditional: the tile
+        // index is clamped -- a branch around the loads would reset the compiler's wait counts).  Unrolled by two over the named sets, first
+        // step peeled (exact counts at the loop header), as in tc1_bwd_kernel.
+        auto stepE = [&](int t1, Tile& ts) __attribute__((always_inline)) {
             __syncthreads();   // (B) tile t1 visible to the M waves
-            if (t1 + 1 < T2) {
-                E(t1 + 1, p0);
-                p0 = p1;
-                fetch(t1 + 3, p1);
-            }
+            if (t1 + 1 < T2) E(t1 + 1, ts);
+            fetch(t1 + 3, ts);
+        };
+        int t1 = 0;
+        stepE(t1, pB);
+        for (++t1; t1 + 1 < T1; t1 += 2) {
+            stepE(t1, pA);
+            stepE(t1 + 1, pB);
         }
+        if (t1 < T1) stepE(t1, pA);
         STGCN_PHASE(8, 4);
         __syncthreads();       // (C) last partial tiles visible
         if (rv) {
@@ -900,10 +905,10 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             const int rc = rv ? n0 + r : N - 1;
             auto get_x = [&](int xt) __attribute__((always_inline)) {
                 const int xc = xt < T ? xt : T - 1, qc = cq < CIN / 4 ? cq : CIN / 4 - 1;
-                const f32x4 v = ldx4(x_ + (((size_t)b * T + xc) * N + rc) * CIN + 4 * qc);
-                return (cq < CIN / 4 && rv && xt < T) ? v : zero4();
+                return ldraw4(x_ + (((size_t)b * T + xc) * N + rc) * CIN + 4 * qc);   // (raw: converted and masked by put_x, see tc1_bwd_kernel)
             };
-            auto put_x = [&](int xt, f32x4 v) {
+            auto put_x = [&](int xt, const Raw4<ET>& raw) {
+                const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
                 if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);
             };
             auto F = [&](int t) {   // A[t] = sum of the 4 waves' partial tiles + bias
@@ -911,12 +916,12 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
                 const float v = (rd[(0 * 16 + r) * 20 + cq] + rd[(1 * 16 + r) * 20 + cq]) + (rd[(2 * 16 + r) * 20 + cq] + rd[(3 * 16 + r) * 20 + cq]) + bj;
                 if (rv) stx1(A_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
             };
-            f32x4 xs[KT];
+            Raw4<ET> xs[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) xs[k] = get_x(sb + k);
 #pragma unroll
             for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);   // (the previous range's M steps are over: every role passed its barrier (C))
-            f32x4 x_n = get_x(sb + KT);
+            Raw4<ET> x_n = get_x(sb + KT);
             __syncthreads();   // (A)
             for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B)

@@ -80,3 +80,12 @@ def test_graph_conv_two_slabs_per_workgroup():
 def test_big_bf16_gemm_32_deep_steps():
     # the 256-row-tile bf16 operator GEMM on its 4-buffer ring of 32-deep steps (the default is 64-deep steps on two buffers)
     run_subset({"STGCN_GEMM_BIG_BK": "32"}, ["tests/test_emu_gctile.py"], "bf16_gemm or tiled_block")
+
+
+def test_layernorm_slab_statistics_prepass():
+    # the stage-per-launch LayerNorm (graphs beyond the fused kernel's 448 nodes; here forced by STGCN_FUSE without bit 2) with its slab
+    # statistics from the one-workgroup-per-slab pre-pass (ln_slab_stats_kernel) that big slabs take, forced for every slab
+    run_subset({"STGCN_FUSE": str(0x7fffffff & ~2), "STGCN_LN_STATS_MIN_CHUNKS": "1"}, [FWD], "17-1-6 or 35-1-5")
+    run_subset({"STGCN_FUSE": str(0x7fffffff & ~2), "STGCN_LN_STATS_MIN_CHUNKS": "1"}, [BWD], "17-2-6")
+    # (bf16: the tiled configurations take this LayerNorm; tests/test_emu_bf16.py::test_tiled_block_bf16_matches_bf16_oracle with the pre-pass forced)
+    run_subset({"STGCN_LN_STATS_MIN_CHUNKS": "1"}, ["tests/test_emu_bf16.py"], "tiled_block_bf16 and 37-2-6")
