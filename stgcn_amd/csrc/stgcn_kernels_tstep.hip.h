@@ -921,14 +921,21 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             for (int k = 0; k < KT; ++k) xs[k] = get_x(sb + k);
 #pragma unroll
             for (int k = 0; k < KT; ++k) put_x(sb + k, xs[k]);   // (the previous range's M steps are over: every role passed its barrier (C))
-            Raw4<ET> x_n = get_x(sb + KT);
+            Raw4<ET> xA = get_x(sb + KT), xB = get_x(sb + KT + 1);   // x tiles requested two steps ahead, in two named sets (see tc1_bwd_kernel)
             __syncthreads();   // (A)
-            for (int i = sb; i < se; ++i) {
+            auto step = [&](int i, Raw4<ET>& xs) __attribute__((always_inline)) {
                 __syncthreads();   // (B)
                 if (i > sb) F(i - 1);
-                put_x(i + KT, x_n);          // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1
-                x_n = get_x(i + KT + 1);
+                put_x(i + KT, xs);           // slot (i + KT) % RING = (i - 1) % RING: last read by step i - 1
+                xs = get_x(i + KT + 2);
+            };
+            int i = sb;
+            step(i, xA);
+            for (++i; i + 1 < se; i += 2) {
+                step(i, xB);
+                step(i + 1, xA);
             }
+            if (i < se) step(i, xB);
             __syncthreads();       // (C)
             F(se - 1);
         }
