@@ -1,0 +1,143 @@
+"""The ST-Conv block as PyTorch dispatcher operators (last row: ``stgcn::stblock_fwd`` / ``stgcn::stblock_bwd``).
+
+``stgcn_amd.ops.st_conv_block`` (what ``layers.STConvBlock`` calls) drives the C ABI with extra state of a training step -- workspace
+caches, LayerNorm hooks between modules, deferred gradient reductions.  The two operators here are the PLAIN form of the same two entry
+points (``stgcn_stblock_forward`` / ``stgcn_stblock_backward``, include/stgcn_hip.h) with tensors in, tensors out, registered with the
+dispatcher so that code that works on ``torch.ops`` (custom passes, ``torch.library.opcheck``, exporters) sees the block as one node:
+
+    y, saved, ws = torch.ops.stgcn.stblock_fwd(x_cl, gso_pad, params, cfg, act, gc_type, droprate, training, seed, offset)
+    dx, *grads   = torch.ops.stgcn.stblock_bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate, training,
+                                               seed, offset, need_dx)
+
+``x_cl``: (B, T, N, c_in) contiguous, float32 or bfloat16; ``params``: the 14 tensors of ``_lib.PARAM_FIELDS`` in order, an EMPTY tensor
+for a parameter the block does not have (``align_conv`` of a temporal layer whose channels already fit; ``model/layers.py:14-23``);
+``cfg`` = [c_in, c0, c1, c2, Kt, Ks, n_vertex]; ``gso_pad`` / ``gso_t_pad`` from ``ops.gso_prepare``.  ``stblock_bwd`` returns 15 tensors
+(dx, then one gradient per parameter slot; empty where there is nothing to return).  ``stblock(x_cl, ...)`` below is the differentiable
+wrapper over the pair.
+
+Dispatch keys: ``CUDA`` is the HIP library.  ``CPU`` is NOT a fallback: it raises unless the bound library is the CPU emulator of the test
+suite (tests/emu), which runs the same kernel sources on host tensors -- the product path needs an MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import _lib, ops
+from ._lib import PARAM_FIELDS, StblockGrads, StblockParams
+
+_NS = "stgcn"
+_libdef = torch.library.Library(_NS, "DEF")
+_libdef.define("stblock_fwd(Tensor x_cl, Tensor gso_pad, Tensor[] params, int[] cfg, str act, str gc_type, float droprate, bool training, "
+               "int seed, int offset) -> (Tensor, Tensor, Tensor)")
+_libdef.define("stblock_bwd(Tensor dy, Tensor x_cl, Tensor gso_t_pad, Tensor y, Tensor saved, Tensor ws, Tensor[] params, int[] cfg, str act, "
+               "str gc_type, float droprate, bool training, int seed, int offset, bool need_dx) -> Tensor[]")
+
+
+def _cfg(cfg: Sequence[int], act: str, gc_type: str, droprate: float) -> ops.BlockConfig:
+    if len(cfg) != 7:
+        raise ValueError("cfg = [c_in, c0, c1, c2, Kt, Ks, n_vertex]")
+    c_in, c0, c1, c2, Kt, Ks, n = (int(v) for v in cfg)
+    return ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=n, c_in=c_in, channels=(c0, c1, c2), act_func=act, graph_conv_type=gc_type,
+                           droprate=float(droprate))
+
+
+def _params(params: Sequence[torch.Tensor], dev) -> List:
+    if len(params) != len(PARAM_FIELDS):
+        raise ValueError(f"params: expected {len(PARAM_FIELDS)} tensors in the order {PARAM_FIELDS}")
+    out = []
+    for name, p in zip(PARAM_FIELDS, params):
+        if p.numel() == 0:
+            out.append(None)
+            continue
+        if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+            raise ValueError(f"params.{name}: expected a contiguous float32 tensor on {dev}")
+        out.append(p.detach())
+    return out
+
+
+def _fwd(x_cl, gso_pad, params, cfg, act, gc_type, droprate, training, seed, offset):
+    ops._check_device(x_cl, "x_cl", activation=True)
+    if x_cl.dim() != 4 or not x_cl.is_contiguous():
+        raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
+    L = _lib.lib()
+    bc = _cfg(cfg, act, gc_type, droprate)
+    B, T, N, c_in = x_cl.shape
+    if N != bc.n_vertex or c_in != bc.c_in:
+        raise ValueError(f"x_cl is {tuple(x_cl.shape)}, cfg says N={bc.n_vertex}, c_in={bc.c_in}")
+    desc = ops.make_desc(bc, B, T, bool(training), True, dtype=x_cl.dtype)
+    plan = ops.query_plan(desc)
+    ps = _params(params, x_cl.device)
+    y = torch.empty(B, plan.T2, N, bc.channels[2], dtype=x_cl.dtype, device=x_cl.device)
+    saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=x_cl.device)
+    ws = torch.empty(plan.ws_floats, dtype=torch.float32, device=x_cl.device)
+    pst = ops._param_struct(StblockParams, ps)
+    L.check(L.dll.stgcn_stblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_pad.data_ptr(), y.data_ptr(), saved.data_ptr(),
+                                        ws.data_ptr(), int(seed), int(offset), None, ops._stream_of(x_cl)), "stgcn_stblock_forward")
+    return y, saved, ws
+
+
+def _bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate, training, seed, offset, need_dx):
+    ops._check_device(x_cl, "x_cl", activation=True)
+    L = _lib.lib()
+    bc = _cfg(cfg, act, gc_type, droprate)
+    B, T, N, c_in = x_cl.shape
+    desc = ops.make_desc(bc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
+    ps = _params(params, x_cl.device)
+    c0, c1, c2 = bc.channels
+    used = {"tc1_aw": c_in > c0, "tc1_ab": c_in > c0, "al_w": c0 > c1, "al_b": c0 > c1, "tc2_aw": c1 > c2, "tc2_ab": c1 > c2}
+    grads = [torch.empty_like(p) if (p is not None and used.get(n, True)) else None for n, p in zip(PARAM_FIELDS, ps)]
+    dy = dy.contiguous()
+    if dy.dtype != x_cl.dtype:
+        dy = dy.to(x_cl.dtype)
+    dx = torch.empty_like(x_cl) if need_dx else None
+    pst = ops._param_struct(StblockParams, ps)
+    gst = ops._param_struct(StblockGrads, grads)
+    L.check(L.dll.stgcn_stblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(), y.data_ptr(),
+                                              saved.data_ptr(), ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
+                                              int(seed), int(offset), None, None, ops._stream_of(x_cl)), "stgcn_stblock_backward")
+    empty = x_cl.new_empty(0, dtype=torch.float32)
+    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else empty for g in grads]
+
+
+def _cpu_guard(fn):
+    def impl(*args):
+        if not _lib.lib().is_emulator:
+            raise RuntimeError("stgcn::stblock_* have no CPU implementation: the HIP library (MI355X) is the only product path")
+        return fn(*args)
+    return impl
+
+
+_libimpl_cuda = torch.library.Library(_NS, "IMPL", "CUDA")
+_libimpl_cuda.impl("stblock_fwd", _fwd)
+_libimpl_cuda.impl("stblock_bwd", _bwd)
+_libimpl_cpu = torch.library.Library(_NS, "IMPL", "CPU")
+_libimpl_cpu.impl("stblock_fwd", _cpu_guard(_fwd))
+_libimpl_cpu.impl("stblock_bwd", _cpu_guard(_bwd))
+
+
+class _Block(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, gso_pad, gso_t_pad, cfg, act, gc_type, droprate, training, seed, offset, *params):
+        y, saved, ws = torch.ops.stgcn.stblock_fwd(x_cl, gso_pad, [p.detach() for p in params], cfg, act, gc_type, droprate, training, seed, offset)
+        ctx.save_for_backward(x_cl, gso_t_pad, y, saved, ws, *params)
+        ctx.meta = (list(cfg), act, gc_type, droprate, training, seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, gso_t_pad, y, saved, ws, *params = ctx.saved_tensors
+        cfg, act, gc_type, droprate, training, seed, offset = ctx.meta
+        out = torch.ops.stgcn.stblock_bwd(dy, x_cl, gso_t_pad, y, saved, ws, [p.detach() for p in params], cfg, act, gc_type, droprate, training,
+                                          seed, offset, bool(ctx.needs_input_grad[0]))
+        dx = out[0] if out[0].numel() else None
+        grads = [g if (g.numel() and ctx.needs_input_grad[10 + i]) else None for i, g in enumerate(out[1:])]
+        return (dx, None, None, None, None, None, None, None, None, None, *grads)
+
+
+def stblock(x_cl: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tensor, params: Sequence[torch.Tensor], cfg: Sequence[int], act: str,
+            gc_type: str, droprate: float, training: bool, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """Differentiable ST-Conv block over the two dispatcher operators (channels-last in, channels-last out)."""
+    return _Block.apply(x_cl, gso_pad, gso_t_pad, list(cfg), act, gc_type, float(droprate), bool(training), int(seed), int(offset), *params)
