@@ -1,4 +1,5 @@
-"""The ST-Conv block as PyTorch dispatcher operators (last row: ``stgcn::stblock_fwd`` / ``stgcn::stblock_bwd``).
+"""The ST-Conv block and the output head as PyTorch dispatcher operators (last row: ``stgcn::stblock_fwd`` /
+``stgcn::stblock_bwd``, ``stgcn::outblock_fwd`` / ``stgcn::outblock_bwd``).
 
 ``stgcn_amd.ops.st_conv_block`` (what ``layers.STConvBlock`` calls) drives the C ABI with extra state of a training step -- workspace
 caches, LayerNorm hooks between modules, deferred gradient reductions.  The two operators here are the PLAIN form of the same two entry
@@ -105,9 +106,84 @@ def _bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate,
 def _cpu_guard(fn):
     def impl(*args):
         if not _lib.lib().is_emulator:
-            raise RuntimeError("stgcn::stblock_* have no CPU implementation: the HIP library (MI355X) is the only product path")
+            raise RuntimeError("stgcn::* operators have no CPU implementation: the HIP library (MI355X) is the only product path")
         return fn(*args)
     return impl
+
+
+# ---- OutputBlock (model/layers.py:267-284): stgcn::outblock_fwd / outblock_bwd ----------------------------------------------------------
+# out, saved, ws = torch.ops.stgcn.outblock_fwd(x_cl, params, [c_in, c0, c1, end_channel, Ko, n_vertex], act, droprate, training, seed, offset)
+# dx, *grads     = torch.ops.stgcn.outblock_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_dx)
+# params: the 10 tensors of _lib.HEAD_PARAM_FIELDS (empty = absent); out: (B, T - Ko + 1, N) float32.
+_libdef.define("outblock_fwd(Tensor x_cl, Tensor[] params, int[] cfg, str act, float droprate, bool training, int seed, int offset) "
+               "-> (Tensor, Tensor, Tensor)")
+_libdef.define("outblock_bwd(Tensor dout, Tensor x_cl, Tensor saved, Tensor ws, Tensor[] params, int[] cfg, str act, float droprate, "
+               "bool training, bool need_dx) -> Tensor[]")
+
+
+def _head_cfg(cfg: Sequence[int], act: str, droprate: float) -> ops.HeadConfig:
+    if len(cfg) != 6:
+        raise ValueError("cfg = [c_in, c0, c1, end_channel, Ko, n_vertex]")
+    c_in, c0, c1, c_end, Ko, n = (int(v) for v in cfg)
+    hc = ops.HeadConfig(Ko=Ko, n_vertex=n, c_in=c_in, channels=(c0, c1), end_channel=c_end, act_func=act, droprate=float(droprate))
+    if not ops.head_supported(hc):
+        raise ValueError(f"OutputBlock plan {cfg} is not covered by the HIP operator (INTEGRATION.md section B2)")
+    return hc
+
+
+def _head_params(params: Sequence[torch.Tensor], dev) -> List:
+    from ._lib import HEAD_PARAM_FIELDS
+    if len(params) != len(HEAD_PARAM_FIELDS):
+        raise ValueError(f"params: expected {len(HEAD_PARAM_FIELDS)} tensors in the order {HEAD_PARAM_FIELDS}")
+    out = []
+    for name, p in zip(HEAD_PARAM_FIELDS, params):
+        if p.numel() == 0:
+            out.append(None)
+            continue
+        if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+            raise ValueError(f"params.{name}: expected a contiguous float32 tensor on {dev}")
+        out.append(p.detach())
+    return out
+
+
+def _head_fwd(x_cl, params, cfg, act, droprate, training, seed, offset):
+    ops._check_device(x_cl, "x_cl", activation=True)
+    if x_cl.dim() != 4 or not x_cl.is_contiguous():
+        raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
+    L = _lib.lib()
+    hc = _head_cfg(cfg, act, droprate)
+    B, T, N, c_in = x_cl.shape
+    desc = ops.make_head_desc(hc, B, T, bool(training), True, dtype=x_cl.dtype)
+    plan = ops.query_head_plan(desc)
+    ps = _head_params(params, x_cl.device)
+    out = torch.empty(B, plan.T1, N, dtype=torch.float32, device=x_cl.device)
+    saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=x_cl.device)
+    ws = torch.empty(plan.ws_floats, dtype=torch.float32, device=x_cl.device)
+    pst = ops._head_struct(_lib.OutblockParams, ps)
+    L.check(L.dll.stgcn_outblock_forward(C.byref(desc), C.byref(pst), x_cl.data_ptr(), out.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+                                         int(seed), int(offset), None, ops._stream_of(x_cl)), "stgcn_outblock_forward")
+    return out, saved, ws
+
+
+def _head_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_dx):
+    from ._lib import HEAD_PARAM_FIELDS
+    ops._check_device(x_cl, "x_cl", activation=True)
+    L = _lib.lib()
+    hc = _head_cfg(cfg, act, droprate)
+    B, T, N, c_in = x_cl.shape
+    desc = ops.make_head_desc(hc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
+    ps = _head_params(params, x_cl.device)
+    used = {"tc_aw": c_in > hc.channels[0], "tc_ab": c_in > hc.channels[0]}
+    grads = [torch.empty_like(p) if (p is not None and used.get(n, True)) else None for n, p in zip(HEAD_PARAM_FIELDS, ps)]
+    dout = dout.contiguous().float()
+    dx = torch.empty_like(x_cl) if need_dx else None
+    pst = ops._head_struct(_lib.OutblockParams, ps)
+    gst = ops._head_struct(_lib.OutblockGrads, grads)
+    L.check(L.dll.stgcn_outblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+                                               C.byref(gst), None if dx is None else dx.data_ptr(), None, ops._stream_of(x_cl)),
+            "stgcn_outblock_backward")
+    empty = x_cl.new_empty(0, dtype=torch.float32)
+    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else empty for g in grads]
 
 
 _libimpl_cuda = torch.library.Library(_NS, "IMPL", "CUDA")
@@ -116,6 +192,10 @@ _libimpl_cuda.impl("stblock_bwd", _bwd)
 _libimpl_cpu = torch.library.Library(_NS, "IMPL", "CPU")
 _libimpl_cpu.impl("stblock_fwd", _cpu_guard(_fwd))
 _libimpl_cpu.impl("stblock_bwd", _cpu_guard(_bwd))
+_libimpl_cuda.impl("outblock_fwd", _head_fwd)
+_libimpl_cuda.impl("outblock_bwd", _head_bwd)
+_libimpl_cpu.impl("outblock_fwd", _cpu_guard(_head_fwd))
+_libimpl_cpu.impl("outblock_bwd", _cpu_guard(_head_bwd))
 
 
 class _Block(torch.autograd.Function):
@@ -141,3 +221,28 @@ def stblock(x_cl: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tensor, 
             gc_type: str, droprate: float, training: bool, seed: int = 0, offset: int = 0) -> torch.Tensor:
     """Differentiable ST-Conv block over the two dispatcher operators (channels-last in, channels-last out)."""
     return _Block.apply(x_cl, gso_pad, gso_t_pad, list(cfg), act, gc_type, float(droprate), bool(training), int(seed), int(offset), *params)
+
+
+class _Head(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, cfg, act, droprate, training, seed, offset, *params):
+        out, saved, ws = torch.ops.stgcn.outblock_fwd(x_cl, [p.detach() for p in params], cfg, act, droprate, training, seed, offset)
+        ctx.save_for_backward(x_cl, saved, ws, *params)
+        ctx.meta = (list(cfg), act, droprate, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_cl, saved, ws, *params = ctx.saved_tensors
+        cfg, act, droprate, training = ctx.meta
+        res = torch.ops.stgcn.outblock_bwd(dout, x_cl, saved, ws, [p.detach() for p in params], cfg, act, droprate, training,
+                                           bool(ctx.needs_input_grad[0]))
+        dx = res[0] if res[0].numel() else None
+        grads = [g if (g.numel() and ctx.needs_input_grad[7 + i]) else None for i, g in enumerate(res[1:])]
+        return (dx, None, None, None, None, None, None, *grads)
+
+
+def outblock(x_cl: torch.Tensor, params: Sequence[torch.Tensor], cfg: Sequence[int], act: str, droprate: float, training: bool,
+             seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """Differentiable OutputBlock over the two dispatcher operators: (B, T, N, c_in) channels-last in, (B, T - Ko + 1, N) out."""
+    return _Head.apply(x_cl, list(cfg), act, float(droprate), bool(training), int(seed), int(offset), *params)

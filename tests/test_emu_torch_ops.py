@@ -77,3 +77,33 @@ def test_plain_operator_call_and_cpu_key_is_not_a_fallback():
                 torch.ops.stgcn.stblock_fwd(x_cl, gp, params, [64, 64, 16, 64, 3, 3, 17], "glu", "cheb_graph_conv", 0.5, False, 0, 0)
         finally:
             bind_emulator()
+
+
+def test_head_operators_equal_the_module_path():
+    from oracle import stgcn_oracle as orc
+    bind_emulator()
+    c_in, channels, Ko, N, B, T, act = 64, (128, 128), 4, 21, 2, 4, "glu"
+    cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=Ko, act_func=act, droprate=0.5, blocks=[[c_in], list(channels), [1]])
+    p = {k: v for k, v in orc.random_params(cfg, N, seed=5, dtype=torch.float32).items() if k.startswith("output.")}
+    names = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight",
+             "tmp_conv1.align.align_conv.bias", "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    rs = np.random.RandomState(2)
+    x = torch.from_numpy(rs.standard_normal((B, c_in, T, N)).astype(np.float32))
+    dout = torch.from_numpy(rs.standard_normal((B, 1, T - Ko + 1, N)).astype(np.float32))
+    hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=c_in, channels=channels, end_channel=1, act_func=act, droprate=0.5)
+    pm = [p["output." + n].clone().requires_grad_(True) for n in names]
+    xm = x.clone().requires_grad_(True)
+    om = ops.output_block(xm, hcfg, pm, True, 77, 5, ops.WorkspaceCache())
+    om.backward(dout)
+    po = [p["output." + n].clone().requires_grad_(True) for n in names]
+    xo = x.permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    oo = torch_ops.outblock(xo, po, [c_in, channels[0], channels[1], 1, Ko, N], act, 0.5, True, 77, 5)
+    oo.backward(dout[:, 0])
+    assert torch.equal(oo, om[:, 0])
+    assert torch.equal(xo.grad, xm.grad.permute(0, 2, 3, 1))
+    for n, a, b in zip(names, pm, po):
+        if a.grad is None:
+            assert b.grad is None, n
+        else:
+            assert torch.equal(a.grad, b.grad), n
+    assert "-> (Tensor, Tensor, Tensor)" in str(torch.ops.stgcn.outblock_fwd.default._schema)
