@@ -222,6 +222,18 @@ template <typename ET> __device__ __forceinline__ f32x4 cvt4(const Raw4<ET>& r) 
     if constexpr (sizeof(ET) == 2) return unpack_bf16x4(r.v);
     else return r.v;
 }
+template <typename ET> struct Raw1 { float v; };               // one element, raw (see Raw4)
+template <> struct Raw1<bf16> { unsigned short v; };
+template <typename ET> __device__ __forceinline__ Raw1<ET> ldraw1(const ET* p) {
+    Raw1<ET> r;
+    if constexpr (sizeof(ET) == 2) r.v = *reinterpret_cast<const unsigned short*>(p);
+    else r.v = *reinterpret_cast<const float*>(p);
+    return r;
+}
+template <typename ET> __device__ __forceinline__ float cvt1(const Raw1<ET>& r) {
+    if constexpr (sizeof(ET) == 2) return __builtin_bit_cast(float, (unsigned)r.v << 16);
+    else return r.v;
+}
 // 8 consecutive elements (16 B of bf16: one dwordx4 access; 32 B of fp32: two)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ldx8(const float* p, f32x4& a, f32x4& b) { a = ld4(p); b = ld4(p + 4); }

@@ -1025,26 +1025,34 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
     const ET* const dA_ = et_ptr<ET>(a.dA);
     ET* const dZ_ = et_ptr<ET>(a.dZ);
     const size_t xbs = (size_t)tap_bstride(a.ts);
+    // dA rows (one 16-byte load per thread) and the K valid taps of x (one scalar load for the first 64*K threads) of a tile are requested
+    // together, raw, ONE TILE AHEAD (unconditional: clamped rows, masked where they are stored); the Align weights of the wave's column
+    // tile are stationary.  Loaded where they are used, every tile waited for its dA / x round trip and then for the weight fragment's.
+    const int ra = tid >> 2, qa = tid & 3;
+    const int rx = tid < kTileRows * K ? tid / K : kTileRows - 1, kx = tid < kTileRows * K ? tid - rx * K : 0;
+    auto request = [&](long t, Raw4<ET>& da, Raw1<ET>& xv) __attribute__((always_inline)) {
+        const long row0 = (t < tiles ? t : tiles - 1) * kTileRows;
+        const long Ra = row0 + ra < a.rows ? row0 + ra : a.rows - 1, Rx = row0 + rx < a.rows ? row0 + rx : a.rows - 1;
+        da = ldraw4(dA_ + (size_t)Ra * 16 + 4 * qa);
+        const unsigned Ru = (unsigned)Rx, b = Ru / per_b, rem = Ru - b * per_b;
+        const int tap = kx / a.ts.C, ch = kx - tap * a.ts.C;
+        xv = ldraw1(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
+    };
+    PreW<1, 1> waw;
+    pre_load_weights<1, 1>(waw, a.WaT, 1, wave, 4);
+    Raw4<ET> da_n;
+    Raw1<ET> xv_n;
+    request(blockIdx.x, da_n, xv_n);
     for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long row0 = t * kTileRows;
         __syncthreads();
-        // dA rows (one 16-byte load per thread) and the K valid taps of x (one scalar load for the first 64*K threads) are
-        // requested together; the 16 - K padding columns of the im2col tile are zero-filled meanwhile
-        const int ra = tid >> 2, qa = tid & 3;
-        const f32x4 dav = row0 + ra < a.rows ? ldx4(dA_ + (size_t)(row0 + ra) * 16 + 4 * qa) : zero4();
-        float xv0 = 0.f;
-        const int rx = tid / K, kx = tid - rx * K;
-        if (tid < kTileRows * K && row0 + rx < a.rows) {
-            const unsigned Ru = (unsigned)(row0 + rx), b = Ru / per_b, rem = Ru - b * per_b;
-            const int tap = kx / a.ts.C, ch = kx - tap * a.ts.C;
-            xv0 = ldx1(xsrc + ((size_t)b * xbs + rem + (size_t)tap * a.ts.N) * a.ts.C + ch);
-        }
         for (int idx = tid; idx < kTileRows * (16 - K); idx += kThreads) {
             const int r = idx / (16 - K), k = K + idx - r * (16 - K);
             xt[r * LDX + k] = 0.f;
         }
-        st4(dAt + ra * LDA + 4 * qa, dav);
-        if (tid < kTileRows * K) xt[rx * LDX + kx] = xv0;
+        st4(dAt + ra * LDA + 4 * qa, row0 + ra < a.rows ? cvt4(da_n) : zero4());
+        if (tid < kTileRows * K) xt[rx * LDX + kx] = row0 + rx < a.rows ? cvt1(xv_n) : 0.f;
+        request(t + gridDim.x, da_n, xv_n);   // (past the last tile: a valid address, never used)
         __syncthreads();
         {
             const int rg = tid >> 4, jj = tid & 15;
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         f32x4 acc[4][1];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][0] = zero4();
-        seg_mma<4, 1, ET>(acc, dAt, LDA, 0, 1, a.WaT, 0, 1, wave, 4);
+        pre_mma<4, 1, 1, ET>(acc, dAt, LDA, 0, 1, waw);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
