@@ -737,9 +737,9 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
         static const int off = getenv("STGCN_GCBWD2") ? atoi(getenv("STGCN_GCBWD2")) == 0 : 0;
         static const int force_parts = getenv("STGCN_GCBWD2_PARTS") ? atoi(getenv("STGCN_GCBWD2_PARTS")) : 0;
         // One node tile per tile wave (<= 8 tile waves per workgroup), and the whole grid resident in ONE round: every part re-stages the
-        // slab's dY and re-forms all G_k, so a grid that needs more rounds than the slab kernel costs more than it returns (measured at
-        // the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
-        const size_t lds2 = ((size_t)(a.Ks - 1) * 16 * (a.NP + 4) + (size_t)a.NP * 20) * sizeof(float);
+        // slab's dY and re-forms all G_k, so a grid of SEVERAL parts that needs more rounds than the slab kernel costs more than it returns
+        // (measured at the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
+        const size_t lds2 = ((size_t)(a.Ks - 1) * 16 * (a.NP + 4) + (size_t)a.NP * 20 + (size_t)(a.Ks + 1) * 16 * 20) * sizeof(float);   // (+ the job waves' transposition tiles)
         if (!off && lds2 <= 150 * 1024 && HT <= 64) {
             int best = 0;
             for (int parts = (HT + 7) / 8; parts <= HT && !force_parts; ++parts) {
@@ -749,6 +749,9 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
                 if (a.slabs * parts <= cap) best = parts;
             }
             if (force_parts > 0 && force_parts <= HT && (HT + force_parts - 1) / force_parts <= 24) best = force_parts;   // (tuning: up to 3 tiles per wave)
+            // no split fits one round (C3: 640 slabs): ONE part per slab still beats the kernel below since the job waves fetch whole tiles
+            // (r3-49: 54.9 / 38.8 -> 47.5 / 33.5 us; 70 KB of LDS = two workgroups per CU instead of one)
+            if (!best && !force_parts && HT <= 24) best = 1;
             if (best > 0) {
                 const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = (a.Ks + 1 + best - 1) / best;
                 a.parts = best;

@@ -222,6 +222,14 @@ template <typename ET> __device__ __forceinline__ f32x4 cvt4(const Raw4<ET>& r) 
     if constexpr (sizeof(ET) == 2) return unpack_bf16x4(r.v);
     else return r.v;
 }
+// orders LDS accesses between the lanes of ONE wave: a wave's LDS instructions execute in order, so the hardware needs nothing; the compiler
+// must not move LDS accesses across this point (and the emulator lets the wave's other lanes catch up here)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename ET> struct Raw1 { float v; };               // one element, raw (see Raw4)
 template <> struct Raw1<bf16> { unsigned short v; };
 template <typename ET> __device__ __forceinline__ Raw1<ET> ldraw1(const ET* p) {

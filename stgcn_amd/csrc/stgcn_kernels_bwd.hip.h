@@ -754,25 +754,50 @@ __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa
         __syncthreads();   // (2) (nothing to wait for: keeps the barrier count of the workgroup)
         float* part = a.part + (size_t)slab * (Ks + 1) * 256;
         for (int kk = prt + P * (w - nwa); kk <= Ks; kk += P * ((THREADS >> 6) - nwa)) {
-            // job kk < Ks: dW_kk = X_kk^T dY (A[m = c][k = node] straight from memory, 64-byte segments) ; kk == Ks: db via A = 1
-            const ET* Xsl = kk < Ks ? (kk == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(kk - 1) * a.slabs * N * 16) + (size_t)slab * N * 16 : nullptr;
-            auto fetchA = [&](int kc) __attribute__((always_inline)) {
-                f32x4 v = {1.f, 1.f, 1.f, 1.f};
-                if (Xsl) {
+            // job kk < Ks: dW_kk = X_kk^T dY ; kk == Ks: db via A = 1.  A[m = c][k = node]: a lane needs ONE channel of 4 consecutive nodes --
+            // 4 scalar loads 16 elements apart, and requested one chunk ahead with ldx1 (which converts at the load) that was no request
+            // ahead at all: every chunk waited for 4 dependent round trips (C3: the job waves made this kernel 99 us against 55 for the
+            // one-workgroup-per-slab form, r3-48).  Now a chunk = the 16 x 16 tile as ONE 4-element load per lane (node lane >> 2, channels
+            // 4 (lane & 3) ..), raw, in a ring of 4 chunks with static indices; it is transposed through a wave-private LDS tile when its
+            // turn comes.
+            f32x4 c0 = zero4(), c1 = zero4();
+            if (kk < Ks) {
+                const ET* const Xsl = (kk == 0 ? et_ptr<ET>(a.X0) : et_ptr<ET>(a.Xk) + (size_t)(kk - 1) * a.slabs * N * 16) + (size_t)slab * N * 16;
+                float* const TJ = dYs + NP * LDY + (w - nwa) * (16 * 20);   // [16 nodes][20]
+                constexpr int RG = 4;
+                const int jn = lane >> 2, jc = (lane & 3) * 4;
+                auto req = [&](int kc) __attribute__((always_inline)) {
+                    const int n = kc * 16 + jn;
+                    return ldraw4(Xsl + (size_t)(n < N ? n : N - 1) * 16 + jc);
+                };
+                Raw4<ET> xr[RG];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int n = kc * 16 + 4 * g + s;
-                        v[s] = n < N ? ldx1(Xsl + (size_t)n * 16 + l15) : 0.f;
+                for (int d = 0; d < RG; ++d) xr[d] = req(d < KCH ? d : KCH - 1);
+                auto chunk = [&](int kc, int d, auto load_tag) __attribute__((always_inline)) {
+                    st4(TJ + jn * 20 + jc, kc * 16 + jn < N ? cvt4(xr[d]) : zero4());
+                    if (decltype(load_tag)::value) xr[d] = req(kc + RG);
+                    wave_lds_sync();
+                    const f32x4 af = gather4(TJ + (4 * g) * 20 + l15, 20);   // X[node 4g + s][c = l15]
+                    MM::mma_split(MM::cvt(af), MM::cvt(gather4(dYs + (kc * 16 + 4 * g) * LDY + l15, LDY)), c0, c1);
+                    wave_lds_sync();   // (the next chunk overwrites the tile)
+                };
+                int kc0 = 0;
+                for (; kc0 + 2 * RG <= KCH; kc0 += RG) {
+#pragma unroll
+                    for (int d = 0; d < RG; ++d) chunk(kc0 + d, d, std::true_type());
+                }
+                for (; kc0 < KCH; kc0 += RG) {
+#pragma unroll
+                    for (int d = 0; d < RG; ++d) {
+                        if (kc0 + d < KCH) {
+                            if (kc0 + d + RG < KCH) chunk(kc0 + d, d, std::true_type());
+                            else chunk(kc0 + d, d, std::false_type());
+                        }
                     }
                 }
-                return v;
-            };
-            f32x4 c0 = zero4(), c1 = zero4();
-            f32x4 an = fetchA(0);
-            for (int kc = 0; kc < KCH; ++kc) {
-                const f32x4 af = an;
-                if (kc + 1 < KCH) an = fetchA(kc + 1);
-                MM::mma_split(MM::cvt(af), MM::cvt(gather4(dYs + (kc * 16 + 4 * g) * LDY + l15, LDY)), c0, c1);
+            } else {
+                const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                for (int kc = 0; kc < KCH; ++kc) MM::mma_split(MM::cvt(one), MM::cvt(gather4(dYs + (kc * 16 + 4 * g) * LDY + l15, LDY)), c0, c1);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[kk * 256 + (4 * g + r) * 16 + l15] = c0[r] + c1[r];

@@ -594,14 +594,6 @@ __device__ __forceinline__ void barrier_only() {
 #endif
 }
 
-// orders LDS accesses between the lanes of ONE wave: a wave's LDS instructions execute in order, so the hardware needs nothing; the compiler
-// must not move LDS accesses across this point (and the emulator lets the wave's other lanes catch up here)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int NT, typename ET, int BK>
 __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a) {
     extern __shared__ float stgcn_smem[];
