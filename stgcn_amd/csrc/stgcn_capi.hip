@@ -602,7 +602,7 @@ int launch_gconv_fwd_tiled(const GconvFwdArgs& a, hipStream_t st) {
     r.X0 = a.A; r.Xk = a.Xk; r.W = a.W; r.bias = a.bias; r.G = a.G; r.rows = a.slabs * a.N; r.kstride = ks; r.terms = a.Ks; r.kipf = a.kipf;
     const long tiles = (r.rows + 15) / 16;
     const long wgs = (tiles + 3) / 4;
-    STGCN_LAUNCH_ET("gconv_rows_fwd", st, (gconv_rows_fwd_kernel<ET>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, r);
+    STGCN_LAUNCH_ET("gconv_rows_fwd", st, (gconv_rows_fwd_kernel<ET>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), (size_t)4 * 16 * 20 * sizeof(float), r);
     return STGCN_OK;
 }
 // backward: row pass (g_k, parameter-gradient partials), then dA = sum_k T_k(L^T) g_k by the Clenshaw recurrence
@@ -618,7 +618,7 @@ int launch_gconv_bwd_tiled(const GconvBwdArgs& a, hipStream_t st) {
     r.dY = a.dY; r.X0 = a.X0; r.Xk = a.Xk; r.W = a.W; r.part = a.part; r.rows = a.slabs * a.N; r.kstride = ks; r.gstride = ks;
     r.Gk = K == 0 ? a.dA : a.Gk;   // a single term: g_0 (+ dY) is dA itself
     r.terms = a.Ks; r.kipf = a.kipf; r.tiles_per_wg = a.tiles_per_wg;
-    STGCN_LAUNCH_ET("gconv_rows_bwd", st, (gconv_rows_bwd_kernel<ET>), dim3((unsigned)a.wgs), dim3(256), (size_t)4 * (a.Ks + 1) * 256 * sizeof(float), r);
+    STGCN_LAUNCH_ET("gconv_rows_bwd", st, (gconv_rows_bwd_kernel<ET>), dim3((unsigned)a.wgs), dim3(256), gc_rows_bwd_lds_bytes(r.terms), r);
     if (K == 0) return STGCN_OK;
     auto gk = [&](int k) { return a.Gk + (size_t)k * ksf; };
     if (g_gc_precision > 0 || g_bf16) {   // bf16 / bf16x3 products: b_{k+1} travels in operand form from epilogue to epilogue

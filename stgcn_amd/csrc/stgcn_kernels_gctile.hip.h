@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256) void gconv_rows_fwd_kernel(GcRowsFwdArgs a) {
         }
     }
     const float bb = a.bias ? a.bias[l15] : 0.f;
+    extern __shared__ float stgcn_smem[];          // [4 waves][16][20]
+    float* const To = stgcn_smem + w * (16 * 20);
     const long tiles = (a.rows + 15) >> 4;
     for (long tile = (long)blockIdx.x * 4 + w; tile < tiles; tile += (long)gridDim.x * 4) {
         const long row0 = tile << 4, row = row0 + l15;
@@ -198,22 +200,25 @@ __global__ __launch_bounds__(256) void gconv_rows_fwd_kernel(GcRowsFwdArgs a) {
                 xr[k] = ldraw4(Xs + (size_t)rowc * 16 + 4 * g);   // A[row = l15][c = 4g + s]
             }
         }
-        float res[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long rr = row0 + 4 * g + r;   // D[row = 4g + r][j = l15]
-            res[r] = ldx1(X0_ + (size_t)(rr < a.rows ? rr : a.rows - 1) * 16 + l15);
-        }
+        Raw4<ET> x0r = xr[0];
+        if (a.kipf) x0r = ldraw4(X0_ + (size_t)rowc * 16 + 4 * g);   // (the residual; term 0 of the Kipf conv is not a product)
         f32x4 y = zero4();
 #pragma unroll
         for (int k = 0; k < kGcMaxTerms; ++k) {
             if (k < a.terms && !(a.kipf && k == 0)) y = MM::mma(MM::cvt(in ? cvt4(xr[k]) : zero4()), MM::cvt(wf[k]), y);
         }
+        // D[row = 4g + r][j = l15] -> row major through the wave's LDS tile: one 4-element store per lane, the residual is the A fragment of term 0
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long rr = row0 + 4 * g + r;
-            if (rr < a.rows) stx1(G_ + (size_t)rr * 16 + l15, fmaxf(y[r] + bb + res[r], 0.f));
+        for (int r = 0; r < 4; ++r) To[(4 * g + r) * 20 + l15] = y[r] + bb;
+        wave_lds_sync();
+        const f32x4 o = ld4(To + l15 * 20 + 4 * g) + cvt4(x0r);
+        if (in) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(o[i], 0.f);
+            stx4(G_ + (size_t)row * 16 + 4 * g, v);
         }
+        wave_lds_sync();   // (the next tile overwrites it)
     }
 }
 
@@ -236,6 +241,11 @@ struct GcRowsBwdArgs {
     int terms, kipf, tiles_per_wg;
 };
 
+constexpr int kGcRowsTile = 3 * 16 * 20;   // floats of a wave's three 16 x 16 transposition tiles (row stride 20) in gconv_rows_bwd_kernel
+inline size_t gc_rows_bwd_lds_bytes(int terms) {   // the tiles alias the [4][(terms + 1) * 256] reduction buffer of the kernel's end
+    const size_t red = (size_t)4 * (terms + 1) * 256, tl = (size_t)4 * kGcRowsTile;
+    return (red > tl ? red : tl) * sizeof(float);
+}
 template <typename ET>
 __global__ __launch_bounds__(256) void gconv_rows_bwd_kernel(GcRowsBwdArgs a) {
     typedef Mma<ET> MM;
@@ -258,39 +268,47 @@ __global__ __launch_bounds__(256) void gconv_rows_bwd_kernel(GcRowsBwdArgs a) {
     const long t0 = (long)blockIdx.x * a.tiles_per_wg;
     long t1 = t0 + a.tiles_per_wg;
     if (t1 > tiles) t1 = tiles;
+    // Every tensor of a tile moves as ONE 4-element access per lane in the fragment layout that is also row major (row l15, channels
+    // 4g .. 4g + 3: a wave instruction covers the 16 x 16 tile contiguously); the transposed operands (B = dY with the rows as K, A = X_k^T)
+    // and the G_k tiles (D leaves a lane with one channel of 4 rows) go through wave-private LDS tiles.  Gathered / scattered straight from
+    // memory it was 4 + 4 terms scalar loads and 4 terms scalar stores per tile and lane, each term's round trip waited for in turn.
+    constexpr int LDT = 20;
+    float* const Ty = stgcn_smem + w * kGcRowsTile, * const Tx = Ty + 16 * LDT, * const To = Tx + 16 * LDT;
     for (long tile = t0 + w; tile < t1; tile += 4) {
         const long row0 = tile << 4, row = row0 + l15;
-        const f32x4 ya = row < a.rows ? ldx4(dY_ + (size_t)row * 16 + 4 * g) : zero4();   // A[row = l15][j = 4g + s]
-        f32x4 yb;                                                                          // B[kk = row 4g + s][col = j = l15]
+        const bool in = row < a.rows;
+        const size_t ro = (size_t)(in ? row : a.rows - 1) * 16 + 4 * g;
+        const Raw4<ET> yr = ldraw4(dY_ + ro);
+        Raw4<ET> xr[kGcMaxTerms];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long rr = row0 + 4 * g + s;
-            yb[s] = rr < a.rows ? ldx1(dY_ + (size_t)rr * 16 + l15) : 0.f;
-        }
+        for (int k = 0; k < kGcMaxTerms; ++k)
+            if (k < terms) xr[k] = ldraw4((k == 0 ? X0_ : Xk_ + (size_t)(k - 1) * a.kstride) + ro);
+        const f32x4 ya = in ? cvt4(yr) : zero4();                                          // A[row = l15][j = 4g + s]
+        st4(Ty + l15 * LDT + 4 * g, ya);
+        wave_lds_sync();
+        const f32x4 yb = gather4(Ty + (4 * g) * LDT + l15, LDT);                          // B[kk = row 4g + s][col = j = l15]
         const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
         const typename MM::frag fya = MM::cvt(ya), fyb = MM::cvt(yb);
         db = MM::mma(MM::cvt(ones), fyb, db);
 #pragma unroll
         for (int k = 0; k < kGcMaxTerms; ++k) {
             if (k < terms) {
-                const ET* Xs = k == 0 ? X0_ : Xk_ + (size_t)(k - 1) * a.kstride;
-                f32x4 xa;                                                                  // A[i = l15][kk = row 4g + s]
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const long rr = row0 + 4 * g + s;
-                    xa[s] = rr < a.rows ? ldx1(Xs + (size_t)rr * 16 + l15) : 0.f;
-                }
+                st4(Tx + l15 * LDT + 4 * g, in ? cvt4(xr[k]) : zero4());
+                wave_lds_sync();
+                const f32x4 xa = gather4(Tx + (4 * g) * LDT + l15, LDT);                  // A[i = l15][kk = row 4g + s]
                 f32x4 gk = zero4();
                 MM::mma_2x(MM::cvt(xa), fyb, dw[k], fya, MM::cvt(wt[k]), gk);
-                ET* Go = Gk_ + (size_t)k * a.gstride;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long rr = row0 + 4 * g + r;   // D[row = 4g + r][i = l15]
-                    if (rr < a.rows) stx1(Go + (size_t)rr * 16 + l15, gk[r] + (k == 0 ? yb[r] : 0.f));
-                }
+                for (int r = 0; r < 4; ++r) To[(4 * g + r) * LDT + l15] = gk[r];          // D[row = 4g + r][i = l15]
+                wave_lds_sync();
+                f32x4 o = ld4(To + l15 * LDT + 4 * g);
+                if (k == 0) o += ya;
+                if (in) stx4(Gk_ + (size_t)k * a.gstride + (size_t)row * 16 + 4 * g, o);
+                wave_lds_sync();   // (the next term overwrites both tiles)
             }
         }
     }
+    __syncthreads();   // (the tiles above live in the reduction buffer below)
     // D[i = 4g + r][j = l15] -> slot k, element i * 16 + j
     float* mine = stgcn_smem + w * PS;
 #pragma unroll
