@@ -518,10 +518,15 @@ __global__ __launch_bounds__(WAVES * 64) void tconv_fwd_kernel(TconvFwdArgs a) {
     const int KCHa = Cout >> 4;
     for (int nt = 0; nt < (a.c1 >> 4); ++nt) {
         f32x4 c0 = zero4(), c1v = zero4();
-        for (int kc = 0; kc < KCHa; ++kc) {
-            const f32x4 b = ld4(a.Wap + ((size_t)(nt * KCHa + kc) * 64 + lane) * 4);
-            const f32x4 av = ld4(At + (wv * 16 + l15) * ldh + kc * 16 + 4 * g);
-            MM::mma_split(MM::cvt(av), MM::cvt(b), c0, c1v);
+        f32x4 bw[8];   // the Align weights of this column tile, requested together (Cout <= 128: at most 8 chunks; one L2 round trip, not KCHa)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) bw[kc] = ld4(a.Wap + ((size_t)(nt * KCHa + (kc < KCHa ? kc : KCHa - 1)) * 64 + lane) * 4);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            if (kc < KCHa) {
+                const f32x4 av = ld4(At + (wv * 16 + l15) * ldh + kc * 16 + 4 * g);
+                MM::mma_split(MM::cvt(av), MM::cvt(bw[kc]), c0, c1v);
+            }
         }
         const int col = nt * 16 + l15;
         const float bb = a.ba[col];
