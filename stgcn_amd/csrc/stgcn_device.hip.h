@@ -222,6 +222,15 @@ template <typename ET> __device__ __forceinline__ f32x4 cvt4(const Raw4<ET>& r) 
     if constexpr (sizeof(ET) == 2) return unpack_bf16x4(r.v);
     else return r.v;
 }
+// workgroup barrier that does not wait for outstanding memory operations of the calling wave (the emulator's copies are synchronous)
+__device__ __forceinline__ void barrier_only() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // orders LDS accesses between the lanes of ONE wave: a wave's LDS instructions execute in order, so the hardware needs nothing; the compiler
 // must not move LDS accesses across this point (and the emulator lets the wave's other lanes catch up here)
 __device__ __forceinline__ void wave_lds_sync() {

@@ -603,15 +603,6 @@ __device__ __forceinline__ void wait_vmcnt_le() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
-// workgroup barrier that does not wait for outstanding memory operations of the calling wave (the emulator's copies are synchronous)
-__device__ __forceinline__ void barrier_only() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-
 template <int NT, typename ET, int BK>
 __global__ __launch_bounds__(512) void gso_gemm_bf16_big_kernel(GsoGemmBfArgs a) {
     extern __shared__ float stgcn_smem[];

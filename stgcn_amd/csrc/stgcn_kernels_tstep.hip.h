@@ -1092,16 +1092,35 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
         red[3 * wv + 1] = mean_w;
         red[3 * wv + 2] = m2;
     }
-    __syncthreads();
+    // (the barrier only publishes `red`: it must not wait for the U2 / S2 stores of the tile loop -- __syncthreads() drains vmcnt; and the
+    //  merge is the closed form about the slab mean, two independent sums, instead of a 16-step chain of dependent divisions: the
+    //  statistics phase was 5.6 us of a 23 us launch, r3-58)
     float nn = 0.f, mean = 0.f, M2 = 0.f;
+    if constexpr (NTI == 6) {   // (the 6-tile bf16 form sits at its register limit: the chained merge, which holds fewer values)
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4 * HV; ++k) {
-        const float nw = red[3 * k], mw = red[3 * k + 1], qw = red[3 * k + 2];
-        if (nw > 0.f) {
-            const float d = mw - mean, nt2 = nn + nw;
-            mean += d * (nw / nt2);
-            M2 += qw + d * d * (nn * nw / nt2);
-            nn = nt2;
+        for (int k = 0; k < 4 * HV; ++k) {
+            const float nw = red[3 * k], mw = red[3 * k + 1], qw = red[3 * k + 2];
+            if (nw > 0.f) {
+                const float d = mw - mean, nt2 = nn + nw;
+                mean += d * (nw / nt2);
+                M2 += qw + d * d * (nn * nw / nt2);
+                nn = nt2;
+            }
+        }
+    } else {
+        barrier_only();
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4 * HV; ++k) {
+            nn += red[3 * k];
+            sm += red[3 * k] * red[3 * k + 1];
+        }
+        mean = sm / nn;
+#pragma unroll
+        for (int k = 0; k < 4 * HV; ++k) {
+            const float d = red[3 * k + 1] - mean;
+            M2 += red[3 * k + 2] + red[3 * k] * d * d;
         }
     }
     const float rstd = 1.0f / sqrtf(M2 / nn + a.eps);
