@@ -1467,18 +1467,22 @@ struct LnFwdArgs {
 
 // mean / rstd of one slab from its row partials; all 256 threads must call; red: >= 8 floats of LDS
 __device__ __forceinline__ void slab_stats_from_rows(const float2* rs, int N, int C, float eps, float* red, float& mean, float& rstd) {
-    float sm = 0.f, dummy = 0.f;
-    for (int r = threadIdx.x; r < N; r += kThreads) sm += rs[r].x;
-    block_sum2(sm, dummy, red);
-    mean = sm / (float)N;
-    float m2 = 0.f;
-    dummy = 0.f;
+    // ONE pass and one block reduction: sums about the first row's mean x0 (every row mean is within O(sigma) of the slab mean, so the
+    // correction term below cancels nothing that matters):  mu = x0 + S1 / N ,  M2 = S2 - N C (mu - x0)^2  with
+    // S1 = sum_r (x_r - x0) ,  S2 = sum_r M2_r + C (x_r - x0)^2.  (The two-pass form read the partials twice with a dependent second pass.)
+    const float x0 = rs[0].x;
+    float s1 = 0.f, s2 = 0.f;
     for (int r = threadIdx.x; r < N; r += kThreads) {
         const float2 v = rs[r];
-        m2 += v.y + (float)C * (v.x - mean) * (v.x - mean);
+        const float d = v.x - x0;
+        s1 += d;
+        s2 += v.y + (float)C * d * d;
     }
-    block_sum2(m2, dummy, red);
-    rstd = 1.0f / sqrtf(m2 / ((float)N * (float)C) + eps);
+    block_sum2(s1, s2, red);
+    const float dm = s1 / (float)N;
+    mean = x0 + dm;
+    const float m2 = s2 - (float)N * (float)C * dm * dm;
+    rstd = 1.0f / sqrtf(fmaxf(m2, 0.f) / ((float)N * (float)C) + eps);
 }
 
 // slab statistics once per slab (grid = slabs) for slabs of many chunks: every workgroup of ln_norm_kernel otherwise re-derives them from
