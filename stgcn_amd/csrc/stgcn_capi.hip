@@ -837,6 +837,13 @@ int launch_reduce_list(const char* label, ReduceList& L, hipStream_t st) {
     if (L.overflow) return fail(STGCN_ERR_INVALID, "%s: more than %d reduction jobs in one launch", label, kMaxReduceJobs);
     if (L.nj == 0) return STGCN_OK;
     L.ra.njobs = L.nj;
+    static const bool log_jobs = getenv("STGCN_REDUCE_LOG") != nullptr;   // diagnostic: the partial-sum tables one launch folds
+    if (log_jobs)
+        for (int i = 0; i < L.nj; ++i) {
+            const ReduceJob& j = L.ra.job[i];
+            fprintf(stderr, "[stgcn reduce] %s job %d: %ld elements x %d partials (%.2f MB read), %d workgroups\n", label, i,
+                    (long)j.n0 * j.n1 * j.n2, j.P, 4e-6 * (double)j.n0 * j.n1 * j.n2 * j.P, L.ra.start[i + 1] - L.ra.start[i]);
+        }
     STGCN_LAUNCH(label, st, reduce_kernel, dim3(L.ra.start[L.nj]), dim3(kThreads), kThreads * 4 * sizeof(float), L.ra);
     return STGCN_OK;
 }
