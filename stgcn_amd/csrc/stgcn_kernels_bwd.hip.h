@@ -281,14 +281,31 @@ __global__ __launch_bounds__(256) void ln_bwd_rowstats_kernel(LnBwdArgs a) {
     if (valid && (q & (c4n - 1)) == 0) a.rowstat[slab * a.N + fast_div(q, c4n, pow2_shift(c4n))] = make_float2(s1, s2);
 }
 
-// c1 = mean(g), c2 = mean(g * xhat) of one slab from its row partials (same summation as ln_gate_bwd_kernel's own
-// rebuild: thread-strided partial sums, block_sum2); grid = slabs.  Launched only for big slabs (kLnBigColgroups).
+// c1 = mean(g), c2 = mean(g * xhat) of one slab from its row partials (thread-strided partial sums, block_sum2, like
+// ln_gate_bwd_kernel's own rebuild); grid = slabs.  Launched only for big slabs (kLnBigColgroups).
 __global__ __launch_bounds__(256) void ln_slab_consts_kernel(LnBwdArgs a) {
     extern __shared__ float stgcn_smem[];
     const long slab = blockIdx.x;
     float x = 0.f, y = 0.f;
     const float2* rs = a.rowstat + slab * a.N;
-    for (int r = threadIdx.x; r < a.N; r += kThreads) {
+    int r0 = 0;
+    if ((reinterpret_cast<uintptr_t>(rs) & 15) == 0) {   // two rows per 16-byte load, four loads in flight (as slab_stats_from_rows)
+        const f32x4* rs4 = reinterpret_cast<const f32x4*>(rs);
+        const int N2 = a.N >> 1;
+        f32x4 t0 = zero4(), t1 = zero4();
+        int q = threadIdx.x;
+        for (; q + 3 * kThreads < N2; q += 4 * kThreads) {
+            const f32x4 v0 = rs4[q], v1 = rs4[q + kThreads], v2 = rs4[q + 2 * kThreads], v3 = rs4[q + 3 * kThreads];
+            t0 += v0 + v1;
+            t1 += v2 + v3;
+        }
+        for (; q < N2; q += kThreads) t0 += rs4[q];
+        t0 += t1;
+        x = t0[0] + t0[2];
+        y = t0[1] + t0[3];
+        r0 = N2 * 2;
+    }
+    for (int r = r0 + threadIdx.x; r < a.N; r += kThreads) {
         const float2 v = rs[r];
         x += v.x;
         y += v.y;
