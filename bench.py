@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--replay-times", action="store_true", help="diagnostic: config.replay_ms = GPU time of each of the first steps after a synchronisation")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-resident-series", action="store_true",
                     help="feed (num, 1, n_his, N) window tensors copied per step instead of device-side windows of a resident series")
@@ -336,6 +337,22 @@ def main():
         el = float(t.item())
     loss_val = float(loss.item())
     assert np.isfinite(loss_val), "training diverged"
+    replay_ms = None
+    if args.replay_times:   # diagnostic (after the timed region): the GPU time of each of the first steps after a synchronisation
+        n_ev = min(args.steps, 24)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+        sync()
+        tw0 = time.perf_counter()
+        for i in range(n_ev):
+            ev[i].record()
+            run_step(*batch(step_i))
+            step_i += 1
+        ev[n_ev].record()
+        tw1 = time.perf_counter()
+        sync()
+        tw2 = time.perf_counter()
+        replay_ms = {"gpu_ms_per_step": [round(ev[i].elapsed_time(ev[i + 1]), 4) for i in range(n_ev)],
+                     "host_enqueue_ms": round(1e3 * (tw1 - tw0), 3), "host_total_ms": round(1e3 * (tw2 - tw0), 3)}
     n_gpus = torch.distributed.get_world_size() if (world > 1 and torch.distributed.is_initialized()) else 1
 
     out = {"metric": cfg["metric"], "value": round(B_LOCAL * world * args.steps / el, 2),
@@ -345,6 +362,7 @@ def main():
            "config": {"workload": cfg["workload"], "graph": gso_src, "global_batch": B_LOCAL * world, "parallelism": f"dp{world}",
                       "output_block": "fused HIP path (stgcn_outblock_*)", "final_loss": round(loss_val, 5),
                       "launch": "hipGraph replay" if use_graph else "eager", "graph_error": graph_err,
+                      **({"replay_ms": replay_ms} if replay_ms else {}),
                       "chains": args.chains if use_graph else 1,
                       "backward_products": ("bf16" if DTYPE == "bf16" else args.bwd_precision),
                       "operator_products": ("bf16" if DTYPE == "bf16" else args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32"),
