@@ -1470,6 +1470,8 @@ __device__ __forceinline__ void slab_stats_from_rows(const float2* rs, int N, in
     // ONE pass and one block reduction: sums about the first row's mean x0 (every row mean is within O(sigma) of the slab mean, so the
     // correction term below cancels nothing that matters):  mu = x0 + S1 / N ,  M2 = S2 - N C (mu - x0)^2  with
     // S1 = sum_r (x_r - x0) ,  S2 = sum_r M2_r + C (x_r - x0)^2.  (The two-pass form read the partials twice with a dependent second pass.)
+    // Cancellation in M2 is bounded: (mu - x0)^2 <= N * Var(row means) <= N * sigma^2, so the relative error of M2 is at most ~N * 2^-24
+    // (207 nodes: 1e-5, 8192 nodes: 5e-4 in the worst case of ONE outlying first row) against the 1e-3 bar on rstd.
     const float x0 = rs[0].x;
     float s1 = 0.f, s2 = 0.f;
     int r0 = 0;
