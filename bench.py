@@ -133,7 +133,7 @@ def stblock_flops_by_label(B, N, Ks=3):
     return tot
 
 
-def cpu_baseline(gso_np, cfg, B, budget_s=20.0):
+def cpu_baseline(gso_np, cfg, B, budget_s=20.0, probe=True):
     """The reference's loop body restated by the oracle (torch CPU), bounded sample.  kind = "port": the reference's own modules
     live in /root/reference, which does not exist on the GPU box; the oracle is the line-by-line restatement pinned against them
     (tests/test_oracle_golden.py), with the dropout masks drawn up front (the reference's nn.Dropout spends 36 % of its CPU step in
@@ -159,8 +159,8 @@ def cpu_baseline(gso_np, cfg, B, budget_s=20.0):
         orc.train_step(x, y, gso, p, ocfg, state, keep_masks=masks())
         return time.perf_counter() - t
 
-    best, cores = None, 1
-    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+    best, cores = None, min(ncpu, 32)
+    for th in (sorted({min(ncpu, c) for c in (8, 16, 32, 64)}) if probe else []):
         torch.set_num_threads(th)
         st = {}
         one_step(st)                       # warm-up at this thread count
@@ -171,7 +171,8 @@ def cpu_baseline(gso_np, cfg, B, budget_s=20.0):
             break
     torch.set_num_threads(cores)
     state = {}
-    one_step(state)
+    if probe:
+        one_step(state)
     n, t0 = 0, time.perf_counter()
     while True:
         one_step(state)
@@ -181,7 +182,28 @@ def cpu_baseline(gso_np, cfg, B, budget_s=20.0):
             break
     return {"value": round(B * n / el, 2), "unit": "windows/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of bs {B} ({cfg['workload'][:2]} shapes, dropout on (masks pre-drawn), AdamW) in {el:.1f} s, torch CPU oracle "
-                      f"(restatement of the reference modules), {cores} of {ncpu} host threads"}
+                      f"(restatement of the reference modules), {cores} of {ncpu} host threads" + ("" if probe else "; no warm-up step, thread count not probed")}
+
+
+def side_config(name, steps, warmup, timeout_s=420):
+    """One of the other single-GPU entries of BASELINE.json `configs` (c3: configs[2], c5: configs[4]) measured by THIS script in a fresh
+    process (its own library modes, model and captured graph), summarised for the headline line: value, step time, dtype, the dominant
+    launch against its roofline, the CPU baseline of the same shapes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", str(warmup), "--no-gpu-baseline",
+           "--no-side-configs", "--cpu-budget", "10"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001  (a failing side config must not lose the headline line)
+        return {"error": repr(e)[:300]}
+    rl = rec.get("roofline") or {}
+    return {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+            "dtype": rec["dtype"], "workload": rec["config"]["workload"], "launch": rec["config"]["launch"], "final_loss": rec["config"]["final_loss"],
+            "roofline": {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "stblock_kernels_ms_per_step",
+                                               "stblock_fwd_bwd_frac", "stblock_hbm_frac", "stblock_traffic_bytes", "stblock_compulsory_bytes")},
+            "cpu_baseline": rec.get("cpu_baseline"), "wall_s": round(time.perf_counter() - t0, 1)}
 
 
 def gpu_baseline(model, gso_t, cfg, B, N, dev):
@@ -227,6 +249,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="c2 only: do not append the c3 / c5 (bf16) measurements as `side_configs`")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of timed CPU-baseline steps")
     ap.add_argument("--replay-times", action="store_true", help="diagnostic: config.replay_ms = GPU time of each of the first steps after a synchronisation")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-resident-series", action="store_true",
@@ -469,10 +493,18 @@ def main():
             rl["stblock_hbm_frac"] = round(comp / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     if rank == 0 and world == 1 and not args.no_gpu_baseline:
         out["gpu_baseline"] = gpu_baseline(model, gso_t, cfg, B_LOCAL, N, dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and N <= 1024:
-        out["cpu_baseline"] = cpu_baseline(gso_np, cfg, B_LOCAL)
-        out["cpu_baseline"]["reference_published"] = {"value": {"c2": 159.2, "c3": 79.5}.get(args.config), "unit": "windows/s",
-                                                      "source": "BASELINE.md section 2: the unmodified reference loop on 8 vCPU (survey container), fp32"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if N <= 1024:
+            out["cpu_baseline"] = cpu_baseline(gso_np, cfg, B_LOCAL, args.cpu_budget)
+            out["cpu_baseline"]["reference_published"] = {"value": {"c2": 159.2, "c3": 79.5}.get(args.config), "unit": "windows/s",
+                                                          "source": "BASELINE.md section 2: the unmodified reference loop on 8 vCPU (survey container), fp32"}
+        else:   # 8192 nodes: one oracle step costs ~1 TFLOP of fp32 operator products on the host -- a bounded sample at bs 2, no thread probing
+            out["cpu_baseline"] = cpu_baseline(gso_np, cfg, 2, args.cpu_budget, probe=False)
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_side_configs and not B_OVERRIDE:
+        # the other single-GPU configurations of BASELINE.json, witnessed by the same invocation
+        del model, opt
+        torch.cuda.empty_cache()
+        out["side_configs"] = {"c3_bf16": side_config("c3", args.steps, args.warmup), "c5_bf16": side_config("c5", min(args.steps, 30), min(args.warmup, 5))}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -28,6 +28,12 @@
 extern "C" {
 #endif
 
+/* ABI revision: bumped whenever an entry point changes its argument list or a struct its layout (round 3 added `y` to the
+ * backward entry points and `stored_US2` to the plan: 1 -> 2 in effect, never recorded; round 4: stgcn_set_gemm_big_nt, the
+ * chained-launch control words in `ws`: 3).  stgcn_version() returns the value the LIBRARY was built with; a binding built
+ * against another header must refuse to run (stgcn_amd/_lib.py does).                                                  */
+#define STGCN_ABI_VERSION 3
+
 #define STGCN_OK 0
 #define STGCN_ERR_UNSUPPORTED 1 /* shape outside what the kernels cover (message says which) */
 #define STGCN_ERR_INVALID 2     /* null pointer / bad enum / inconsistent sizes */
@@ -205,6 +211,12 @@ int stgcn_set_slab_gc_precision(int32_t mode);
  * arithmetic -- an opt-in, reported as such by bench.py; the forward always keeps exact fp32 products).  Returns the previous mode; a mode
  * outside 0..1 only queries.                                                                                                          */
 int stgcn_set_bwd_precision(int32_t mode);
+
+/* Test / tuning knob: the column extent of the 256 x (32 * NT) tiles of the big bf16 operator GEMM (gso_gemm_bf16_big_kernel<NT>, taken
+ * when the padded node count is a multiple of 256): nt in {4, 5, 6, 8, 10} forces that instance for every launch, 0 restores the
+ * grid-rounds heuristic (BASELINE.json configs[4] at bs 16 picks NT = 10 for block 0's 2560 columns and NT = 6 for block 1's 1536;
+ * every small test shape would pick NT = 4, so the tests force each instance).  Returns the previous value; other values only query. */
+int stgcn_set_gemm_big_nt(int32_t nt);
 
 /* Tuning knob: extra bf16 elements (multiple of 8) between consecutive rows of every 16-bit plane of the tiled graph conv
  * (operator hi / lo planes, activation operand form), so that the rows of a tile do not all start in the same L2 channel

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libstgcn_hip.so")
 
 STGCN_OK = 0
+ABI_VERSION = 3      # include/stgcn_hip.h: STGCN_ABI_VERSION (tests/test_capi_symbols.py keeps the two equal)
 ACT = {"glu": 0, "gtu": 1}
 GRAPH_CONV = {"cheb_graph_conv": 0, "graph_conv": 1}
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -128,6 +129,12 @@ class _Lib:
         self.dll = C.CDLL(path)
         d = self.dll
         d.stgcn_version.restype = C.c_int
+        # The argument lists below are those of include/stgcn_hip.h at STGCN_ABI_VERSION: a library built from another revision of the
+        # header (a stale .so left in the tree, an external build) would take shifted arguments and corrupt device memory -- refuse it.
+        got = int(d.stgcn_version())
+        if got != ABI_VERSION:
+            raise StgcnError(f"{path} was built for ABI revision {got}, this binding needs {ABI_VERSION} (include/stgcn_hip.h "
+                             f"STGCN_ABI_VERSION): rebuild with `python -m stgcn_amd.build --force`")
         d.stgcn_backend.restype = C.c_char_p
         d.stgcn_last_error.restype = C.c_char_p
         d.stgcn_stblock_plan_query.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockPlan)]
@@ -152,6 +159,8 @@ class _Lib:
         d.stgcn_set_gc_precision.restype = C.c_int
         d.stgcn_set_gc_ld_pad.argtypes = [C.c_int32]
         d.stgcn_set_gc_ld_pad.restype = C.c_int
+        d.stgcn_set_gemm_big_nt.argtypes = [C.c_int32]
+        d.stgcn_set_gemm_big_nt.restype = C.c_int
         d.stgcn_stblock_forward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         d.stgcn_stblock_backward.argtypes = [C.POINTER(StblockDesc), C.POINTER(StblockParams), C.c_void_p, C.c_void_p,
@@ -230,4 +239,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_mse_loss_grad", "stgcn_grad_flush", "stgcn_gso_layout", "stgcn_set_gc_tiled_min_nodes",
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
                     "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
-                    "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss", "stgcn_set_bwd_precision"]
+                    "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss", "stgcn_set_bwd_precision", "stgcn_set_gemm_big_nt"]

@@ -20,6 +20,7 @@ namespace {
 thread_local char g_err[512] = "";
 // storage / arithmetic type of the activations of the call being served (set by every entry point from its descriptor)
 thread_local bool g_bf16 = false;
+int g_gemm_big_nt = 0;   // stgcn_set_gemm_big_nt: forced column extent of the big bf16 operator GEMM's tiles (0 = heuristic)
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int fail(int code, const char* fmt, ...) {
@@ -256,12 +257,17 @@ int wg_capacity(K kernel, int threads, size_t lds) {
             cus = 256;
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess || nb <= 0) nb = 1;
+    // a block the kernel cannot be launched with at all (more threads than its __launch_bounds__, more LDS than a CU has) gets capacity 0:
+    // the launch heuristics then never pick that geometry (a failed query used to read as "one workgroup per CU")
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        nb = 0;
+    }
     const int cap = nb * cus;
     if (n < 64) cache[n++] = Entry{key, threads, lds, cap};
     return cap;
 }
-inline int rounds_of(long wgs, int cap) { return (int)((wgs + cap - 1) / cap); }
+inline int rounds_of(long wgs, int cap) { return cap <= 0 ? (1 << 30) : (int)((wgs + cap - 1) / cap); }
 
 // pack jobs: appended to one PackArgs so that several modules can share a launch (stgcn_prepack)
 struct PackList {
@@ -523,7 +529,8 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     const int split = g_gc_precision == 1 && !g_bf16;   // (bf16 activations: operands are bf16 numbers already, one MFMA per product)
     {   // 256 x (32 * NT) tiles, one workgroup per CU (gso_gemm_bf16_big_kernel); STGCN_GEMM_BIG=0: the 128 x 128 kernel
         static const int off = getenv("STGCN_GEMM_BIG") ? atoi(getenv("STGCN_GEMM_BIG")) == 0 : 0;
-        static const int force_nt = getenv("STGCN_GEMM_BIG_NT") ? atoi(getenv("STGCN_GEMM_BIG_NT")) : 0;
+        static const int env_nt = getenv("STGCN_GEMM_BIG_NT") ? atoi(getenv("STGCN_GEMM_BIG_NT")) : 0;
+        const int force_nt = g_gemm_big_nt ? g_gemm_big_nt : env_nt;   // stgcn_set_gemm_big_nt (tests force every instance) before the environment
         static const int big_bk = getenv("STGCN_GEMM_BIG_BK") && atoi(getenv("STGCN_GEMM_BIG_BK")) == 32 ? 32 : 64;   // r3-17: 64-deep steps 6 % faster
         if (!off && !split && NP % kGbBigBM == 0) {
             const long CP = gc_operand_cols(slabs);
@@ -728,6 +735,13 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
     return STGCN_OK;
 }
 
+// job waves of gconv_bwd2_kernel: one per parameter-gradient job of the part (Ks weight terms + the bias, spread over the parts), but never
+// more than the kernel's __launch_bounds__(768) leaves beside the tile waves -- the job loop strides by the job-wave count, so fewer waves
+// only walk more jobs each (Ks >= 4 with one part asked for 13+ waves and the launch failed)
+inline int gcbwd2_job_waves(int Ks, int parts, int nwa) {
+    const int want = (Ks + 1 + parts - 1) / parts, room = 768 / 64 - nwa;
+    return want < room ? want : room;
+}
 int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     if (gc_is_tiled(a.N, a.Ks)) return launch_gconv_bwd_tiled(a, st);
     const int HT = a.NP / 16;
@@ -735,7 +749,7 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     gc_parts_override(pf, pb);
     {   // round 3: slab split over parts, parameter-gradient jobs on their own waves (gconv_bwd2_kernel); STGCN_GCBWD2=0: the one-workgroup-per-slab kernel
         static const int off = getenv("STGCN_GCBWD2") ? atoi(getenv("STGCN_GCBWD2")) == 0 : 0;
-        static const int force_parts = getenv("STGCN_GCBWD2_PARTS") ? atoi(getenv("STGCN_GCBWD2_PARTS")) : 0;
+        const int force_parts = getenv("STGCN_GCBWD2_PARTS") ? atoi(getenv("STGCN_GCBWD2_PARTS")) : 0;   // (read per call: the tests force geometries)
         // One node tile per tile wave (<= 8 tile waves per workgroup), and the whole grid resident in ONE round: every part re-stages the
         // slab's dY and re-forms all G_k, so a grid of SEVERAL parts that needs more rounds than the slab kernel costs more than it returns
         // (measured at the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
@@ -743,9 +757,9 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
         if (!off && lds2 <= 150 * 1024 && HT <= 64) {
             int best = 0;
             for (int parts = (HT + 7) / 8; parts <= HT && !force_parts; ++parts) {
-                const int per = (HT + parts - 1) / parts, njw = (a.Ks + 1 + parts - 1) / parts;
+                const int per = (HT + parts - 1) / parts, njw = gcbwd2_job_waves(a.Ks, parts, per > 8 ? 8 : per);
                 if (per < 4 && parts > (HT + 7) / 8) break;     // keep >= 4 tile waves per workgroup
-                const int cap = STGCN_ETB_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, (per + njw) * 64, lds2));
+                const int cap = STGCN_ETB_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, ((per > 8 ? 8 : per) + njw) * 64, lds2));
                 if (a.slabs * parts <= cap) best = parts;
             }
             if (force_parts > 0 && force_parts <= HT && (HT + force_parts - 1) / force_parts <= 24) best = force_parts;   // (tuning: up to 3 tiles per wave)
@@ -753,7 +767,7 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
             // (r3-49: 54.9 / 38.8 -> 47.5 / 33.5 us; 70 KB of LDS = two workgroups per CU instead of one)
             if (!best && !force_parts && HT <= 24) best = 1;
             if (best > 0) {
-                const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = (a.Ks + 1 + best - 1) / best;
+                const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = gcbwd2_job_waves(a.Ks, best, nwa);
                 a.parts = best;
                 const dim3 grid2((unsigned)(a.slabs * best)), blk2((nwa + njw) * 64);
                 if (maxq <= 1) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), grid2, blk2, lds2, a, nwa);
@@ -912,7 +926,7 @@ LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
 
 extern "C" {
 
-int stgcn_version(void) { return 1; }
+int stgcn_version(void) { return STGCN_ABI_VERSION; }
 const char* stgcn_backend(void) { return STGCN_BACKEND_NAME; }
 const char* stgcn_last_error(void) { return g_err; }
 
@@ -1030,6 +1044,12 @@ int stgcn_set_gc_tiled_min_nodes(int32_t n) {
 int stgcn_set_gc_ld_pad(int32_t pad) {
     const int prev = g_gc_ld_pad;
     if (pad >= 0 && pad <= 65536 && (pad & 7) == 0) g_gc_ld_pad = pad;
+    return prev;
+}
+
+int stgcn_set_gemm_big_nt(int32_t nt) {
+    const int prev = g_gemm_big_nt;
+    if (nt == 0 || nt == 4 || nt == 5 || nt == 6 || nt == 8 || nt == 10) g_gemm_big_nt = nt;
     return prev;
 }
 

@@ -144,8 +144,9 @@ struct f32x { float v; };
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned bf16_bits_rne(float x) {   // round-to-nearest-even, finite inputs
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {   // round-to-nearest-even; NaN stays NaN (quiet bit set), +-inf stays +-inf
     const unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // (the rounding add would carry a large NaN payload into the sign: -0)
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 // two floats -> two bf16 packed little-endian (v_cvt_pk_bf16_f32 on gfx950; the emulator rounds in software: same RNE result)
@@ -271,7 +272,7 @@ __device__ __forceinline__ void stx8(bf16* p, f32x4 a, f32x4 b) {
 __device__ __forceinline__ float ldx1(const float* p) { return *p; }
 __device__ __forceinline__ float ldx1(const bf16* p) { return __builtin_bit_cast(float, (unsigned)p->v << 16); }
 __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
-__device__ __forceinline__ void stx1(bf16* p, float v) { p->v = (unsigned short)bf16_bits_rne(v); }
+__device__ __forceinline__ void stx1(bf16* p, float v) { p->v = (unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu); }   // (v_cvt_pk_bf16_f32 on the device: RNE, NaN-preserving)
 // write-through variants (see st4_wt)
 #if STGCN_TS_DBG == 3
 __device__ __forceinline__ void stx4_wt(float* p, f32x4 v) { (void)p; dbg_keep4(v); }

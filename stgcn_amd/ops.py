@@ -194,6 +194,12 @@ def set_tc1_bwd_wgs(n: int) -> int:
     return prev
 
 
+def set_gemm_big_nt(nt: int) -> int:
+    """Force the column extent (32 * nt, nt in {4, 5, 6, 8, 10}) of the big bf16 operator GEMM's tiles, 0 = the grid-rounds heuristic
+    (``stgcn_set_gemm_big_nt``; the parity tests run every instance the bs-16 8192-node configuration selects).  Returns the previous value."""
+    return int(_lib.lib().dll.stgcn_set_gemm_big_nt(int(nt)))
+
+
 def set_gc_ld_pad(pad: int) -> int:
     """Row padding (bf16 elements, multiple of 8) of the 16-bit planes of the tiled graph conv (``stgcn_set_gc_ld_pad``);
     returns the previous value.  Operators and plans made under one setting must be used under the same setting."""

@@ -66,8 +66,13 @@ def sync_operators(model, src: int = 0) -> None:
         if isinstance(m, STConvBlock) and torch.is_tensor(m.gso):
             g = seen.get(id(m.gso))
             if g is None:
-                g = m.gso.detach().clone().contiguous()
-                dist.broadcast(g, src=src)
+                # the collective runs on the process group's device (RCCL needs a tensor on this rank's GPU; `gso` is a plain attribute
+                # that .to(device) never moved, so it is often still a CPU tensor) and the result goes back where the operator lived
+                home = m.gso.device
+                comm_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                t = m.gso.detach().to(comm_dev, copy=True).contiguous()
+                dist.broadcast(t, src=src)
+                g = t.to(home)
                 seen[id(m.gso)] = g
             m.gso = g
             m.graph_conv.gso = g

@@ -28,7 +28,21 @@ def test_hip_library_builds_loads_and_exports_all_symbols():
     L = _lib._Lib(path)
     for sym in declared_symbols():
         assert hasattr(L.dll, sym), sym
-    assert L.backend == "hip-gfx950" and L.dll.stgcn_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "stgcn_hip.h")).read()
+    abi = int(re.search(r"#define STGCN_ABI_VERSION (\d+)", hdr).group(1))
+    assert L.backend == "hip-gfx950" and L.dll.stgcn_version() == abi == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """A library built from another revision of the header must not be bound (its argument lists differ)."""
+    from stgcn_amd import _lib, build
+    try:
+        path = build.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.StgcnError, match="ABI revision"):
+        _lib._Lib(path)
 
 
 def test_missing_library_fails_loudly(tmp_path):

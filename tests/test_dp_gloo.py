@@ -115,3 +115,44 @@ def test_tail_batch_weighted_by_local_count(tmp_path):
         # (AdamW divides every gradient element by its own magnitude: an element whose gradient nearly cancels turns the different
         #  summation order of the two-rank run into a few 1e-6 of the lr = 1e-3 step)
         assert (got["params"][k] - v).abs().max() <= 1e-5, k
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from stgcn_amd import models
+    from stgcn_amd.train import init_distributed, sync_operators
+    from tests.emu_util import bind_emulator, nonsym_gso
+    torch.set_num_threads(1)
+    init_distributed("gloo")
+    bind_emulator()
+    N = 12
+    gso = torch.from_numpy(nonsym_gso(N, 2 + rank))      # every rank built ITS OWN operator (differently seeded numpy state)
+    args = types.SimpleNamespace(Kt=3, Ks=3, act_func="glu", graph_conv_type="cheb_graph_conv", gso=gso, enable_bias=True, droprate=0.0, n_his=12)
+    torch.manual_seed(3)
+    model = models.STGCNChebGraphConv(args, [[1], [64, 16, 64], [64, 16, 64], [128, 128], [1]], N)
+    x, _ = _data()
+    before = model(x).detach().clone()
+    sync_operators(model)
+    blocks = [m for m in model.modules() if type(m).__name__ == "STConvBlock"]
+    after = model(x).detach().clone()
+    torch.save({"gso": [b.gso.clone() for b in blocks], "device": str(blocks[0].gso.device), "before": before, "after": after,
+                "inner": [b.graph_conv.cheb_graph_conv.gso.clone() for b in blocks]}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_operators_broadcasts_rank0_graph(tmp_path):
+    """train.sync_operators had no test.  Two ranks that built different operators end up with rank 0's, on the device the
+    operator lived on, in every place a block keeps it (block, graph-conv layer, inner graph conv), and the forward uses it."""
+    from tests.emu_util import nonsym_gso
+    out = str(tmp_path / "s")
+    mp.spawn(_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    g0 = torch.from_numpy(nonsym_gso(12, 2))
+    for r in (r0, r1):
+        assert r["device"] == "cpu"
+        for g in r["gso"] + r["inner"]:
+            assert torch.equal(g, g0)
+    assert torch.equal(r0["before"], r0["after"])                       # rank 0 keeps its operator
+    assert not torch.equal(r1["before"], r1["after"])                   # rank 1 trained on another graph before the broadcast
+    assert torch.equal(r0["after"], r1["after"])                        # identical replicas afterwards

@@ -106,3 +106,20 @@ def test_tc1_bwd_ranges_cut_inside_items(wgs):
         test_block_backward(32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False)
     finally:
         ops.set_tc1_bwd_wgs(prev)
+
+
+def test_gconv_bwd2_job_waves_fit_the_launch_bounds(monkeypatch):
+    """with Ks >= 4 the split graph-conv backward asked for one job wave per parameter-gradient job and, with 8 tile waves,
+    for more than the 12 waves its __launch_bounds__(768) admits.  The job-wave count is clamped (the job loop strides by it); forcing
+    two parts on a 256-node-tile graph with Ks = 8 gives 8 tile waves + 5 wanted job waves -> 4."""
+    import tests.test_emu_backward as me
+
+    def sym_gso(n, seed):      # symmetric, spectrum in [-1, 1]: T_7 of it stays bounded (a non-normal operator's polynomials grow)
+        rs = np.random.RandomState(seed)
+        a = rs.uniform(-1, 1, (n, n)) * (rs.uniform(size=(n, n)) < 0.6)
+        a = 0.5 * (a + a.T)
+        return (a / np.abs(np.linalg.eigvalsh(a)).max()).astype(np.float32)
+
+    monkeypatch.setattr(me, "nonsym_gso", sym_gso)
+    monkeypatch.setenv("STGCN_GCBWD2_PARTS", "2")
+    test_block_backward(64, (64, 16, 64), 3, 8, "cheb_graph_conv", "glu", 250, 1, 5, True)

@@ -52,6 +52,24 @@ def test_tiled_block_bf16_matches_bf16_oracle(c_in, channels, Kt, Ks, gct, act, 
     assert_bf16_errors(stored, f32)
 
 
+@pytest.mark.parametrize("nt", [10, 8, 6, 5, 4])
+def test_big_operator_gemm_every_tile_width(nt):
+    """gso_gemm_bf16_big_kernel<NT> (256 x 32 NT tiles; padded node count a multiple of 256): BASELINE.json configs[4] at bs 16 runs NT = 10
+    (block 0: 2560 columns) and NT = 6 (block 1: 1536), which no small shape selects by itself -- stgcn_set_gemm_big_nt forces each instance.
+    250 nodes (ragged last row block), 15 slabs = 240 operand columns: narrower than every tile but NT = 4 / 5 (column overrun rows), two
+    column tiles for NT = 4 .. 6."""
+    bind_emulator()
+    prev = ops.set_gc_tiled_min_nodes(1)
+    prev_nt = ops.set_gemm_big_nt(nt)
+    try:
+        assert ops.set_gemm_big_nt(-1) == nt
+        stored, f32 = run_block_case_bf16("cpu", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 250, 3, 7, True)
+    finally:
+        ops.set_gemm_big_nt(prev_nt)
+        ops.set_gc_tiled_min_nodes(prev)
+    assert_bf16_errors(stored, f32)
+
+
 @pytest.mark.parametrize("N,B,training", [(21, 3, True), (40, 2, False)])
 def test_head_bf16_matches_bf16_oracle(N, B, training):
     bind_emulator()

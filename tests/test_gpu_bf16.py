@@ -59,6 +59,40 @@ def test_c5_graph_8192_nodes_bf16(blk):
     assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, (64, 16, 64), 3, 5, "cheb_graph_conv", "glu", 8192, 1, T, True, gso=big_gso(8192, 3)))
 
 
+@pytest.mark.parametrize("nt", [10, 8, 6, 5, 4])
+@pytest.mark.parametrize("N,B,T", [(512, 3, 7), (1000, 5, 8)])
+def test_big_operator_gemm_every_tile_width(nt, N, B, T):
+    """gso_gemm_bf16_big_kernel<NT> for every NT the launcher can pick (configs[4] at bs 16 runs NT = 10 and NT = 6; batch-1
+    tests only ever selected NT = 4).  512 nodes = two full row tiles; 1000 nodes = four row tiles, the last one ragged; 15 slabs = 240 and
+    30 slabs = 480 operand columns: ragged against every tile width (column-overrun rows of gc_operand_alloc, LDS-transposed epilogue)."""
+    from stgcn_amd import ops
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    prev = ops.set_gc_tiled_min_nodes(1)
+    prev_nt = ops.set_gemm_big_nt(nt)
+    try:
+        from tests.emu_util import big_gso
+        res = run_block_case_bf16("cuda:0", 64, (64, 16, 64), 3, 5 if N == 512 else 3, "cheb_graph_conv", "glu", N, B, T, True, gso=big_gso(N, 7))
+    finally:
+        ops.set_gemm_big_nt(prev_nt)
+        ops.set_gc_tiled_min_nodes(prev)
+    assert_bf16_errors(*res)
+
+
+@pytest.mark.parametrize("blk", [0, 1])
+def test_c5_full_size_bs16_bf16(blk):
+    """BASELINE.json configs[4] AT ITS STATED BATCH: 8192 nodes, dense operator, ChebConv Ks = 5, bs 16, bf16, both ST blocks (block 0:
+    12 -> 8 steps, 2560 operand columns = 256 x 320 tiles; block 1: 8 -> 4 steps, 1536 columns = 256 x 192 tiles), every stored tensor
+    and gradient against the bf16 statement of the stage oracle (its operator products are BLAS GEMMs: about a minute of host time)."""
+    from stgcn_amd import ops
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    from tests.emu_util import big_gso
+    _bind()
+    assert ops.set_gemm_big_nt(-1) == 0          # the heuristic decides, as in bench.py --config c5
+    c_in, T = ((1, 12), (64, 8))[blk]
+    assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, (64, 16, 64), 3, 5, "cheb_graph_conv", "glu", 8192, 16, T, True, gso=big_gso(8192, 3)))
+
+
 def test_tiled_small_graph_bf16():
     from stgcn_amd import ops
     from tests.bf16_util import assert_bf16_errors, run_block_case_bf16

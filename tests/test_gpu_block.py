@@ -36,6 +36,15 @@ def test_c2_full_size(blk, training):
     assert_errors(run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, training, gso=gso))
 
 
+def test_ks5_slab_path_more_slabs_than_one_round():
+    """207 nodes, Ks = 5 / 4, 320 / 384 slabs -- no split of the graph-conv backward fits one round, so the one-part geometry runs with
+    8 tile waves and its parameter-gradient jobs on the 4 waves the launch bounds leave (it used to ask for 6 and fail to launch)."""
+    from tests.gpu_util import assert_errors, run_block_case
+    gso = real_gso("metr_la.cheb_sym_norm_lap")      # (symmetric, spectrum in [-1, 1]: the higher polynomials stay bounded)
+    assert_errors(run_block_case(1, (64, 16, 64), 3, 5, "cheb_graph_conv", "glu", 207, 32, 12, True, gso=gso))
+    assert_errors(run_block_case(64, (64, 16, 64), 3, 4, "cheb_graph_conv", "glu", 207, 64, 8, True, gso=gso))
+
+
 def test_c1_shapes_kipf():
     """BASELINE.json configs[0] shapes (PeMSD7(M) 228 nodes, graph_conv, bs 8) on the GPU path."""
     from tests.gpu_util import assert_errors, run_block_case

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT="$GRAFT_REPO_ROOT/gpurun_out/${1:-bsweep}"
 mkdir -p $OUT
 for b in ${BS:-4 8 16 32 64 128}; do
-  STGCN_BENCH_B=$b timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-gpu-baseline 2> $OUT/err.log > $OUT/bench_b$b.json
+  STGCN_BENCH_B=$b timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --no-gpu-baseline 2> $OUT/err.log > $OUT/bench_b$b.json
   python -c "
 import json,sys
 d=json.load(open('$OUT/bench_b$b.json')); r=d['roofline']['per_kernel_us_per_step']

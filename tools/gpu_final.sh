@@ -12,8 +12,8 @@ cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 cp ${O}c3/pmc_traffic.json profiles/${TAG}_pmc_traffic_c3_bf16.json
 cp ${O}c5/pmc_traffic.json profiles/${TAG}_pmc_traffic_c5_bf16.json
 python bench.py > $O/bench_full.json 2> $O/bench_full.err
-python bench.py --config c3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
-python bench.py --config c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
+python bench.py --config c3 --no-cpu-baseline --no-side-configs > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --config c5 --no-cpu-baseline --no-side-configs > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> /dev/null
 for F in bench_full bench_c3 bench_c5 bench_driver_style; do
   python -c "
