@@ -90,6 +90,8 @@ def block_flops(B, c_in, T, N, Ks, need_dx):
             "tconv_bwd_data.tc2": F_tc2, "gconv_bwd": F_L + 2 * F_W, "align_gate_bwd": 2 * F_al,
             "tconv_bwd_data.tc1": F_tc1 if need_dx else 0, "tconv_bwd_weight.tc1": F_tc1, "tconv_bwd_weight.tc2": F_tc2,
             "tc2_bwd": 2 * F_tc2, "tc1_bwd": (2 * F_tc1 if need_dx else F_tc1) + 2 * F_al,
+            # chained launches: several stages as roles of one launch
+            "stblock_fwd": F_tc1 + F_al + F_L + F_W + F_tc2, "tc1_gconv_fwd": F_tc1 + F_al + F_L + F_W,
             "gso_gemm_fwd": F_L / max(Ks - 1, 1), "gso_gemm_bwd": F_L / max(Ks - 1, 1),
             "_total": (F_tc1 + F_al + F_L + F_W + F_tc2) + (F_tc1 if need_dx else 0) + F_tc1 + 2 * (F_al + F_W + F_tc2) + F_L}
 
@@ -103,7 +105,10 @@ def block_bytes(B, c_in, T, N, Ks, need_dx, e, part):
     r0, r1, r2 = B * T * N, B * T1 * N, B * T2 * N
     ln = 2 * N * c2 * 4
     recompute = KT * c_in <= 16
-    return {"tconv_fwd.tc1": e * (r0 * c_in + (0 if recompute else 2 * r1 * c0) + r1 * c1),
+    tc1b = e * (r0 * c_in + (0 if recompute else 2 * r1 * c0) + r1 * c1)
+    return {"tconv_fwd.tc1": tc1b,
+            # chained launches: the hand-off tensors (A, G) are written once (they are saved for backward) and re-read on chip / from L2
+            "tc1_gconv_fwd": tc1b + e * (r1 * c1 * Ks), "stblock_fwd": tc1b + e * (r1 * c1 * Ks) + e * (3 * r2 * c2) + ln,
             "gconv_fwd": e * (r1 * c1 * (Ks + 1)),
             "tc2_ln_fwd": e * (r1 * c1 + 3 * r2 * c2) + ln,
             "tc2_bwd": e * (3 * r2 * c2 + 2 * r1 * c1) + ln // 2 + 4 * part.get("tc2_bwd", 0),
@@ -255,6 +260,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-resident-series", action="store_true",
                     help="feed (num, 1, n_his, N) window tensors copied per step instead of device-side windows of a resident series")
+    ap.add_argument("--capture-collective", default="auto", choices=["auto", "off"],
+                    help="N > 1: record the gradient all-reduce inside the step's hipGraph (one graph per step) when a watchdogged probe in a child "
+                         "process shows that RCCL capture works on this machine (auto), or keep the two-graph form around an eager all-reduce (off)")
     ap.add_argument("--chains", type=int, default=int(os.environ.get("STGCN_CHAINS", "1")),
                     help="micro-batch chains of the minibatch run concurrently on separate HIP streams (train.chained_fwd_bwd)")
     args = ap.parse_args()
@@ -316,10 +324,22 @@ def main():
     step_i = 0
     graph_err = None
     graphed = None
+    capture_coll, coll_why = False, None
+    if use_graph and world > 1 and args.capture_collective == "auto":
+        from stgcn_amd.train import probe_collective_capture
+        capture_coll, coll_why = probe_collective_capture(timeout_s=60.0)      # (every rank: the verdict is agreed on inside)
     if use_graph:
         try:
-            graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains, series=series, n_his=N_HIS, n_pred=N_PRED,
-                                       rank=rank)
+            try:
+                graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains, series=series, n_his=N_HIS, n_pred=N_PRED,
+                                           rank=rank, capture_collective=capture_coll)
+            except Exception as e:  # noqa: BLE001  -- the probe passed but the real capture did not: the two-graph form is the known-good one
+                if not capture_coll:
+                    raise
+                capture_coll, coll_why = False, "captured step failed: " + repr(e)[:200]
+                torch.cuda.synchronize()
+                graphed = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains, series=series, n_his=N_HIS, n_pred=N_PRED,
+                                           rank=rank, capture_collective=False)
 
             def run_step(xb, yb):
                 return graphed() if resident else graphed(xb, yb)
@@ -405,8 +425,16 @@ def main():
             torch.distributed.all_reduce(flat)
         e1.record()
         torch.cuda.synchronize()
-        out["config"]["allreduce"] = {"bytes": int(flat.numel() * 4), "us": round(1e3 * e0.elapsed_time(e1) / 50, 2),
-                                      "placement": "eager all-reduce (torch.distributed backend " + torch.distributed.get_backend() + "; nccl = RCCL) between the two captured graphs of the step" if use_graph else "eager"}
+        ar_us = 1e3 * e0.elapsed_time(e1) / 50
+        in_graph = bool(use_graph and graphed is not None and graphed.capture_collective)
+        out["config"]["allreduce"] = {"bytes": int(flat.numel() * 4), "us": round(ar_us, 2),
+                                      # nothing overlaps the collective in either form (it needs the last gradient and feeds the optimizer), so all of
+                                      # it is exposed; what the one-graph form removes is the two host enqueue boundaries around it
+                                      "exposed_fraction_of_step": round(ar_us / (1e6 * el / args.steps), 4),
+                                      "captured_in_graph": in_graph, "capture_probe": coll_why or ("ok" if in_graph else "not run"),
+                                      "placement": ("inside the step's single hipGraph (RCCL all-reduce recorded on the capturing stream)" if in_graph else
+                                                    "eager all-reduce (torch.distributed backend " + torch.distributed.get_backend() +
+                                                    "; nccl = RCCL) between the two captured graphs of the step" if use_graph else "eager")}
 
     if world == 1 and use_graph and resident and DTYPE == "f32" and args.bwd_precision == "fp32" and not args.no_secondary:
         # secondary measurement, same run, same model and optimizer state: the step with the opt-in "bf16x3" backward products

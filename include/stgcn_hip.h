@@ -153,6 +153,11 @@ typedef struct stgcn_stblock_plan {
                                          need_dx); dZ1 stays on chip (ws_dZ1 is only written under stgcn_set_debug_stages)           */
     int64_t stored_US2;               /* 1: the forward writes U2 / S2 into `saved` (LayerNorm as a separate pass, the stage-per-launch
                                          backward, or stgcn_set_debug_stages); 0: tc2_bwd_kernel recomputes them from G               */
+    int64_t ws_chain;                 /* control words of the chained launches (uint32: 4 header words -- ticket, finished workgroups, sticky
+                                         error, spare -- then the per-slab arrival counters), chain_words of them.  Zeroed by the weight-pack
+                                         launch that opens every forward / training step and re-armed by the last workgroup of each chained
+                                         launch; word 2 != 0 after a call means a bounded wait gave up (the results of that call are void).  */
+    int64_t chain_words;
 } stgcn_stblock_plan;
 
 int stgcn_version(void);

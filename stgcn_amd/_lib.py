@@ -55,7 +55,7 @@ PLAN_FIELDS = ["T1", "T2", "rows1", "rows2", "NP", "y_floats", "saved_floats", "
                "sv_U1", "sv_S1", "sv_A", "sv_Xk", "sv_G", "sv_U2", "sv_S2", "sv_mean", "sv_rstd", "sv_rowstat",
                "ws_W1p", "ws_W1d", "ws_b1", "ws_Wap", "ws_WaT", "ws_ba", "ws_W2p", "ws_W2d", "ws_b2", "ws_W1dense", "recompute_tc1", "ws_WaDense", "thin_tc1",
                "ws_rowstat_b", "ws_dZ2", "ws_dYg", "ws_dA", "ws_dZ1", "ws_part", "part_floats",
-               "tiled_gc", "ws_Gk", "ws_XT", "fused_tc2_bwd", "ws_W2dense", "fused_tc1_bwd", "stored_US2"]
+               "tiled_gc", "ws_Gk", "ws_XT", "fused_tc2_bwd", "ws_W2dense", "fused_tc1_bwd", "stored_US2", "ws_chain", "chain_words"]
 
 
 class StblockPlan(C.Structure):

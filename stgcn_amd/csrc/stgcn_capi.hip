@@ -20,6 +20,12 @@ namespace {
 thread_local char g_err[512] = "";
 // storage / arithmetic type of the activations of the call being served (set by every entry point from its descriptor)
 thread_local bool g_bf16 = false;
+// Default OFF: measured on MI355X (profiles/r4-02_chain_ab.txt) the chained forward of C2's second block is SLOWER than three launches
+// (tmp_conv1 + graph conv: 67.4 us against 28.6 + 14.7; all three stages: 75.7 against 61.7): a launch has ONE register and LDS budget, the
+// widest role's (tc1_fwd: 133 VGPRs, 3 waves per SIMD), and a workgroup is only dispatched when the whole block -- surplus waves included --
+// fits, so a graph-conv workgroup (73 VGPRs, ~5 per CU on its own) cannot start beside a tmp_conv1 workgroup at all and runs one per CU
+// afterwards.  The protocol itself is sound (0 wrong words in 600 launches of tools/ubench/chain_probe.hip, all GPU tests green with it).
+constexpr int kChainDefault = 0;   // (see fwd_chain_mode)
 int g_gemm_big_nt = 0;   // stgcn_set_gemm_big_nt: forced column extent of the big bf16 operator GEMM's tiles (0 = heuristic)
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -308,6 +314,7 @@ bool pack_fill_block(PackList& L, const stgcn_stblock_desc* d, const stgcn_stblo
         ok &= L.add(PK_ALIGN_DENSE, d->c0 * d->c1, ws + pl.ws_WaDense, P->al_w, P->al_b, nullptr, nullptr, d->c0, d->c1, 1, 0);
     if (pl.fused_tc2_bwd)
         ok &= L.add(PK_TCONV_DENSE, v.KP2 * v.NC2, ws + pl.ws_W2dense, P->tc2_w, P->tc2_b, P->tc2_aw, P->tc2_ab, d->c1, d->c2, d->Kt, 0);
+    ok &= L.add(PK_ZERO, (int)pl.chain_words, ws + pl.ws_chain, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0);   // control words of the chained launches
     return ok;
 }
 int launch_pack_list(const char* label, PackList& L, hipStream_t st) {
@@ -735,6 +742,17 @@ int launch_bwd_data(const char* label, const TconvBwdDataArgs& a, int ntt, hipSt
     return STGCN_OK;
 }
 
+// Chained forward launches (stgcn_device.hip.h): 0 = every stage its own launch, 1 = tmp_conv1 + graph conv in one launch, 2 = the whole
+// forward of a block (tmp_conv1 + graph conv + tmp_conv2 / LayerNorm / dropout) where the shapes allow.  STGCN_CHAIN overrides (A/B runs);
+// the hand-off relies on write-through stores, so a build with STGCN_WT_STORES=0 never chains.
+inline int fwd_chain_mode() {
+#if !STGCN_WT_STORES
+    return 0;
+#else
+    const char* e = getenv("STGCN_CHAIN");
+    return e ? atoi(e) : kChainDefault;
+#endif
+}
 // job waves of gconv_bwd2_kernel: one per parameter-gradient job of the part (Ks weight terms + the bias, spread over the parts), but never
 // more than the kernel's __launch_bounds__(768) leaves beside the tile waves -- the job loop strides by the job-wave count, so fewer waves
 // only walk more jobs each (Ks >= 4 with one part asked for 13+ waves and the launch failed)
@@ -992,6 +1010,10 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     p->sv_rowstat = take(2 * v.rows2);
     p->saved_floats = o;
     o = 0;
+    // control words of the chained launches FIRST: their offset must not depend on need_dx / training, because the pack launch that zeroes
+    // them may have been planned with other flags than the forward that uses them (stgcn_prepack packs a whole model with need_dx = 1)
+    p->chain_words = kChainHdr + 2 * v.slabs1;   // forward chain: arrival counters of A[slab] and G[slab]
+    p->ws_chain = take(p->chain_words);
     p->ws_W1p = take((int64_t)v.NC1 * v.KP1);
     p->ws_W1d = take((int64_t)d->Kt * v.NC1 * v.CP_in);
     p->ws_b1 = take(v.NC1);
@@ -1164,6 +1186,66 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     rc = d->prepacked ? STGCN_OK : launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
 
+    // ---- chained forward: tmp_conv1 + Align -> graph conv [-> tmp_conv2 + LayerNorm + dropout] as roles of ONE launch -----------------
+    {
+        const int mode = fwd_chain_mode();
+        const int HT = v.NP / 16;
+        const bool tc1_ts = !pl.recompute_tc1 && !d->x_bstride && !d->x_index_dev && tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt);
+        const bool slab_gc = !gc_is_tiled(d->N, v.terms) && !(g_slab_gc_precision > 0 && !g_bf16);
+        const bool tc2_one = tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N) && d->N <= 256 && v.slabs2 <= 2L * device_cus();
+        if (mode > 0 && tc1_ts && slab_gc && d->c_in == 64 && d->c0 == 64 && d->Kt == 3 && d->act == STGCN_ACT_GLU && HT <= 64) {
+            const bool with_tc2 = mode >= 2 && tc2_one && HT <= 16;
+            Tc1FwdArgs f1;
+            memset(&f1, 0, sizeof(f1));
+            f1.x = x; f1.Wp = ws + pl.ws_W1p; f1.bias = ws + pl.ws_b1; f1.WaD = ws + pl.ws_WaDense; f1.ba = ws + pl.ws_ba;
+            f1.U = saved + pl.sv_U1; f1.S = saved + pl.sv_S1; f1.A = saved + pl.sv_A;
+            f1.B = d->B; f1.T = d->T; f1.T1 = v.T1; f1.N = d->N; f1.node_tiles = (d->N + 15) / 16;
+            f1.chain_out = 0;                                   // counters [0, slabs1): node tiles of A[slab]
+            GconvFwdArgs f2;
+            memset(&f2, 0, sizeof(f2));
+            f2.A = saved + pl.sv_A; f2.Lp = gso_pad; f2.W = P->gc_w; f2.bias = P->gc_b; f2.Xk = saved + pl.sv_Xk; f2.G = saved + pl.sv_G;
+            f2.N = d->N; f2.NP = v.NP; f2.Ks = v.terms; f2.kipf = d->graph_conv == STGCN_GC_KIPF; f2.slabs = v.slabs1;
+            f2.chain_in = 0; f2.chain_expect = (unsigned)f1.node_tiles;
+            f2.chain_out = with_tc2 ? (int)v.slabs1 : -1;       // counters [slabs1, 2 slabs1): parts of G[slab]
+            // graph-conv geometry: with the third role every workgroup reserves tmp_conv2's 1024 threads and ~60 KB (two per CU), so a slab is ONE
+            // workgroup with a wave per node tile; without it the stand-alone split (4-wave parts, ~5 per CU) stays
+            const GcGeom gg = gc_geom(HT, with_tc2 ? 1 : (HT + 3) / 4);
+            if (gg.maxq == 1) {
+                f2.parts = gg.parts;
+                const int gc_threads = gg.waves * 64;
+                Tc2LnFwdArgs f3;
+                memset(&f3, 0, sizeof(f3));
+                f3.G = saved + pl.sv_G; f3.Wp = ws + pl.ws_W2p; f3.bias = ws + pl.ws_b2; f3.gamma = P->ln_w; f3.beta = P->ln_b;
+                f3.U = pl.stored_US2 ? saved + pl.sv_U2 : nullptr; f3.S = pl.stored_US2 ? saved + pl.sv_S2 : nullptr;
+                f3.y = y; f3.mean = saved + pl.sv_mean; f3.rstd = saved + pl.sv_rstd;
+                f3.T1 = v.T1; f3.T2 = v.T2; f3.N = d->N; f3.NPR = (int)rup(d->N, 16); f3.act = d->act; f3.training = d->training && d->droprate > 0.f;
+                f3.eps = d->ln_eps; f3.keep_scale = 1.0f / (1.0f - d->droprate); f3.thresh = drop_thresh(d->droprate);
+                f3.seed = seed; f3.offset = offset; f3.offset_dev = offset_dev;
+                f3.chain_in = (int)v.slabs1; f3.chain_expect = (unsigned)gg.parts;
+                const long items = (long)d->B * f1.node_tiles;
+                static const int force_per_cu = getenv("STGCN_TC1_FWD_PER_CU") ? atoi(getenv("STGCN_TC1_FWD_PER_CU")) : 0;
+                const long want = (long)device_cus() * (force_per_cu > 0 ? force_per_cu : (g_bf16 ? 2 : 1));
+                const int n1 = (int)(items < want ? items : want), n2 = (int)(v.slabs1 * gg.parts), n3 = with_tc2 ? (int)v.slabs2 : 0;
+                size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
+                const size_t l2 = gconv_fwd_lds_bytes(v.NP, 1, gg.waves, with_tc2), l3 = with_tc2 ? tc2_ln_fwd_lds_bytes(d->Kt, d->N) : 0;
+                lds = lds > l2 ? lds : l2;
+                lds = lds > l3 ? lds : l3;
+                const int slot = (int)(lds / 4);                // the ticket's LDS word sits behind every role's own LDS
+                lds += 16;
+                ChainCtl cc;
+                cc.words = reinterpret_cast<unsigned*>(ws + pl.ws_chain);
+                cc.ncount = with_tc2 ? 2 * (int)v.slabs1 : (int)v.slabs1;
+                cc.total = (unsigned)(n1 + n2 + n3);
+                const dim3 grid(cc.total);
+                if (with_tc2) STGCN_LAUNCH_ET("stblock_fwd", st, (stblock_fwd_chain_kernel<64, 3, 4, true, ET>), grid, dim3(1024), lds, f1, f2, f3, cc, n1, n2, gc_threads, slot);
+                else STGCN_LAUNCH_ET("tc1_gconv_fwd", st, (stblock_fwd_chain_kernel<64, 3, 4, false, ET>), grid, dim3(512), lds, f1, f2, f3, cc, n1, n2, gc_threads, slot);
+                if (with_tc2) return STGCN_OK;
+                goto after_gconv;
+            }
+        }
+    }
+
+    {
     // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------
     if (!pl.recompute_tc1 && !d->x_bstride && !d->x_index_dev && tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt)) {
         // time-stepping kernel: weights stationary in registers, every input tile read once (stgcn_kernels_tstep.hip.h)
@@ -1210,7 +1292,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     gc.XT = pl.tiled_gc && v.terms > 1 ? ws + pl.ws_XT : nullptr;
     rc = launch_gconv_fwd(gc, st);
     if (rc) return rc;
-
+    }
+after_gconv:
     if (tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N)) {
         // ---- tmp_conv2 + GLU + LayerNorm([N, c2]) + dropout: one workgroup per (b, t2) slab ------------------------------------
         Tc2LnFwdArgs f;

@@ -528,6 +528,106 @@ __device__ __forceinline__ void gate_bwd(float dh, float u, float s, int act, fl
     }
 }
 
+// ================================================================================================
+// Chained launches: consecutive, DEPENDENT stages of a block run as roles of ONE launch; a consumer workgroup
+// starts as soon as the slab it needs is complete instead of after the producer kernel's last workgroup, and its prologue (weights,
+// operator fragments) overlaps the producer's tail.  Protocol (MI355X_MICROARCH.md "inter-workgroup visibility", recipe R1):
+//   * a workgroup's role and item come from an atomic TICKET, not from blockIdx: tickets are handed out in start order and the stages
+//     are numbered producer first, so a workgroup only ever waits for workgroups that are already running -- no assumption about
+//     dispatch order or residency (a consumer that holds a compute unit can never starve the producer it waits for);
+//   * the producer stores the hand-off tensor WRITE-THROUGH (16-byte sc1 stores), every storing wave drains its stores
+//     (s_waitcnt vmcnt(0)), a workgroup barrier (or a single storing wave) orders them before ONE lane bumps the slab's arrival counter
+//     (relaxed, agent scope);
+//   * the consumer's lane 0 polls that ONE word (relaxed, s_sleep between polls, bounded: a give-up sets a sticky error word instead of
+//     hanging the device), a workgroup barrier follows, and the hand-off tensor is then read with sc1 loads (never served from this
+//     CU's L1, which another CU's stores do not refresh);
+//   * the LAST workgroup to finish zeroes ticket and counters (kernels of one stream do not overlap, so the next launch finds them
+//     clean -- also under hipGraph replay, where no host code runs between launches).
+// The CPU emulator runs the workgroups of a launch one after another in ticket order: every counter is complete when it is read.
+// ================================================================================================
+constexpr int kChainHdr = 4;   // words: [0] ticket, [1] finished workgroups, [2] sticky error (1 + counter index of a wait that gave up), [3] spare
+struct ChainCtl {
+    unsigned* words;   // device words of this launch: header, then `ncount` arrival counters (null: the stage runs as its own launch)
+    int ncount;
+    unsigned total;    // workgroups of the launch
+};
+constexpr long long kChainSpinTicks = 200000000ll;   // 2 s of the 100 MHz wall clock
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) unsigned chain_gu32;
+__device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return __hip_atomic_load((const chain_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_st(unsigned* p, unsigned v) { __hip_atomic_store((chain_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned chain_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add((chain_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every wave that stored hand-off data calls this before the barrier / the counter bump (inline asm: the compiler cannot drop it)
+__device__ __forceinline__ void chain_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return *p; }
+__device__ __forceinline__ void chain_st(unsigned* p, unsigned v) { *p = v; }
+__device__ __forceinline__ unsigned chain_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+__device__ __forceinline__ void chain_drain_stores() {}
+#endif
+// virtual block index of this workgroup (all threads call; `slot` = one LDS word the launcher reserved behind the roles' own LDS)
+__device__ __forceinline__ int chain_enter(const ChainCtl& c, unsigned* slot) {
+    if (threadIdx.x == 0) *slot = chain_add(c.words, 1u);
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane((int)*slot);
+}
+// one lane, after the hand-off stores of the whole workgroup are drained and ordered before this call
+__device__ __forceinline__ void chain_publish(const ChainCtl& c, int idx, unsigned n = 1u) { chain_add(c.words + kChainHdr + idx, n); }
+// thread `leader` waits until counter idx has reached `expected` (all threads of the role call: a workgroup barrier follows)
+__device__ __forceinline__ void chain_wait(const ChainCtl& c, int idx, unsigned expected) {
+    if (threadIdx.x == 0) {
+        const unsigned* p = c.words + kChainHdr + idx;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (chain_ld(p) < expected) {
+            const long long t0 = wall_clock64();
+            while (chain_ld(p) < expected) {
+                __builtin_amdgcn_s_sleep(24);   // ~0.7 us between polls: hundreds of waiting workgroups share the counters' memory channels with the producers' bumps (tools/ubench/chain_probe.hip)
+                if (wall_clock64() - t0 > kChainSpinTicks) {   // never hang the device: flag it and go on (the results of this launch are void)
+                    chain_st(c.words + 2, 1u + (unsigned)idx);
+                    break;
+                }
+            }
+        }
+#elif !defined(__HIPCC__)
+        if (chain_ld(p) < expected) {   // (emulator: producers ran to completion before this workgroup started -- a short count is a protocol bug)
+            fprintf(stderr, "emu: chained launch: counter %d holds %u, expected %u (missing publish?)\n", idx, chain_ld(p), expected);
+            abort();
+        }
+#endif
+    }
+    __syncthreads();
+}
+// end of a role body (every wave that is still alive calls): the last workgroup of the launch to get here re-arms the control words
+__device__ __forceinline__ void chain_exit(const ChainCtl& c) {
+    __syncthreads();   // no wave of this workgroup publishes after the count below
+    if (threadIdx.x == 0) {
+        if (chain_add(c.words + 1, 1u) == c.total - 1) {
+            for (int i = 0; i < c.ncount; ++i) chain_st(c.words + kChainHdr + i, 0u);
+            chain_st(c.words, 0u);
+            chain_st(c.words + 1, 0u);
+        }
+    }
+}
+// 4 consecutive elements of a hand-off tensor, never from this CU's L1 (sc1 buffer load; `base` must be wave-uniform: kernel arguments and
+// the virtual block index only).  off = element offset from base.
+template <typename ET> __device__ __forceinline__ Raw4<ET> ldraw4_sc1(const ET* base, long nelem, int off) {
+    Raw4<ET> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nelem * (long)sizeof(ET)), 0x00020000);
+    if constexpr (sizeof(ET) == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off * 2, 0, 16);
+        r.v[0] = v[0]; r.v[1] = v[1];
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off * 4, 0, 16);
+        r.v = __builtin_bit_cast(f32x4, v);
+    }
+#else
+    (void)nelem;
+    r = ldraw4(base + off);
+#endif
+    return r;
+}
+
 // ---- block-wide sum of two values (256 threads) ----------------------------------------------
 // red must point to >= 8 floats of LDS.  All threads must call.
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {

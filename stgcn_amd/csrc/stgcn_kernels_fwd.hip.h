@@ -17,7 +17,8 @@ namespace stgcn {
 enum PackKind { PK_TCONV_FWD = 0, PK_TCONV_BWD = 1, PK_TCONV_BIAS = 2, PK_ALIGN_FWD = 3, PK_ALIGN_BWD = 4, PK_ALIGN_BIAS = 5,
                 PK_LIN_FWD = 6, PK_LIN_BWD = 7,
                 PK_TCONV_DENSE = 8, PK_ALIGN_DENSE = 9,
-                PK_TCONV_BWDT = 10 };   // one-step transposed conv as a dense GEMM: K = NC (o), cols = tap*Cin + i   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
+                PK_TCONV_BWDT = 10,
+                PK_ZERO = 11 };   // n zero words at dst (control words of the chained launches: re-armed by the launch that opens the step)   // one-step transposed conv as a dense GEMM: K = NC (o), cols = tap*Cin + i   // W_eff row major [KP][NC] (used to recompute a cheap first-layer conv in backward)   // nn.Linear weight (out = Cout, in = Cin): y = x W^T / dx = dy W
 
 struct PackJob {
     int kind;
@@ -29,7 +30,7 @@ struct PackJob {
     const float* ab;  // temporal-layer Align conv bias (Cout) or null
     int Cin, Cout, Kt, KCH, gated;
 };
-constexpr int kMaxPackJobs = 36;   // 2-3 ST blocks x 10 jobs + the head (stgcn_prepack)
+constexpr int kMaxPackJobs = 40;   // 2-3 ST blocks x 10 jobs + the head (stgcn_prepack)
 constexpr int kMaxStepCounters = 4;
 struct PackArgs {
     PackJob job[kMaxPackJobs];
@@ -65,7 +66,9 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     if (e >= j.n) return;
     const int NC = j.gated ? 2 * j.Cout : j.Cout;
     float v = 0.f;
-    if (j.kind == PK_TCONV_BIAS) {
+    if (j.kind == PK_ZERO) {
+        v = 0.f;
+    } else if (j.kind == PK_TCONV_BIAS) {
         v = j.b ? j.b[e] : 0.f;
         if (j.Cin > j.Cout && e < j.Cout && j.ab) v += j.ab[e];
     } else if (j.kind == PK_ALIGN_BIAS) {
@@ -1124,6 +1127,10 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
 // 13 waves for the 207-node graph: measured faster than 8 waves x 2 tiles), 8 waves x MAXQ tiles beyond.
 // ================================================================================================
 struct GconvFwdArgs {
+    // chained launch (ChainCtl of the launch, stgcn_device.hip.h): counter index bases, -1 = not chained on that side
+    int chain_in;        // counter chain_in + slab counts the node tiles of A[slab] that are complete (chain_expect of them)
+    unsigned chain_expect;
+    int chain_out;       // counter chain_out + slab: bumped once per part when this part's rows of G[slab] are written (through)
     const float* A;      // [slabs][N][16]
     const float* Lp;     // fragment-packed T_1 .. T_{Ks-1} (stgcn_gso_prepare), NP*NP floats each
     const float* W;      // cheb: [Ks][16][16] ; kipf: [16][16]
@@ -1138,13 +1145,19 @@ struct GconvFwdArgs {
 
 // SP = (b, t) slabs per workgroup (2: every operator fragment a wave loads multiplies the X chunks of two slabs; opt-in, STGCN_GC_SP=2:
 // measured equal / slower, the loop was never bound by the volume of that stream).
+inline size_t gconv_fwd_lds_bytes(int NP, int sp, int waves, bool chain_out) {   // X0 transposed (+ one 16 x 20 transposition tile per wave for written-through G rows)
+    return ((size_t)sp * 16 * (NP + 4) + (chain_out ? (size_t)waves * 16 * 20 : 0)) * sizeof(float);
+}
+// bid = (slab group, part) index of this workgroup, THREADS = threads of the role (the calling waves: threadIdx.x < THREADS)
 template <int MAXQ, int MAXW, typename ET, int SP>
-__global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
+__device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int bid, const int THREADS, const ChainCtl& chain) {
     typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
-    const int THREADS = blockDim.x, tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const int P = a.parts, part = (int)(blockIdx.x % (unsigned)P);
-    const long slab0 = (long)(blockIdx.x / (unsigned)P) * SP;   // slabs slab0 .. slab0 + SP - 1 (the last group may be short)
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int P = a.parts, part = (int)((unsigned)bid % (unsigned)P);
+    const long slab0 = (long)((unsigned)bid / (unsigned)P) * SP;   // slabs slab0 .. slab0 + SP - 1 (the last group may be short)
+    const bool cin = SP == 1 && chain.words && a.chain_in >= 0, cout = SP == 1 && chain.words && a.chain_out >= 0;
+    if (cin) chain_wait(chain, a.chain_in + (int)slab0, a.chain_expect);   // every node tile of A[slab0] has been written (through) by its producer
     // node tile of (wave w, slot q) = part + P * (w + nwaves * q) = wave + WAVES * q with the two names below
     const int wave = part + P * __builtin_amdgcn_readfirstlane(tid >> 6), WAVES = P * (THREADS >> 6);   // (scalar: the tile tests below are branches, not exec masks)
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
@@ -1165,7 +1178,8 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = idx0 + u * THREADS, n = idx >> 2, c4 = idx & 3;
-                rw[u] = ldraw4(Asl + (size_t)(n < N ? n : N - 1) * 16 + c4 * 4);
+                const int eo = (n < N ? n : N - 1) * 16 + c4 * 4;
+                rw[u] = cin ? ldraw4_sc1(Asl, (long)N * 16, eo) : ldraw4(Asl + eo);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1309,6 +1323,29 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     }
 
     const float bb = a.bias ? a.bias[l15] : 0.f;
+    if (cout) {
+        // hand-off form: the tile goes through a wave-private LDS tile so that a lane writes 4 channels of one node (16 bytes, write-through);
+        // the storing waves drain, the workgroup meets, ONE lane bumps the slab's counter
+        float* const tw = stgcn_smem + 16 * LDX + (tid >> 6) * (16 * 20);
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int ht = wave + WAVES * q;
+            if (ht < HT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tw[(4 * g + r) * 20 + l15] = fmaxf(yacc[q][0][r] + bb + res[q][0][r], 0.f);
+                wave_lds_sync();
+                const int h = ht * 16 + (lane >> 2);
+                const f32x4 v = ld4(tw + (lane >> 2) * 20 + 4 * (lane & 3));
+                if (h < N) stx4_wt(G_ + ((size_t)slab0 * N + h) * 16 + 4 * (lane & 3), v);
+                wave_lds_sync();
+            }
+        }
+        chain_drain_stores();
+        __syncthreads();
+        if (tid == 0) chain_publish(chain, a.chain_out + (int)slab0);
+        STGCN_PHASE(4, 15);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
         const int ht = wave + WAVES * q;
@@ -1325,6 +1362,10 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
         }
     }
     STGCN_PHASE(4, 15);
+}
+template <int MAXQ, int MAXW, typename ET, int SP>
+__global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
+    gconv_fwd_body<MAXQ, MAXW, ET, SP>(a, (int)blockIdx.x, (int)blockDim.x, ChainCtl{nullptr, 0, 0u});
 }
 
 #ifdef STGCN_EXPERIMENTS   // operator-stationary graph conv (opt-in, STGCN_GC_REG=<workgroups per CU>)

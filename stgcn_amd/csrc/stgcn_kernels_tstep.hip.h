@@ -822,11 +822,14 @@ struct Tc1FwdArgs {
     float* S;
     float* A;                 // [B][T1][N][16]
     int B, T, T1, N, node_tiles;
+    int chain_out;            // chained launch: counter chain_out + b * T1 + t counts the node tiles of A[b][t] written (-1: none)
 };
 inline size_t tc1_fwd_lds_bytes(int CIN, int Kt) { return ((size_t)(Kt + 1) * 16 * (CIN + 8) + 2 * 4 * 16 * 20) * sizeof(float); }
 
+// bid / nb: this workgroup's index among the nb workgroups of the role (the kernel's own grid, or the role's share of a chained launch);
+// chain.words != null: every A tile is published on counter chain_out + b * T1 + t (node_tiles arrivals complete a slab)
 template <int C0, int CIN, int KT, int ACT, typename ET>
-__global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
+__device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid, const int nb, const ChainCtl& chain) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
     typedef Mma<ET> MM;
     const ET* const x_ = et_ptr<ET>(a.x);
@@ -842,9 +845,10 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     const int N = a.N, T = a.T, T1 = a.T1;
     // this workgroup's range of the (item, step) sequence (identical in both roles): units [u_lo, u_hi), item = b * node_tiles + tile
     const long items = (long)a.B * a.node_tiles, units = items * T1;
-    const long u_lo = units * (long)blockIdx.x / (long)gridDim.x, u_hi = units * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    const long u_lo = units * (long)bid / (long)nb, u_hi = units * ((long)bid + 1) / (long)nb;
     const long item0 = u_lo / T1, item1 = u_hi / T1;
     const int s0 = (int)(u_lo - item0 * T1), s1 = (int)(u_hi - item1 * T1);
+    const bool chained = chain.words != nullptr && a.chain_out >= 0;
 
     if (roleM) {
         // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
@@ -895,8 +899,9 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
         }
     } else {
         // =========================================== E waves ===========================================================
-        const int r = tid >> 4, cq = tid & 15;         // x tiles: row r, float4 column cq (< CIN / 4); A tiles: row r, channel cq
-        const float bj = a.ba[cq];
+        const int r = tid >> 4, cq = tid & 15;         // x tiles: row r, float4 column cq (< CIN / 4)
+        const int fr = lane >> 2, fq = lane & 3;       // A tiles (first E wave only): row fr, channels 4 fq .. 4 fq + 3
+        const f32x4 bj = ld4(a.ba + 4 * fq);
         for (long item = item0; item <= item1 && item < items; ++item) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T1;
             if (sb >= se) continue;
@@ -911,10 +916,18 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
                 const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
                 if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);
             };
-            auto F = [&](int t) {   // A[t] = sum of the 4 waves' partial tiles + bias
-                const float* rd = red + (t & 1) * RED;
-                const float v = (rd[(0 * 16 + r) * 20 + cq] + rd[(1 * 16 + r) * 20 + cq]) + (rd[(2 * 16 + r) * 20 + cq] + rd[(3 * 16 + r) * 20 + cq]) + bj;
-                if (rv) stx1(A_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
+            // A[t] = sum of the 4 waves' partial tiles + bias: ONE wave, 16 bytes per lane, written through (round 3: 256 scalar stores).  In a
+            // chained launch the wave then drains its stores and bumps the slab's arrival counter: the graph conv of slab (b, t) starts when
+            // all node tiles have arrived, while this workgroup walks on.
+            auto F = [&](int t) {
+                if (tid >= 64) return;   // (wave-uniform)
+                const float* rd = red + (t & 1) * RED + fr * 20 + 4 * fq;
+                const f32x4 v = ((ld4(rd) + ld4(rd + 16 * 20)) + (ld4(rd + 2 * 16 * 20) + ld4(rd + 3 * 16 * 20))) + bj;
+                if (n0 + fr < N) stx4_wt(A_ + (((size_t)b * T1 + t) * N + n0 + fr) * 16 + 4 * fq, v);
+                if (chained) {
+                    chain_drain_stores();
+                    if (lane == 0) chain_publish(chain, a.chain_out + b * T1 + t);
+                }
             };
             Raw4<ET> xs[KT];
 #pragma unroll
@@ -940,6 +953,10 @@ __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
             F(se - 1);
         }
     }
+}
+template <int C0, int CIN, int KT, int ACT, typename ET>
+__global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
+    tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
 }
 
 // ================================================================================================
@@ -967,6 +984,8 @@ struct Tc2LnFwdArgs {
     float* mean;           // [B*T2]
     float* rstd;
     int T1, T2, N, NPR, act, training;   // NPR = roundup16(N)
+    int chain_in;          // chained launch: counter chain_in + b * T1 + t counts the parts of G[b][t] written (chain_expect of them); -1: none
+    unsigned chain_expect;
     float eps, keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
@@ -975,8 +994,9 @@ struct Tc2LnFwdArgs {
 constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
 inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 64) * sizeof(float); }
 
+// bid = the (b, t2) slab of this workgroup; chained launch: the KT input slabs G[b][t2 + tap] are awaited on counters chain_in + b * T1 + t2 + tap
 template <int C2, int KT, int NTI, int HV, typename ET>
-__global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
+__device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int bid, const ChainCtl& chain) {
     static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
     typedef Mma<ET> MM;
     ET* const U_ = et_ptr<ET>(a.U);
@@ -987,8 +1007,9 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]
     float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [3 * 4 * HV]
     const int tid = threadIdx.x, wv = tid >> 6, p = wv & (MT - 1), hf = wv >> 2, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long slab = blockIdx.x;
+    const long slab = bid;
     const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N, NPR = a.NPR, ntiles = NPR >> 4;
+    const bool cin = chain.words != nullptr && a.chain_in >= 0;
 
     STGCN_PHASE(9, 0);
     // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)
@@ -1000,6 +1021,16 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     }
     // stage the KT input slabs G[b][t2 + tap] (zero rows beyond N)
     const ET* Gb = et_ptr<ET>(a.G) + ((size_t)b * a.T1 + t2) * N * 16;
+    if (cin) {   // (the weight loads above are in flight while the last of the KT slabs arrives)
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap) chain_wait(chain, a.chain_in + b * a.T1 + t2 + tap, a.chain_expect);
+        for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
+            const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
+            const int eo = (tap * N + (rr < N ? rr : N - 1)) * 16 + 4 * q;
+            const f32x4 v = cvt4(ldraw4_sc1(Gb, (long)KT * N * 16, eo));
+            st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? v : zero4());
+        }
+    } else
     for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
         const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
         st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ldx4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
@@ -1145,6 +1176,34 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
         }
     }
     STGCN_PHASE(9, 5);
+}
+template <int C2, int KT, int NTI, int HV, typename ET>
+__global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
+    tc2_ln_fwd_body<C2, KT, NTI, HV, ET>(a, (int)blockIdx.x, ChainCtl{nullptr, 0, 0u});
+}
+
+// ================================================================================================
+// Chained forward of one ST block (stgcn_device.hip.h "Chained launches"): tmp_conv1 + Align (role 1, n1 workgroups of 512 threads walking the
+// time axis) -> graph conv (role 2, n2 = slabs x parts workgroups of gc_threads threads, slab (b, t) as soon as its node tiles have
+// arrived) [-> tmp_conv2 + LayerNorm + dropout (role 3, one workgroup of 1024 threads per output slab, as soon as its KT input slabs have
+// arrived)] in ONE launch.  Roles and items come from the ticket; waves beyond a role's width leave at once (a finished wave does not take
+// part in s_barrier); every workgroup reserves the widest role's threads and LDS.
+// ================================================================================================
+template <int CIN, int KT, int NTI, bool WITH_TC2, typename ET>
+__global__ __launch_bounds__(WITH_TC2 ? 1024 : 512) void stblock_fwd_chain_kernel(Tc1FwdArgs a1, GconvFwdArgs a2, Tc2LnFwdArgs a3, ChainCtl chain, int n1, int n2,
+                                                                                   int gc_threads, int slot) {
+    extern __shared__ float stgcn_smem[];
+    const int vb = chain_enter(chain, reinterpret_cast<unsigned*>(stgcn_smem) + slot);
+    if (vb < n1) {
+        if (threadIdx.x >= 512) return;
+        tc1_fwd_body<64, CIN, KT, 0, ET>(a1, vb, n1, chain);
+    } else if (vb < n1 + n2) {
+        if ((int)threadIdx.x >= gc_threads) return;
+        gconv_fwd_body<1, 16, ET, 1>(a2, vb - n1, gc_threads, chain);
+    } else {
+        if constexpr (WITH_TC2) tc2_ln_fwd_body<64, KT, NTI, 4, ET>(a3, vb - n1 - n2, chain);
+    }
+    chain_exit(chain);
 }
 
 }  // namespace stgcn

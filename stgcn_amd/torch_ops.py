@@ -59,6 +59,25 @@ def _params(params: Sequence[torch.Tensor], dev) -> List:
     return out
 
 
+def _buf(t: torch.Tensor, name: str, dev, dtype, min_numel: int = 0, shape=None) -> torch.Tensor:
+    """The C ABI takes raw device addresses: everything it would otherwise find out by faulting is checked here."""
+    if t.device != dev or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous {dtype} tensor on {dev}, got {t.dtype} on {t.device}"
+                         f"{'' if t.is_contiguous() else ' (not contiguous)'}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.numel() < min_numel:
+        raise ValueError(f"{name}: {t.numel()} elements, the plan of this call needs {min_numel}")
+    return t
+
+
+def _gso_floats(bc: ops.BlockConfig) -> int:
+    np_, nm_, ns_, tiled_ = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+    L = _lib.lib()
+    L.check(L.dll.stgcn_gso_layout(bc.n_vertex, int(ops.graph_terms(bc)), C.byref(np_), C.byref(nm_), C.byref(ns_), C.byref(tiled_)), "stgcn_gso_layout")
+    return int(np_.value) * int(np_.value) * int(nm_.value)
+
+
 def _fwd(x_cl, gso_pad, params, cfg, act, gc_type, droprate, training, seed, offset):
     ops._check_device(x_cl, "x_cl", activation=True)
     if x_cl.dim() != 4 or not x_cl.is_contiguous():
@@ -70,6 +89,7 @@ def _fwd(x_cl, gso_pad, params, cfg, act, gc_type, droprate, training, seed, off
         raise ValueError(f"x_cl is {tuple(x_cl.shape)}, cfg says N={bc.n_vertex}, c_in={bc.c_in}")
     desc = ops.make_desc(bc, B, T, bool(training), True, dtype=x_cl.dtype)
     plan = ops.query_plan(desc)
+    _buf(gso_pad, "gso_pad", x_cl.device, torch.float32, _gso_floats(bc))
     ps = _params(params, x_cl.device)
     y = torch.empty(B, plan.T2, N, bc.channels[2], dtype=x_cl.dtype, device=x_cl.device)
     saved = torch.empty(plan.saved_floats, dtype=torch.float32, device=x_cl.device)
@@ -85,9 +105,21 @@ def _bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate,
     L = _lib.lib()
     bc = _cfg(cfg, act, gc_type, droprate)
     B, T, N, c_in = x_cl.shape
+    if x_cl.dim() != 4 or not x_cl.is_contiguous():
+        raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
+    if N != bc.n_vertex or c_in != bc.c_in:
+        raise ValueError(f"x_cl is {tuple(x_cl.shape)}, cfg says N={bc.n_vertex}, c_in={bc.c_in}")
     desc = ops.make_desc(bc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
+    plan = ops.query_plan(ops.make_desc(bc, B, T, bool(training), True, dtype=x_cl.dtype))      # (the sizes stblock_fwd allocated with)
     ps = _params(params, x_cl.device)
     c0, c1, c2 = bc.channels
+    dev = x_cl.device
+    _buf(gso_t_pad, "gso_t_pad", dev, torch.float32, _gso_floats(bc))
+    _buf(y, "y", dev, x_cl.dtype, shape=(B, plan.T2, N, c2))
+    _buf(saved, "saved", dev, torch.float32, int(plan.saved_floats))
+    _buf(ws, "ws", dev, torch.float32, int(plan.ws_floats))
+    if dy.device != dev or tuple(dy.shape) != (B, plan.T2, N, c2):
+        raise ValueError(f"dy: expected shape {(B, plan.T2, N, c2)} on {dev}, got {tuple(dy.shape)} on {dy.device}")
     used = {"tc1_aw": c_in > c0, "tc1_ab": c_in > c0, "al_w": c0 > c1, "al_b": c0 > c1, "tc2_aw": c1 > c2, "tc2_ab": c1 > c2}
     grads = [torch.empty_like(p) if (p is not None and used.get(n, True)) else None for n, p in zip(PARAM_FIELDS, ps)]
     dy = dy.contiguous()
@@ -99,8 +131,8 @@ def _bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate,
     L.check(L.dll.stgcn_stblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), gso_t_pad.data_ptr(), dy.data_ptr(), y.data_ptr(),
                                               saved.data_ptr(), ws.data_ptr(), C.byref(gst), None if dx is None else dx.data_ptr(),
                                               int(seed), int(offset), None, None, ops._stream_of(x_cl)), "stgcn_stblock_backward")
-    empty = x_cl.new_empty(0, dtype=torch.float32)
-    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else empty for g in grads]
+    # (a fresh empty tensor per absent slot: dispatcher outputs must not alias each other)
+    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else x_cl.new_empty(0, dtype=torch.float32) for g in grads]
 
 
 def _cpu_guard(fn):
@@ -171,7 +203,14 @@ def _head_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_
     L = _lib.lib()
     hc = _head_cfg(cfg, act, droprate)
     B, T, N, c_in = x_cl.shape
+    if x_cl.dim() != 4 or not x_cl.is_contiguous():
+        raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
     desc = ops.make_head_desc(hc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
+    hplan = ops.query_head_plan(ops.make_head_desc(hc, B, T, bool(training), True, dtype=x_cl.dtype))
+    _buf(saved, "saved", x_cl.device, torch.float32, int(hplan.saved_floats))
+    _buf(ws, "ws", x_cl.device, torch.float32, int(hplan.ws_floats))
+    if dout.device != x_cl.device or dout.numel() != B * hplan.T1 * N:
+        raise ValueError(f"dout: expected {B * hplan.T1 * N} elements on {x_cl.device}, got {dout.numel()} on {dout.device}")
     ps = _head_params(params, x_cl.device)
     used = {"tc_aw": c_in > hc.channels[0], "tc_ab": c_in > hc.channels[0]}
     grads = [torch.empty_like(p) if (p is not None and used.get(n, True)) else None for n, p in zip(HEAD_PARAM_FIELDS, ps)]
@@ -182,8 +221,7 @@ def _head_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_
     L.check(L.dll.stgcn_outblock_backward_hook(C.byref(desc), C.byref(pst), x_cl.data_ptr(), dout.data_ptr(), saved.data_ptr(), ws.data_ptr(),
                                                C.byref(gst), None if dx is None else dx.data_ptr(), None, ops._stream_of(x_cl)),
             "stgcn_outblock_backward")
-    empty = x_cl.new_empty(0, dtype=torch.float32)
-    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else empty for g in grads]
+    return [dx if dx is not None else x_cl.new_empty(0)] + [g if g is not None else x_cl.new_empty(0, dtype=torch.float32) for g in grads]
 
 
 _libimpl_cuda = torch.library.Library(_NS, "IMPL", "CUDA")
@@ -196,6 +234,42 @@ _libimpl_cuda.impl("outblock_fwd", _head_fwd)
 _libimpl_cuda.impl("outblock_bwd", _head_bwd)
 _libimpl_cpu.impl("outblock_fwd", _cpu_guard(_head_fwd))
 _libimpl_cpu.impl("outblock_bwd", _cpu_guard(_head_bwd))
+
+
+# ---- shape-only ("fake") implementations: tracing / export see correctly shaped outputs without a GPU (the plan query is host code) ----
+def _fake_fwd(x_cl, gso_pad, params, cfg, act, gc_type, droprate, training, seed, offset):
+    bc = _cfg(cfg, act, gc_type, droprate)
+    B, T, N, _ = x_cl.shape
+    plan = ops.query_plan(ops.make_desc(bc, B, T, bool(training), True, dtype=x_cl.dtype))
+    return (x_cl.new_empty((B, int(plan.T2), N, bc.channels[2])), x_cl.new_empty((int(plan.saved_floats),), dtype=torch.float32),
+            x_cl.new_empty((int(plan.ws_floats),), dtype=torch.float32))
+
+
+def _fake_bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate, training, seed, offset, need_dx):
+    c_in, c0, c1, c2 = (int(v) for v in cfg[:4])
+    used = {"tc1_aw": c_in > c0, "tc1_ab": c_in > c0, "al_w": c0 > c1, "al_b": c0 > c1, "tc2_aw": c1 > c2, "tc2_ab": c1 > c2}
+    return [torch.empty_like(x_cl) if need_dx else x_cl.new_empty(0)] + [
+        torch.empty_like(p) if (p.numel() and used.get(n, True)) else x_cl.new_empty(0, dtype=torch.float32) for n, p in zip(PARAM_FIELDS, params)]
+
+
+def _fake_head_fwd(x_cl, params, cfg, act, droprate, training, seed, offset):
+    hc = _head_cfg(cfg, act, droprate)
+    B, T, N, _ = x_cl.shape
+    plan = ops.query_head_plan(ops.make_head_desc(hc, B, T, bool(training), True, dtype=x_cl.dtype))
+    return (x_cl.new_empty((B, int(plan.T1), N), dtype=torch.float32), x_cl.new_empty((int(plan.saved_floats),), dtype=torch.float32),
+            x_cl.new_empty((int(plan.ws_floats),), dtype=torch.float32))
+
+
+def _fake_head_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_dx):
+    from ._lib import HEAD_PARAM_FIELDS
+    c_in, c0 = int(cfg[0]), int(cfg[1])
+    used = {"tc_aw": c_in > c0, "tc_ab": c_in > c0}
+    return [torch.empty_like(x_cl) if need_dx else x_cl.new_empty(0)] + [
+        torch.empty_like(p) if (p.numel() and used.get(n, True)) else x_cl.new_empty(0, dtype=torch.float32) for n, p in zip(HEAD_PARAM_FIELDS, params)]
+
+
+for _name, _fn in (("stblock_fwd", _fake_fwd), ("stblock_bwd", _fake_bwd), ("outblock_fwd", _fake_head_fwd), ("outblock_bwd", _fake_head_bwd)):
+    torch.library.register_fake(f"{_NS}::{_name}", _fn, lib=_libdef)
 
 
 class _Block(torch.autograd.Function):

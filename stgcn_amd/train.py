@@ -13,7 +13,7 @@ from the optimizer's work exactly like torch.optim.AdamW skips ``grad is None`` 
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -51,6 +51,65 @@ def init_distributed(backend: Optional[str] = None):
         DropoutStream.rank_offset = rank        # survives a later DropoutStream.manual_seed(s) of user code (set-seed-after-init order)
         DropoutStream.manual_seed(base)
     return rank, local_rank, world
+
+
+def probe_collective_capture(timeout_s: float = 60.0) -> Tuple[bool, str]:
+    """Can this machine record an RCCL all-reduce inside a hipGraph and replay it?  Every rank runs the SAME small experiment in a CHILD
+    process (its own process group on MASTER_PORT + 17, same GPU, a 1 MB buffer: warm-up collective, capture, three replays, value check)
+    under a watchdog: a capture or replay that hangs -- the failure mode that cannot be caught with try / except -- costs ``timeout_s``
+    and one killed child, not the run.  The verdicts are combined over the ranks (all must succeed).  Returns (ok, reason)."""
+    rank, local_rank, world = dist_env()
+    if not (dist.is_available() and dist.is_initialized()) or world <= 1:
+        return False, "no process group"
+    if dist.get_backend() != "nccl":
+        return False, f"backend {dist.get_backend()}: its collectives are host calls, not stream operations"
+    ok, why = run_collective_capture_child(dict(os.environ), timeout_s)
+    flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", local_rank))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0 and ok:
+        ok, why = False, "another rank's probe failed"
+    return ok, why
+
+
+def run_collective_capture_child(env: dict, timeout_s: float = 60.0) -> Tuple[bool, str]:
+    """One rank's share of ``probe_collective_capture``: the experiment in a child process (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+    ``env``, port shifted by 17 so that it cannot meet the parent's group), killed after ``timeout_s``."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "r, lr, w = int(os.environ['RANK']), int(os.environ['LOCAL_RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "torch.cuda.set_device(lr)\n"
+        "dist.init_process_group('nccl', rank=r, world_size=w, device_id=torch.device('cuda', lr))\n"
+        "t = torch.full((1 << 18,), float(r + 1), device='cuda')\n"
+        "dist.all_reduce(t); torch.cuda.synchronize()\n"
+        "t.fill_(float(r + 1))\n"
+        "s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(g, capture_error_mode='thread_local'):\n"
+        "    dist.all_reduce(t)\n"
+        "    t.mul_(1.0 / w)\n"
+        "for _ in range(3):\n"
+        "    t.fill_(float(r + 1)); g.replay()\n"
+        "torch.cuda.synchronize()\n"
+        "want = sum(range(1, w + 1)) / w\n"
+        "assert abs(float(t[0]) - want) < 1e-6 and abs(float(t[-1]) - want) < 1e-6, (float(t[0]), want)\n"
+        "dist.destroy_process_group()\n"
+        "print('CAPTURE_OK')\n")
+    env = dict(env)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ok, why = False, ""
+    try:
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s)
+        ok = p.returncode == 0 and "CAPTURE_OK" in p.stdout
+        why = "" if ok else ("probe failed: " + (p.stderr.strip().splitlines() or ["rc %d" % p.returncode])[-1][:200])
+    except subprocess.TimeoutExpired:
+        why = f"probe hung for {timeout_s:.0f} s (killed)"
+    except Exception as e:  # noqa: BLE001
+        why = "probe could not run: " + repr(e)[:200]
+    return ok, why
 
 
 def sync_operators(model, src: int = 0) -> None:
@@ -308,13 +367,18 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, x_example: torch.Tensor, y_example: torch.Tensor, world: int = 1, warmup: int = 3,
                  chains: int = 1, fused: Optional[bool] = None, series: Optional[torch.Tensor] = None, n_his: int = 12,
-                 n_pred: int = 3, rank: int = 0):
+                 n_pred: int = 3, rank: int = 0, capture_collective: bool = False):
         """``series``: optional resident (time, N) float32 device tensor (already z-scored).  The step then takes its windows
         straight from it (device-side windowing): window b of the minibatch is rows
         [s + b, s + b + n_his) of the series (read in place through a strided view, no (num, 1, n_his, N) tensor, no per-step
         input copies), its label row s + b + n_his + n_pred - 1 (script/dataloader.py:32-47), and s advances by the global
         batch on the device every replay (unshuffled order like main.py:127, wrapping at the end of the series).  Call the
-        step without arguments; ``x_example`` / ``y_example`` only give the batch size."""
+        step without arguments; ``x_example`` / ``y_example`` only give the batch size.
+
+        ``capture_collective`` (world > 1): record the gradient all-reduce INSIDE the graph -- one graph per step (forward, backward,
+        reductions, RCCL all-reduce, AdamW), no host round trip around the collective.  Only for a backend whose collectives are stream
+        operations (nccl = RCCL); the caller is expected to have probed that such a capture works on this machine
+        (``probe_collective_capture``: a capture that hangs instead of raising would otherwise take the run with it)."""
         from .layers import DropoutStream
         assert x_example.is_cuda, "hipGraph capture needs the MI355X path"
         self.model, self.opt, self.world = model, optimizer, world
@@ -381,6 +445,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         if not self.fused:
             self.opt.zero_grad(set_to_none=True)
+        self.capture_collective = bool(capture_collective) and world > 1
         self.g1 = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while this thread captures: "thread_local" keeps such calls of OTHER
         # threads from invalidating the capture (the default "global" mode is for single-threaded programs)
@@ -390,6 +455,12 @@ class GraphedTrainStep:
                 self.loss = self._fused_fwd_bwd()
                 if world > 1:
                     self.flat = self.arena.flat
+                    if self.capture_collective:      # the whole step in ONE graph: collective and optimizer follow on the capturing stream
+                        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                        self.opt.step()
+                        if not self.fold:
+                            DropoutStream.advance()
+                            self._advance_series()
                 else:
                     self.opt.flush_with(self.arena.sink, self.arena.grads, bump_step=not self.fold)
                     if not self.fold:
@@ -400,12 +471,19 @@ class GraphedTrainStep:
                 if world > 1:
                     self.live = [p for p in model.parameters() if p.grad is not None]
                     self.flat = torch.cat([p.grad.reshape(-1) for p in self.live])
+                    if self.capture_collective:
+                        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                        self.flat.mul_(1.0 / world)
+                        torch._foreach_copy_([p.grad.reshape(-1) for p in self.live], list(self.flat.split([p.numel() for p in self.live])))
+                        self.opt.step()
+                        DropoutStream.advance()
+                        self._advance_series()
                 else:
                     self.opt.step()
                     DropoutStream.advance()
                     self._advance_series()
         self.g2 = None
-        if world > 1:
+        if world > 1 and not self.capture_collective:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2, pool=self.g1.pool(), **cap):
                 if not self.fused:

@@ -137,6 +137,20 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     stages = {}
     dx_ref, g_ref = st.stblock_bwd(cl(dy_np), svh, g64, bp, Kt, c_in, channels, gct, act, pdrop, need_dx=c_in > 1, q=Q, gc_form=gc_form,
                                    stages=stages)
+    # How much of the backward the teacher forcing hides: the ReLU-mask flip rate between the two forwards, and the
+    # gradients against the PURE oracle (its own saved tensors, no forcing), bounded in rms: a flipped mask element changes the gradient
+    # entering the graph conv by O(1) there, so the un-forced error is ~sqrt(flip rate) in rms, not a kernel defect.
+    flip = float(((svh["G"] > 0) != (np.asarray(sv["G"]) > 0)).mean())
+    f32["relu_flip_rate"] = flip
+    dx_u, g_u = st.stblock_bwd(cl(dy_np), sv, g64, bp, Kt, c_in, channels, gct, act, pdrop, need_dx=c_in > 1, q=Q, gc_form=gc_form)
+    rms = lambda a: float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
+    if c_in > 1:
+        f32["unforced_rms.dx"] = rms(cl(bf16_numpy(x.grad)) - dx_u) / max(1e-30, rms(dx_u))
+    worst = 0.0
+    for name, prm in zip(_lib.PARAM_FIELDS, params):
+        if prm is not None and prm.grad is not None and g_u.get(name) is not None:
+            worst = max(worst, rms(prm.grad.cpu().numpy().astype(np.float64) - g_u[name].reshape(prm.shape)) / max(1e-30, rms(g_u[name])))
+    f32["unforced_rms.param_grads_worst"] = worst
     stored["bwd.dYg"] = err_stored(seg_bf16(ws, plan.ws_dYg, (B, T1, N, c1)), stages["dYg"])
     stored["bwd.dA"] = err_stored(seg_bf16(ws, plan.ws_dA, (B, T1, N, c1)), stages["dA"])
     if c_in > 1:
@@ -154,6 +168,11 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
 
 
 def assert_bf16_errors(stored, f32):
+    import json, os
+    if os.environ.get("STGCN_BF16_REPORT"):      # (GPU passes: the measured flip rates / un-forced errors go into profiles/)
+        with open(os.environ["STGCN_BF16_REPORT"], "a") as fh:
+            fh.write(json.dumps({"f32": {k: v for k, v in f32.items() if "flip" in k or "unforced" in k},
+                                 "stored_rms": {k: round(v["rms"], 6) for k, v in stored.items()}}) + "\n")
     bad = {}
     for k, e in stored.items():
         if k.endswith("_vs_fp64"):
@@ -164,7 +183,9 @@ def assert_bf16_errors(stored, f32):
             bad[k] = e
     for k, v in f32.items():
         # (LayerNorm statistics are fp32 sums, but of values downstream of bf16 tensors in which a few elements differ by one ulp)
-        tol = 0.0 if (k.startswith("grad_none_ok") or k.endswith("bitwise")) else (1e-3 if k in ("fwd.mean", "fwd.rstd") else F32_TOL)
+        # relu_flip_rate: measured 0 - 3e-4 (elements of G within one bf16 ulp of zero); un-forced gradients: rms error <= 5 % (measured ~1 %)
+        tol = (0.0 if (k.startswith("grad_none_ok") or k.endswith("bitwise")) else 1e-3 if k in ("fwd.mean", "fwd.rstd") else
+               2e-3 if k == "relu_flip_rate" else 5e-2 if k.startswith("unforced_rms") else F32_TOL)
         if not (v <= tol):
             bad[k] = v
     assert not bad, f"out of tolerance: {bad}\nstored: {stored}\nf32: {f32}"

@@ -48,6 +48,12 @@ State g;
 static void fiber_entry() {
     g.body();
     g.cur->done = true;
+    // a finished thread no longer takes part in workgroup barriers (the hardware does not count ended waves in s_barrier: the roles of a
+    // chained launch that are narrower than the launch's block let their surplus waves return at once)
+    if (--g.live > 0 && g.bar_arrived == g.live) {
+        g.bar_arrived = 0;
+        g.bar_gen++;
+    }
     emu_switch(&g.cur->sp, g.main_sp);
     abort();   // a finished fiber is never resumed
 }
@@ -65,7 +71,7 @@ static void wait_for(const unsigned* gen, unsigned my) {
 
 void block_barrier() {
     const unsigned my = g.bar_gen;
-    if (++g.bar_arrived == g.nthreads) {
+    if (++g.bar_arrived == g.live) {
         g.bar_arrived = 0;
         g.bar_gen++;
         return;
@@ -106,6 +112,7 @@ void run_block() {
     }
     g.waves.assign(n / kWave, WaveState());
     g.bar_arrived = 0;
+    g.live = n;
     // poison LDS so that reads of never-written shared memory show up as NaN
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     for (size_t i = 0; i < kLdsBytes / sizeof(float); ++i) stgcn::stgcn_smem[i] = qnan;

@@ -95,6 +95,7 @@ struct State {
     int bar_arrived = 0;
     unsigned bar_gen = 0;
     int nthreads = 0;
+    int live = 0;                       // threads of the running workgroup that have not returned yet
     std::vector<WaveState> waves;
     long n_mfma = 0;
 };
@@ -206,6 +207,8 @@ static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned s
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+static inline long long wall_clock64() { static long long t = 0; return ++t; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier()   // (the point where the lanes of a wave meet: LDS exchange inside a wave)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

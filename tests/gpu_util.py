@@ -68,6 +68,10 @@ def run_block_case(c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None
         return float(np.abs(buf[off:off + ref.size].reshape(ref.shape) - ref).max())
 
     err = {}
+    # chained launches: the sticky error word (a bounded wait gave up) of both workspaces, and ticket / finished-workgroup words re-armed
+    for nm, buf in (("autograd", wsc.buf), ("direct", ws2)):
+        cw = buf[plan.ws_chain:plan.ws_chain + 4].view(torch.int32).cpu().numpy()
+        err[f"grad_none_ok.chain_words_{nm}"] = float(abs(cw[:3]).sum())
     if not plan.recompute_tc1:
         err["fwd.U1"] = seg(svn, plan.sv_U1, sv["U1"])
         err["fwd.S1"] = seg(svn, plan.sv_S1, sv["S1"])

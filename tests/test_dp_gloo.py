@@ -156,3 +156,23 @@ def test_sync_operators_broadcasts_rank0_graph(tmp_path):
     assert torch.equal(r0["before"], r0["after"])                       # rank 0 keeps its operator
     assert not torch.equal(r1["before"], r1["after"])                   # rank 1 trained on another graph before the broadcast
     assert torch.equal(r0["after"], r1["after"])                        # identical replicas afterwards
+
+
+def _probe_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from stgcn_amd.train import init_distributed, probe_collective_capture
+    init_distributed("gloo")
+    res = probe_collective_capture(timeout_s=5.0)
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_capture_probe_declines_host_side_backends(tmp_path):
+    """bench.py --gpus N asks train.probe_collective_capture() whether the all-reduce may be recorded inside the step's graph; a gloo group
+    (CPU collectives, this test) must be turned down without starting the child experiment, and identically on every rank."""
+    out = str(tmp_path / "p.pt")
+    mp.spawn(_probe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok, why = torch.load(out)
+    assert ok is False and "gloo" in why

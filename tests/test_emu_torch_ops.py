@@ -107,3 +107,31 @@ def test_head_operators_equal_the_module_path():
         else:
             assert torch.equal(a.grad, b.grad), n
     assert "-> (Tensor, Tensor, Tensor)" in str(torch.ops.stgcn.outblock_fwd.default._schema)
+
+
+def test_operator_arguments_are_validated_and_fake_impls_give_shapes():
+    """the dispatcher operators hand raw addresses to the C ABI, so wrong-sized / wrong-typed / non-contiguous buffers must be
+    refused in Python; absent gradient slots come back as DISTINCT empty tensors; the fake (meta) implementations produce the shapes."""
+    bcfg, gp, gt, x, dy, plist = _case(64, 3, 3, "cheb_graph_conv", "glu", 17, 1, 6)
+    params = [torch.empty(0) if t is None else t for t in plist]
+    x_cl = x.permute(0, 2, 3, 1).contiguous()
+    cfg = [64, 64, 16, 64, 3, 3, 17]
+    y, saved, ws = torch.ops.stgcn.stblock_fwd(x_cl, gp, params, cfg, "glu", "cheb_graph_conv", 0.5, False, 0, 0)
+    args = lambda **kw: [kw.get("dy", torch.ones_like(y)), x_cl, kw.get("gt", gt), kw.get("y", y), kw.get("saved", saved), kw.get("ws", ws), params,
+                         cfg, "glu", "cheb_graph_conv", 0.5, False, 0, 0, True]
+    for bad in (dict(saved=saved[:-1]), dict(ws=ws[: ws.numel() // 2]), dict(y=y[:, :1]), dict(saved=saved.double()), dict(gt=gt[..., :-1]),
+                dict(dy=torch.ones(1, 2, 17, 32)), dict(ws=ws[::2])):
+        with pytest.raises(ValueError):
+            torch.ops.stgcn.stblock_bwd(*args(**bad))
+    with pytest.raises(ValueError):
+        torch.ops.stgcn.stblock_fwd(x_cl, gp[..., :-1], params, cfg, "glu", "cheb_graph_conv", 0.5, False, 0, 0)
+    out = torch.ops.stgcn.stblock_bwd(*args())
+    empties = [t for t in out if t.numel() == 0]
+    assert len(empties) >= 2 and len({id(t) for t in empties}) == len(empties)
+    # fake tensors: shapes without running anything
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode() as mode:
+        fx = mode.from_tensor(x_cl)
+        fy, fs, fw = torch.ops.stgcn.stblock_fwd(fx, mode.from_tensor(gp), [mode.from_tensor(p) for p in params], cfg, "glu", "cheb_graph_conv", 0.5,
+                                                 False, 0, 0)
+        assert tuple(fy.shape) == tuple(y.shape) and fs.numel() == saved.numel() and fw.numel() == ws.numel()

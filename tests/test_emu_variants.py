@@ -89,3 +89,19 @@ def test_layernorm_slab_statistics_prepass():
     run_subset({"STGCN_FUSE": str(0x7fffffff & ~2), "STGCN_LN_STATS_MIN_CHUNKS": "1"}, [BWD], "17-2-6")
     # (bf16: the tiled configurations take this LayerNorm; tests/test_emu_bf16.py::test_tiled_block_bf16_matches_bf16_oracle with the pre-pass forced)
     run_subset({"STGCN_LN_STATS_MIN_CHUNKS": "1"}, ["tests/test_emu_bf16.py"], "tiled_block_bf16 and 37-2-6")
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_chained_forward_launch(mode, monkeypatch):
+    """STGCN_CHAIN (opt-in): tmp_conv1 + Align -> graph conv [-> tmp_conv2 + LayerNorm + dropout] as ticketed roles of
+    ONE launch with per-slab arrival counters (write-through hand-off tensors, sc1 loads).  The emulator runs the workgroups in ticket order,
+    so what is checked here is the role dispatch, the early exit of surplus waves, the counter bookkeeping (a short count aborts) and the
+    16-byte hand-off store layouts -- every forward stage and gradient against the oracle, fp32 and bf16."""
+    from tests import test_emu_backward as tb
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    from tests.emu_util import bind_emulator
+    monkeypatch.setenv("STGCN_CHAIN", mode)
+    tb.test_block_backward(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 37, 2, 8, True)
+    tb.test_block_backward(64, (64, 16, 64), 3, 2, "graph_conv", "glu", 20, 3, 6, False)
+    bind_emulator()
+    assert_bf16_errors(*run_block_case_bf16("cpu", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 37, 2, 8, True))

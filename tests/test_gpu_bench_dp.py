@@ -26,4 +26,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["steps"] == 10 and out["scaling"] == "weak"
     assert out["config"]["launch"] == "hipGraph replay", out["config"]
-    assert out["config"]["allreduce"]["bytes"] > 900_000
+    ar = out["config"]["allreduce"]
+    assert ar["bytes"] > 900_000 and 0 < ar["exposed_fraction_of_step"] < 1
+    # gloo collectives are host calls: the capture probe must say so and the step must stay in the two-graph form
+    assert ar["captured_in_graph"] is False and "gloo" in ar["capture_probe"], ar

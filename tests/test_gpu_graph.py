@@ -155,3 +155,55 @@ def test_resident_series_step_equals_explicit_batches():
     assert np.allclose(losses, ref_losses[-4:], rtol=1e-5, atol=0), (losses, ref_losses)
     for k, v in m2.state_dict().items():
         assert float((v - m.state_dict()[k]).abs().max()) <= 2e-5, k
+
+
+def test_tail_step_between_replays_keeps_the_window_index():
+    """ADVICE r2 / VERDICT r3 weak 3, on the hardware: a captured step with device-side windows and FOLDED counters (the pack launch advances
+    the window index), then the eager partial batch of an epoch's end (train.tail_step), then replays again.  The tail step must not move
+    the window index, must consume one dropout position and one optimizer step, and the whole sequence must equal the same sequence of
+    eager steps on a twin model."""
+    from stgcn_amd import DropoutStream
+    from stgcn_amd.train import GraphedTrainStep, make_optimizer, tail_step, train_step
+    B, N, n_his, n_pred = 8, 207, 12, 3
+    g = torch.Generator().manual_seed(5)
+    series = torch.randn(6 * B + n_his + n_pred, N, generator=g).to(DEV)
+    xt = torch.randn(5, 1, n_his, N, generator=g).to(DEV)          # the partial batch: 5 of 8 windows
+    yt = torch.randn(5, N, generator=g).to(DEV)
+
+    def windows(s):
+        x = torch.stack([series[s + b:s + b + n_his] for b in range(B)]).unsqueeze(1)
+        return x, series[s + n_his + n_pred - 1:s + n_his + n_pred - 1 + B]
+
+    DropoutStream.use_device_counter(torch.device(DEV))
+    DropoutStream.manual_seed(3)
+    m1 = _make(0.0)
+    o1 = make_optimizer(m1, capturable=True)
+    with GraphedTrainStep(m1, o1, *windows(0), warmup=2, series=series, n_his=n_his, n_pred=n_pred) as gs:
+        assert gs.fold and gs.index is not None
+        usable = (series.shape[0] - n_his - n_pred) // B * B
+        l1 = [float(gs())]
+        i_before = int(gs.index.item())
+        c_before, s_before = int(DropoutStream.counter.item()), int(o1.device_step_counter(torch.device(DEV)).item())
+        lt = float(tail_step(m1, o1, xt, yt))
+        assert int(gs.index.item()) == i_before                                              # the window position is untouched ...
+        assert int(DropoutStream.counter.item()) == c_before + DropoutStream.SITE_STRIDE      # ... one dropout position consumed
+        assert int(o1.device_step_counter(torch.device(DEV)).item()) == s_before + 1          # ... one optimizer step counted
+        l1 += [float(gs()), float(gs())]
+        assert int(gs.index.item()) == (i_before + 2 * B) % usable
+    # the same sequence eagerly: the constructor ran warmup + 1 steps on windows 0, B, 2B (folded: the pack launch advances BEFORE the step)
+    DropoutStream.disable_device_counter()
+    m2 = _make(0.0)
+    o2 = make_optimizer(m2)
+    pos = 0
+    for _ in range(3):
+        train_step(m2, o2, *windows(pos % usable))
+        pos += B
+    l2 = [float(train_step(m2, o2, *windows(pos % usable)))]
+    pos += B
+    lt2 = float(tail_step(m2, o2, xt, yt))
+    for _ in range(2):
+        l2.append(float(train_step(m2, o2, *windows(pos % usable))))
+        pos += B
+    assert np.allclose(l1 + [lt], l2 + [lt2], rtol=2e-5, atol=0), (l1, lt, l2, lt2)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    assert max(float((sd1[k] - sd2[k]).abs().max()) for k in sd1) <= 2e-5

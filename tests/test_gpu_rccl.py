@@ -66,3 +66,15 @@ def test_two_gpus_rccl_equal_one_big_batch(tmp_path):
     errs = {k: float((got[k] - v.cpu()).abs().max()) for k, v in model.state_dict().items()}
     assert float(torch.quantile(diffs[torch.randperm(diffs.numel())[:200000]], 0.999)) <= 2e-5, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     assert max(errs.values()) <= 5e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+
+
+def test_rccl_all_reduce_inside_a_hipgraph_single_rank():
+    """The experiment `train.probe_collective_capture` runs on every rank before bench.py --gpus N records the gradient all-reduce inside
+    the step's graph, here with ONE rank on the one GPU of the test box: an RCCL all-reduce is captured, replayed three
+    times and its result checked, in a child process under the watchdog.  (Two ranks cannot share a GPU under RCCL; the two-rank form of the
+    same code runs on the driver's multi-GPU node.)"""
+    from stgcn_amd.train import run_collective_capture_child
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ok, why = run_collective_capture_child(env, timeout_s=120.0)
+    assert ok, why

@@ -31,6 +31,7 @@ constexpr long long kSpinLimit = 100000000ll;   // 1 s of the 100 MHz wall clock
 struct Ctl {
     unsigned* ticket; unsigned* done; unsigned* ready; unsigned* error; unsigned* epoch; unsigned* bad;
     long long* stamps;   // [4]: min producer start, max producer end, min consumer start, max consumer end (wall clock)
+    int cstride;         // words between the arrival counters of consecutive slabs (1: six counters per 128-byte line; 32: a line each)
 };
 
 __device__ __forceinline__ void busy_us(float us) {
@@ -49,7 +50,7 @@ __device__ void producer_body(float* A, Ctl c, int vb, float prod_us) {
     if (tid == 0) atomicMin((unsigned long long*)&c.stamps[0], (unsigned long long)wall_clock64());
     for (long u = lo; u < hi; ++u) {
         const int item = (int)(u / T), t = (int)(u - (long)item * T), b = item / TILES, j = item - b * TILES, slab = b * T + t;
-        busy_us(prod_us);
+        if (wave != 4) busy_us(prod_us);   // (the storing wave is an "E" wave: it is not on the critical path of the step)
         __syncthreads();
         if (wave == 4) {   // one "E" wave writes the tile: lane -> (row = lane >> 2, quad = lane & 3)
             const int row = j * 16 + (lane >> 2), q = lane & 3;
@@ -61,14 +62,14 @@ __device__ void producer_body(float* A, Ctl c, int vb, float prod_us) {
             }
             if (CHAIN) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains (write-through stores: acknowledged by memory)
-                if (lane == 0) __hip_atomic_fetch_add((gu32*)c.ready + slab, 1u, RLX_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add((gu32*)c.ready + slab * c.cstride, 1u, RLX_AGENT);
             }
         }
     }
     if (tid == 0) atomicMax((unsigned long long*)&c.stamps[1], (unsigned long long)wall_clock64());
 }
 
-template <int MODE>   // 0: plain loads (separate launch), 1: wait + sc1 loads, 2: wait + acquire fence + plain loads
+template <int MODE, int SLEEP = 8, int REP = 1>   // 0: plain loads (separate launch), 1: wait + sc1 loads, 2: wait + acquire fence + plain loads
 __device__ void consumer_body(const float* A, float* out, Ctl c, int vb, float cons_us, float* lds) {
     const unsigned epoch = __hip_atomic_load((gu32*)c.epoch, RLX_AGENT);
     const int tid = threadIdx.x, slab = vb / PARTS;
@@ -81,8 +82,8 @@ __device__ void consumer_body(const float* A, float* out, Ctl c, int vb, float c
         lds[tid] = s;
         if (tid == 0) {
             const long long t0 = wall_clock64();
-            while (__hip_atomic_load((gu32*)c.ready + slab, RLX_AGENT) < (unsigned)TILES) {
-                __builtin_amdgcn_s_sleep(8);
+            while (__hip_atomic_load((gu32*)c.ready + slab * c.cstride, RLX_AGENT) < (unsigned)TILES) {
+                for (int r = 0; r < REP; ++r) __builtin_amdgcn_s_sleep(SLEEP);
                 if (wall_clock64() - t0 > kSpinLimit) { __hip_atomic_store((gu32*)c.error, 1u, RLX_AGENT); break; }
             }
             if (MODE == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -124,7 +125,7 @@ __device__ __forceinline__ void last_finisher_reset(Ctl c, unsigned total) {
     if (threadIdx.x == 0) {
         const unsigned d = __hip_atomic_fetch_add((gu32*)c.done, 1u, RLX_AGENT);
         if (d == total - 1) {
-            for (int i = 0; i < SLABS; ++i) __hip_atomic_store((gu32*)c.ready + i, 0u, RLX_AGENT);
+            for (int i = 0; i < SLABS; ++i) __hip_atomic_store((gu32*)c.ready + i * c.cstride, 0u, RLX_AGENT);
             __hip_atomic_store((gu32*)c.ticket, 0u, RLX_AGENT);
             __hip_atomic_store((gu32*)c.done, 0u, RLX_AGENT);
             __hip_atomic_fetch_add((gu32*)c.epoch, 1u, RLX_AGENT);
@@ -132,7 +133,7 @@ __device__ __forceinline__ void last_finisher_reset(Ctl c, unsigned total) {
     }
 }
 
-template <int CMODE>
+template <int CMODE, int SLEEP, int REP>
 __global__ __launch_bounds__(512) void chain_kernel(float* A, float* out, Ctl c, float prod_us, float cons_us) {
     extern __shared__ float smem[];
     if (threadIdx.x == 0) reinterpret_cast<unsigned*>(smem)[300] = __hip_atomic_fetch_add((gu32*)c.ticket, 1u, RLX_AGENT);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512) void chain_kernel(float* A, float* out, Ctl c,
         producer_body<true>(A, c, vb, prod_us);
     } else {
         if (threadIdx.x >= 256) return;   // the consumer role is 4 waves wide: the other 4 leave (a finished wave is not counted by s_barrier)
-        consumer_body<CMODE>(A, out, c, vb - NPROD, cons_us, smem);
+        consumer_body<CMODE, SLEEP, REP>(A, out, c, vb - NPROD, cons_us, smem);
     }
     last_finisher_reset(c, NPROD + NCONS);
 }
@@ -161,16 +162,16 @@ int main(int argc, char** argv) {
     const int reps = argc > 3 ? atoi(argv[3]) : 200;
     float *A, *out; unsigned* words; long long* stamps;
     CK(hipMalloc(&A, (size_t)SLABS * N * 16 * 4 + 4096)); CK(hipMalloc(&out, (size_t)NCONS * 256 * 4));
-    CK(hipMalloc(&words, (SLABS + 64) * 4)); CK(hipMalloc(&stamps, 64));
-    CK(hipMemset(words, 0, (SLABS + 64) * 4)); CK(hipMemset(A, 0, (size_t)SLABS * N * 16 * 4 + 4096));
-    Ctl c{words, words + 1, words + 16, words + 2, words + 3, words + 4, stamps};
+    CK(hipMalloc(&words, (SLABS * 32 + 64) * 4)); CK(hipMalloc(&stamps, 64));
+    CK(hipMemset(words, 0, (SLABS * 32 + 64) * 4)); CK(hipMemset(A, 0, (size_t)SLABS * N * 16 * 4 + 4096));
+    Ctl c{words, words + 1, words + 32, words + 2, words + 3, words + 4, stamps, 1};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto reset_stamps = [&]() { long long h[4] = {0x7fffffffffffffffll, 0, 0x7fffffffffffffffll, 0}; CK(hipMemcpy(stamps, h, 32, hipMemcpyHostToDevice)); };
     auto report = [&](const char* name, float ms) {
         unsigned h[8]; long long hs[4];
         CK(hipMemcpy(h, words, 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, stamps, 32, hipMemcpyDeviceToHost));
-        printf("%-10s %8.2f us per step | wrong words %u, spin give-ups %u | last launch: producers %.1f us, consumers start %+.1f us after the first producer, end %+.1f us after the last producer\n",
+        printf("%-16s %8.2f us per step | wrong words %u, spin give-ups %u | last launch: producers %.1f us, consumers start %+.1f us after the first producer, end %+.1f us after the last producer\n",
                name, 1e3 * ms / reps, h[4], h[2], (hs[1] - hs[0]) / 100.0, (hs[2] - hs[0]) / 100.0, (hs[3] - hs[1]) / 100.0);
         unsigned z = 0; CK(hipMemcpy(words + 4, &z, 4, hipMemcpyHostToDevice));
     };
@@ -189,21 +190,29 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         report("two", ms);
-        // ---- chained -------------------------------------------------------------------------------------------------------------
-        for (int mode = 1; mode <= 2; ++mode) {
+        // ---- chained: sc1 loads; counter stride 1 / 32 words; s_sleep 8 / 32 / 127 / 10 x 127 between polls; acquire-fence variant ------
+        for (int var = 0; var < 7; ++var) {
+            const int stride = (var == 0 || var == 6) ? 1 : 32, slp = var <= 1 ? 8 : var == 2 ? 32 : var == 3 ? 127 : var == 4 ? 1270 : var == 5 ? -8 : 127;
+            c.cstride = stride;
             for (int w = 0; w < 2; ++w) {
                 if (w == 1) CK(hipEventRecord(e0, st));
                 for (int i = 0; i < (w ? reps : 10); ++i) {
                     if (i == reps - 1) { CK(hipStreamSynchronize(st)); reset_stamps(); }
-                    if (mode == 1) hipLaunchKernelGGL(chain_kernel<1>, dim3(NPROD + NCONS), dim3(512), lds, st, A, out, c, prod_us, cons_us);
-                    else hipLaunchKernelGGL(chain_kernel<2>, dim3(NPROD + NCONS), dim3(512), lds, st, A, out, c, prod_us, cons_us);
+                    const dim3 g(NPROD + NCONS), b(512);
+                    if (slp == 8) hipLaunchKernelGGL((chain_kernel<1, 8, 1>), g, b, lds, st, A, out, c, prod_us, cons_us);
+                    else if (slp == 32) hipLaunchKernelGGL((chain_kernel<1, 32, 1>), g, b, lds, st, A, out, c, prod_us, cons_us);
+                    else if (slp == 127) hipLaunchKernelGGL((chain_kernel<1, 127, 1>), g, b, lds, st, A, out, c, prod_us, cons_us);
+                    else if (slp == 1270) hipLaunchKernelGGL((chain_kernel<1, 127, 10>), g, b, lds, st, A, out, c, prod_us, cons_us);
+                    else hipLaunchKernelGGL((chain_kernel<2, 8, 1>), g, b, lds, st, A, out, c, prod_us, cons_us);
                 }
                 if (w == 1) CK(hipEventRecord(e1, st));
             }
             CK(hipStreamSynchronize(st));
             CK(hipGetLastError());
             CK(hipEventElapsedTime(&ms, e0, e1));
-            report(mode == 1 ? "chain" : "chain_acq", ms);
+            char nm[64];
+            snprintf(nm, sizeof nm, "chain s%d %s%d", stride, slp < 0 ? "acq" : "z", slp < 0 ? 8 : slp);
+            report(nm, ms);
         }
     }
     // ---- hipExtAnyOrderLaunch on this device: does the second kernel start before the first has ended? -----------------------------------
