@@ -122,7 +122,7 @@ def stblock_bytes_by_label(B, N, Ks, e):
     nt = (N + 15) // 16
     for blk, (c_in, T, need_dx) in enumerate(((1, N_HIS, False), (64, N_HIS - 2 * (KT - 1), True))):
         T1 = T - KT + 1
-        part = {"tc2_bwd": B * nt * (KT * 16 * 128 + 128) + 2 * B * N * 64, "gconv_bwd": B * T1 * (Ks + 1) * 256,
+        part = {"tc2_bwd": min(B * nt, 512) * (KT * 16 * 128 + 128) + 2 * B * N * 64, "gconv_bwd": B * T1 * (Ks + 1) * 256,
                 "tc1_bwd": 256 * (KT * c_in * 128 + 128 + 64 * 16 + 16), "align_gate_bwd": 512 * (64 * 16 + 16 + 16 * 128 + 128)}
         for k, v in block_bytes(B, c_in, T, N, Ks, need_dx, e, part).items():
             tot[f"{k}@{blk}"] = v

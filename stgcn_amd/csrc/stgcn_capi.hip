@@ -1267,6 +1267,11 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
             if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0, ET>), grid, blk, lds, f);   \
             else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1, ET>), grid, blk, lds, f);      \
         } while (0)
+        // fp32, 64 input channels, two workgroups per CU asked for: the instance compiled for 4 waves per SIMD (the plain one needs 133 VGPRs,
+        // which silently made "two per CU" two ROUNDS of one per CU: r3-31 measured 27.9 -> 31.3 us for exactly that reason)
+        if (d->c_in == 64 && !g_bf16 && fwd_per_cu >= 2 && d->act == STGCN_ACT_GLU)
+            STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel_2cu<64, 64, 3, 0, float>), grid, blk, lds, f);
+        else
         if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
 #undef STGCN_TC1_FWD
     } else

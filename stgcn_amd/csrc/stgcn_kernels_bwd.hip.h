@@ -115,7 +115,7 @@ struct BwdGeom {
     int thin;                // first layer handled by thin_tc1_bwd_kernel (Kt*c_in <= 16, c0 == 64)
     int k1;                  // tmp_conv2 / LayerNorm backward fused into tc2_bwd_kernel (no dZ2, no w2 partials; ln_sg = B)
     int node_tiles;          // ceil(N / 16)
-    int k1_wgs, k1_stride;   // workgroups (B * node_tiles) and floats per workgroup (Kt*16*NC2 + NC2) of its dW_eff2 | db_eff2 partials
+    int k1_wgs, k1_stride;   // workgroups (min(B * node_tiles, 2 per CU)) and floats per workgroup (Kt*16*NC2 + NC2) of its dW_eff2 | db_eff2 partials
     long off_k1;
     int k3;                  // tmp_conv1 / Align backward fused into tc1_bwd_kernel (needs need_dx): no dZ1, no w1 / align partials
     int k3_wb, k3_wgs, k3_stride;   // windows per workgroup, workgroups (node_tiles * ceil(B / wb)), floats per workgroup
@@ -157,7 +157,11 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.ln_sg = (int)((slabs2 + g.ln_spg - 1) / g.ln_spg);
     g.k1 = tc2_bwd_fused_ok(c1, c2, Kt, T1, T2) ? 1 : 0;
     g.node_tiles = (N + 15) / 16;
-    g.k1_wgs = B * g.node_tiles;
+    {   // tc2_bwd_kernel: whole (window, node tile) items per workgroup, at most two workgroups per CU (its residency: 8 waves of ~100 VGPRs,
+        // 57 KB of LDS) -- beyond that a workgroup walks several items and keeps ONE partial block (C2: 416 items -> unchanged)
+        const long items = (long)B * g.node_tiles, cap = 2L * device_cus();
+        g.k1_wgs = (int)(items < cap ? items : cap);
+    }
     g.k1_stride = Kt * 16 * 2 * c2 + 2 * c2;
     if (g.k1) {   // one LayerNorm-parameter partial per window
         g.ln_spg = T2;

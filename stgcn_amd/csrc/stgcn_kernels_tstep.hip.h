@@ -89,17 +89,29 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     float* const USt = cs + 4 * a.T2;                  // [2][16][LDZ]  recomputed gate inputs [U | S] of tiles t, t + 1 (written by the M waves)
     const bool roleE = threadIdx.x < 256;              // wave-uniform
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const int b = (int)blockIdx.x / a.node_tiles, nt = (int)blockIdx.x - b * a.node_tiles, n0 = nt * 16;
     const int N = a.N, T1 = a.T1, T2 = a.T2;
     const int r = tid >> 4, cq = tid & 15;             // row r, float4 column cq (+ 16 it) of the 16-row tile
-    const bool rv = n0 + r < N;
-    const int rc = rv ? n0 + r : N - 1;                // clamped row: rows beyond N read a valid address and are masked to zero
+    // Round 4: a workgroup walks a contiguous run of whole (window, node tile) items -- gridDim.x = min(items, two per CU) -- and keeps its
+    // dW_eff2 / db_eff2 accumulators across them: on grids of several rounds (C3: 1344 items, the 8192-node graph: 8192) the stationary
+    // weights are loaded once per workgroup instead of once per item and the partial-sum table shrinks from one block per item to one per
+    // workgroup (8192-node graph: 201 MB -> 12.6 MB per block, read once more by the reduction).  At C2 (416 items) nothing changes.
+    const long items = (long)a.B * a.node_tiles;
+    const long it_lo = items * (long)blockIdx.x / (long)gridDim.x, it_hi = items * ((long)blockIdx.x + 1) / (long)gridDim.x;
     float* const part = a.part + (size_t)blockIdx.x * (KT * 16 * NC + NC);
     STGCN_PHASE(8, 0);
 
     if (roleE) {
         // =========================================== E waves ===========================================================
         struct Tile { Raw4<ET> dy[IT], u[IT], s[IT]; };   // (raw: converted and masked where E consumes them, see tc1_bwd_kernel)
+        f32x4 dbu[IT], dbq[IT];                            // bias partials: over all items of this workgroup
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { dbu[it] = zero4(); dbq[it] = zero4(); }
+        const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+        const uint64_t n4 = ((uint64_t)N * C2) >> 2;
+        for (long item = it_lo; item < it_hi; ++item) {
+        const int b = (int)(item / a.node_tiles), nt = (int)(item - (long)b * a.node_tiles), n0 = nt * 16;
+        const bool rv = n0 + r < N;
+        const int rc = rv ? n0 + r : N - 1;                // clamped row: rows beyond N read a valid address and are masked to zero
         auto fetch = [&](int t2, Tile& t) {
             const size_t e0 = (((size_t)b * T2 + (t2 < T2 ? t2 : T2 - 1)) * N + rc) * C2 + 4 * cq;
 #pragma unroll
@@ -114,11 +126,11 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         Tile pA, pB;   // tiles 0, 2, .. / 1, 3, ..: requested two steps ahead of the E that consumes them
         fetch(0, pA);
         fetch(1, pB);
-        f32x4 gam[IT], dgam[IT], dbet[IT], dbu[IT], dbq[IT];
+        f32x4 gam[IT], dgam[IT], dbet[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             gam[it] = ld4(a.gamma + (size_t)rc * C2 + 4 * (cq + 16 * it));
-            dgam[it] = zero4(); dbet[it] = zero4(); dbu[it] = zero4(); dbq[it] = zero4();
+            dgam[it] = zero4(); dbet[it] = zero4();
         }
         // slab constants of this window's T2 slabs: 32 lanes per slab, 8 slabs at a time, 8 independent loads per lane in flight
         {
@@ -162,8 +174,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 }
             }
         }
-        const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-        const uint64_t n4 = ((uint64_t)N * C2) >> 2, q0 = (((uint64_t)rc * C2) >> 2) + cq;
+        const uint64_t q0 = (((uint64_t)rc * C2) >> 2) + cq;
         // E(t): branch free (rows beyond N carry s = 0, dy = 0: every product vanishes)
         auto E = [&](int t, const Tile& tl) {
             float* const Zs = Zt + (t % RING) * 16 * LDZ;
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 st4_wt(a.dbet_part + o, dbet[it]);
             }
         }
+        }   // (next item: its prologue rewrites `cs`, whose last readers -- this role's E(t) -- are behind barrier (C))
         __syncthreads();       // (D) `red` free: it becomes the bias-reduction buffer
         // db_eff2[o] = sum over the 16 rows (threads with equal cq: lanes 16 apart, then the 4 waves through LDS)
         float* bred = red;     // [4 waves][NC] (NC <= 256: fits the 2 x 1280 floats of `red`)
@@ -300,18 +312,21 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 st4(Us + C2 + 16 * (w + 4 * j) + 4 * g, sg);
             }
         };
-        // all G tiles of this (window, node tile), transposed
+        f32x4 accw[KT][NTW];                               // dW_eff2 of all items of this workgroup
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
+        for (long item = it_lo; item < it_hi; ++item) {
+        const int b = (int)(item / a.node_tiles), nt = (int)(item - (long)b * a.node_tiles), n0 = nt * 16;
+        const bool rv = n0 + r < N;
+        // all G tiles of this (window, node tile), transposed (the previous item's last readers of GT / red are this role's own F(T1 - 1))
         for (int idx = tid; idx < T1 * 64; idx += 256) {
             const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
             const f32x4 v = n0 + rr < N ? ldx4(G_ + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
 #pragma unroll
             for (int i = 0; i < 4; ++i) GT[(t * 16 + 4 * q + i) * LDG + rr] = v[i];
         }
-        f32x4 accw[KT][NTW];
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) accw[k][j] = zero4();
         __syncthreads();   // (A)
         if constexpr (RECOMP) {
             R(0);
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
             float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
             if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
             if (rv) stx1(dYg_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
+        }
         }
         STGCN_PHASE(8, 5);
 #pragma unroll
@@ -956,6 +972,12 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
 }
 template <int C0, int CIN, int KT, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
+    tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
+}
+// the same body under a register budget that lets TWO workgroups share a CU (4 waves per SIMD: at most 128 VGPRs; the fp32 CIN = 64 instance
+// takes 133 on its own, i.e. 3 waves per SIMD = one 8-wave workgroup per CU whatever the grid asks for)
+template <int C0, int CIN, int KT, int ACT, typename ET>
+__global__ __launch_bounds__(512, 4) void tc1_fwd_kernel_2cu(Tc1FwdArgs a) {
     tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
 }
 
