@@ -714,6 +714,15 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
         else STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET, 2>), grid2, blk, 2 * lds, a);
         return STGCN_OK;
     }
+    {   // bf16 activations: the operator products from the operator's bf16 fragment plane on 32-deep MFMAs (gconv_fwd_body B16P; STGCN_GC_B16P=0: the 16-deep form)
+        const char* e = getenv("STGCN_GC_B16P");
+        if (g_bf16 && a.Ks > 1 && g.maxq <= 2 && !(e && e[0] == '0')) {
+            const size_t ldsp = gconv_fwd_b16p_lds_bytes(a.NP, a.N);
+            if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_b16p_kernel<1, 16>), grid, blk, ldsp, a);
+            else STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_b16p_kernel<2, 8>), grid, blk, ldsp, a);
+            return STGCN_OK;
+        }
+    }
     if (g.maxq <= 1) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<1, 16, ET, 1>), grid, blk, lds, a);
     else if (g.maxq <= 2) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET, 1>), grid, blk, lds, a);
     else if (g.maxq <= 3) STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<3, 8, ET, 1>), grid, blk, lds, a);
@@ -771,13 +780,16 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
         // One node tile per tile wave (<= 8 tile waves per workgroup), and the whole grid resident in ONE round: every part re-stages the
         // slab's dY and re-forms all G_k, so a grid of SEVERAL parts that needs more rounds than the slab kernel costs more than it returns
         // (measured at the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
-        const size_t lds2 = ((size_t)(a.Ks - 1) * 16 * (a.NP + 4) + (size_t)a.NP * 20 + (size_t)(a.Ks + 1) * 16 * 20) * sizeof(float);   // (+ the job waves' transposition tiles)
+        const char* eb = getenv("STGCN_GC_B16P");
+        const bool b16p = g_bf16 && a.Ks > 1 && !(eb && eb[0] == '0');   // bf16 activations: G_k as bf16 planes, products from the operator's bf16 plane (32-deep MFMAs)
+        const size_t lds2 = gconv_bwd2_lds_bytes(a.NP, a.N, a.Ks, b16p);   // (G_k tiles + dY rows + the job waves' transposition tiles)
         if (!off && lds2 <= 150 * 1024 && HT <= 64) {
             int best = 0;
             for (int parts = (HT + 7) / 8; parts <= HT && !force_parts; ++parts) {
                 const int per = (HT + parts - 1) / parts, njw = gcbwd2_job_waves(a.Ks, parts, per > 8 ? 8 : per);
                 if (per < 4 && parts > (HT + 7) / 8) break;     // keep >= 4 tile waves per workgroup
-                const int cap = STGCN_ETB_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, ((per > 8 ? 8 : per) + njw) * 64, lds2));
+                const int cap = b16p ? wg_capacity(gconv_bwd2_kernel<1, bf16, true>, ((per > 8 ? 8 : per) + njw) * 64, lds2)
+                                     : STGCN_ETB_VALUE(wg_capacity(gconv_bwd2_kernel<1, ET>, ((per > 8 ? 8 : per) + njw) * 64, lds2));
                 if (a.slabs * parts <= cap) best = parts;
             }
             if (force_parts > 0 && force_parts <= HT && (HT + force_parts - 1) / force_parts <= 24) best = force_parts;   // (tuning: up to 3 tiles per wave)
@@ -788,6 +800,12 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
                 const int per = (HT + best - 1) / best, nwa = per > 8 ? 8 : per, maxq = (per + nwa - 1) / nwa, njw = gcbwd2_job_waves(a.Ks, best, nwa);
                 a.parts = best;
                 const dim3 grid2((unsigned)(a.slabs * best)), blk2((nwa + njw) * 64);
+                if (b16p) {
+                    if (maxq <= 1) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd2_kernel<1, bf16, true>), grid2, blk2, lds2, a, nwa);
+                    else if (maxq <= 2) STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd2_kernel<2, bf16, true>), grid2, blk2, lds2, a, nwa);
+                    else STGCN_LAUNCH("gconv_bwd", st, (gconv_bwd2_kernel<3, bf16, true>), grid2, blk2, lds2, a, nwa);
+                    return STGCN_OK;
+                }
                 if (maxq <= 1) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<1, ET>), grid2, blk2, lds2, a, nwa);
                 else if (maxq <= 2) STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<2, ET>), grid2, blk2, lds2, a, nwa);
                 else STGCN_LAUNCH_ETB("gconv_bwd", st, (gconv_bwd2_kernel<3, ET>), grid2, blk2, lds2, a, nwa);
@@ -938,6 +956,10 @@ LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
     o.N = h->N; o.C = h->C; o.training = h->training && h->droprate > 0.f;
     o.keep_scale = 1.0f / (1.0f - h->droprate); o.thresh = drop_thresh(h->droprate); o.seed = h->seed; o.offset = h->offset;
     o.offset_dev = h->offset_dev;
+    {   // STGCN_HOOK_MASK=philox regenerates the hooked LayerNorm's dropout mask instead of reading it off the block output (A/B knob)
+        const char* e = getenv("STGCN_HOOK_MASK");
+        o.mask_from_y = (e && e[0] == 'p') ? 0 : 1;
+    }
     return o;
 }
 }  // namespace
@@ -1267,11 +1289,6 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
             if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0, ET>), grid, blk, lds, f);   \
             else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1, ET>), grid, blk, lds, f);      \
         } while (0)
-        // fp32, 64 input channels, two workgroups per CU asked for: the instance compiled for 4 waves per SIMD (the plain one needs 133 VGPRs,
-        // which silently made "two per CU" two ROUNDS of one per CU: r3-31 measured 27.9 -> 31.3 us for exactly that reason)
-        if (d->c_in == 64 && !g_bf16 && fwd_per_cu >= 2 && d->act == STGCN_ACT_GLU)
-            STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_kernel_2cu<64, 64, 3, 0, float>), grid, blk, lds, f);
-        else
         if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
 #undef STGCN_TC1_FWD
     } else

@@ -142,6 +142,7 @@ struct bf16 { unsigned short v; };
 // activations) keeps exact fp32 products.
 struct f32x { float v; };
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_16x16x32_bf16
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bf16_bits_rne(float x) {   // round-to-nearest-even; NaN stays NaN (quiet bit set), +-inf stays +-inf

@@ -613,6 +613,66 @@ __device__ __forceinline__ void gc_bwd_products(const float* T1, const float* T2
         }
     }
 }
+// The same products for bf16 activations from the operator's bf16 fragment PLANE on v_mfma_f32_16x16x32_bf16 (see gconv_fwd_body B16P): G1 / G2 are
+// bf16 [16][LDB] tiles in LDS, T1 / T2 the hi planes of the transposed polynomials, K = KC32 chunks of 32 nodes.
+template <int MAXQ, int NQ, bool TWO, int RG>
+__device__ __forceinline__ void gc_bwd_products_b16p(const float* T1, const float* T2, const unsigned short* G1, const unsigned short* G2, int LDB, int KC32,
+                                                     int wave, int WAVES, int lane, f32x4 (&acc1)[MAXQ], f32x4 (&acc2)[MAXQ]) {
+    const int g = lane >> 4, l15 = lane & 15;
+    f32x4 r1[RG][NQ], r2[RG][NQ];
+    int fo[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        fo[q] = ((wave + WAVES * q) * KC32 * 64 + lane) * 4;
+#pragma unroll
+        for (int d = 0; d < RG; ++d) {
+            const int dc = d < KC32 ? d : KC32 - 1;
+            r1[d][q] = ld4(T1 + fo[q] + 256 * dc);
+            if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * dc);
+        }
+    }
+    auto chunk = [&](int kc, int d, auto load_tag) __attribute__((always_inline)) {
+        const bf16x8 af1 = __builtin_bit_cast(bf16x8, ld4(reinterpret_cast<const float*>(G1 + l15 * LDB + kc * 32 + 8 * g)));
+        const bf16x8 af2 = __builtin_bit_cast(bf16x8, TWO ? ld4(reinterpret_cast<const float*>(G2 + l15 * LDB + kc * 32 + 8 * g)) : zero4());
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            acc1[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, __builtin_bit_cast(bf16x8, r1[d][q]), acc1[q], 0, 0, 0);
+            if (TWO) acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2, __builtin_bit_cast(bf16x8, r2[d][q]), acc2[q], 0, 0, 0);
+            if (decltype(load_tag)::value) {
+                r1[d][q] = ld4(T1 + fo[q] + 256 * (kc + RG));
+                if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * (kc + RG));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int kc0 = 0;
+    for (; kc0 + 2 * RG <= KC32; kc0 += RG) {
+#pragma unroll
+        for (int d = 0; d < RG; ++d) chunk(kc0 + d, d, std::true_type());
+    }
+    for (; kc0 < KC32; kc0 += RG) {
+#pragma unroll
+        for (int d = 0; d < RG; ++d) {
+            if (kc0 + d < KC32) {
+                if (kc0 + d + RG < KC32) chunk(kc0 + d, d, std::true_type());
+                else chunk(kc0 + d, d, std::false_type());
+            }
+        }
+    }
+}
+template <int MAXQ, int RG>
+__device__ __forceinline__ void gc_bwd_products_b16p_nq(int nq, bool two, const float* T1, const float* T2, const unsigned short* G1, const unsigned short* G2,
+                                                        int LDB, int KC32, int wave, int WAVES, int lane, f32x4 (&acc1)[MAXQ], f32x4 (&acc2)[MAXQ]) {
+#define STGCN_GCB(NQV) \
+    if (nq == NQV) { \
+        if (two) gc_bwd_products_b16p<MAXQ, NQV, true, RG>(T1, T2, G1, G2, LDB, KC32, wave, WAVES, lane, acc1, acc2); \
+        else gc_bwd_products_b16p<MAXQ, NQV, false, RG>(T1, T2, G1, G2, LDB, KC32, wave, WAVES, lane, acc1, acc2); \
+    }
+    STGCN_GCB(1)
+    if constexpr (MAXQ >= 2) { STGCN_GCB(2) }
+    if constexpr (MAXQ >= 3) { STGCN_GCB(3) }
+#undef STGCN_GCB
+}
 template <typename MM, int MAXQ, int RG>
 __device__ __forceinline__ void gc_bwd_products_nq(int nq, bool two, const float* T1, const float* T2, const float* G1, const float* G2, int LDX, int KCH,
                                                    int wave, int WAVES, int lane, f32x4 (&acc1)[MAXQ], f32x4 (&acc2)[MAXQ]) {
@@ -751,16 +811,25 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_bwd_kernel(GconvBwdArgs a) {
 // LDS holds dY and Ks - 1 terms only (44 KB at 207 nodes, Ks = 3: three workgroups per CU instead of two).
 // grid = slabs * parts, block = (nwa + njw) * 64 with njw = ceil((Ks + 1) / parts).
 // ================================================================================================
-template <int MAXQ, typename ET>
+// B16P (bf16 activations): G_k tiles as bf16 [c][node] planes in LDS (half the LDS of that part) and the operator products from the
+// transposed polynomials' bf16 fragment planes on 32-deep MFMAs (gc_bwd_products_b16p).
+inline size_t gconv_bwd2_lds_bytes(int NP, int N, int Ks, bool b16p) {
+    const size_t gk = b16p ? (size_t)(Ks - 1) * 16 * (gc_np32(N) + 8) * 2 : (size_t)(Ks - 1) * 16 * (NP + 4) * 4;
+    return gk + ((size_t)NP * 20 + (size_t)(Ks + 1) * 16 * 20) * sizeof(float);   // + dY rows + the job waves' transposition tiles
+}
+template <int MAXQ, typename ET, bool B16P = false>
 __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa) {
+    static_assert(!B16P || sizeof(ET) == 2, "the bf16-plane products are the bf16-activation form");
     typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int THREADS = blockDim.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int P = a.parts, prt = (int)(blockIdx.x % (unsigned)P);
     const long slab = blockIdx.x / (unsigned)P;
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, LDY = 20, Ks = a.Ks;
+    const int NP32 = gc_np32(N), KC32 = NP32 >> 5, LDB = NP32 + 8;                 // (B16P)
     float* const GTk = stgcn_smem;                         // GT(k) = GTk + (k - 1)*16*LDX for k >= 1, transposed [c][node]
-    float* const dYs = stgcn_smem + (Ks - 1) * 16 * LDX;   // [NP][LDY] row major
+    unsigned short* const GHk = reinterpret_cast<unsigned short*>(stgcn_smem);   // (B16P) the same tiles as bf16 [c][LDB]
+    float* const dYs = stgcn_smem + (B16P ? (Ks - 1) * 16 * LDB / 2 : (Ks - 1) * 16 * LDX);   // [NP][LDY] row major
     const ET* const dYsl = et_ptr<ET>(a.dY) + (size_t)slab * N * 16;
 
     // ---- every wave: stage dY (row major) ------------------------------------------------------------------------------------
@@ -833,7 +902,12 @@ __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa
         const typename MM::frag wf = MM::cvt(ld4(a.W + (a.kipf ? 0 : (size_t)k * 256) + l15 * 16 + 4 * g));   // B[kk = j][col = i] = W_k[i = l15][j = 4g + s]
         for (int ht = w; ht < HT; ht += nwa) {
             const f32x4 af = ld4(dYs + (ht * 16 + l15) * LDY + 4 * g);   // A[h = l15][j = 4g + s]
-            st4(GTk + ((k - 1) * 16 + l15) * LDX + ht * 16 + 4 * g, MM::mma(MM::cvt(af), wf, zero4()));   // D[h = 4g + r][i = l15]
+            const f32x4 gk = MM::mma(MM::cvt(af), wf, zero4());           // D[h = 4g + r][i = l15]
+            if constexpr (B16P) *reinterpret_cast<u32x2_t*>(GHk + ((k - 1) * 16 + l15) * LDB + ht * 16 + 4 * g) = pack_bf16x4(gk);
+            else st4(GTk + ((k - 1) * 16 + l15) * LDX + ht * 16 + 4 * g, gk);
+        }
+        if constexpr (B16P) {   // the plane's padding columns NP .. LDB - 1 meet zero operator columns, but must not hold NaN bit patterns
+            for (int idx = tid; idx < 16 * (LDB - NP); idx += nwa * 64) GHk[((k - 1) * 16 + idx / (LDB - NP)) * LDB + NP + idx % (LDB - NP)] = 0;
         }
     }
     // G_0^T of the owned tiles in the D layout of the operator products: A[m = i = l15][k = j] = W_0[i][j], B[k = j][n = h = l15] = dY[h][j]
@@ -859,9 +933,17 @@ __global__ __launch_bounds__(768) void gconv_bwd2_kernel(GconvBwdArgs a, int nwa
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) nq += wave + WAVES * q < HT ? 1 : 0;
     for (int k0 = 1; k0 < Ks; k0 += 2) {
+        if constexpr (B16P) {
+            const size_t PSZ = gc_plane_floats(NP, N);
+            const float* T1 = a.LTp + (size_t)(Ks - 1) * MSZ + (size_t)(k0 - 1) * 2 * PSZ;   // hi plane of T_k0^T (each term: hi, lo)
+            const unsigned short* G1 = GHk + (k0 - 1) * 16 * LDB;
+            gc_bwd_products_b16p_nq<MAXQ, (MAXQ == 1 ? gc_ring(1) : MAXQ == 2 ? 2 : 1)>(nq, k0 + 1 < Ks, T1, T1 + 2 * PSZ, G1, G1 + 16 * LDB, LDB, KC32, wave, WAVES,
+                                                                                          lane, acc1, acc2);
+        } else {
         const float* T1 = a.LTp + (size_t)(k0 - 1) * MSZ;
         const float* G1 = GTk + (k0 - 1) * 16 * LDX;
         gc_bwd_products_nq<MM, MAXQ, (MAXQ == 1 ? gc_ring(1) : MAXQ == 2 ? 2 : 1)>(nq, k0 + 1 < Ks, T1, T1 + MSZ, G1, G1 + 16 * LDX, LDX, KCH, wave, WAVES, lane, acc1, acc2);
+        }
     }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {

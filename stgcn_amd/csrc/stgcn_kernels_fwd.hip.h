@@ -841,6 +841,9 @@ struct LnRowstatOut {
     const float* mean;    // [slabs]
     const float* rstd;
     int N, C, act, training;
+    int mask_from_y;      // training, y given: an element was kept iff y != 0 (y = mask * (...): a dropped element is an exact zero, a kept one is zero
+                          // only if xhat * gamma + beta is -- never, for data) instead of regenerating the Philox mask: ~100 VALU instructions per
+                          // 4 elements less in the consumer's epilogue, which in the bf16 configurations is what its time steps wait for
     float keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
@@ -857,13 +860,17 @@ __device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, uint64_t of
     const size_t e = ((size_t)slab * o.N + node) * o.C + c;
     const f32x4 ga = ld4(o.gamma + (size_t)node * o.C + c);
     f32x4 k = {1.f, 1.f, 1.f, 1.f};
-    if (o.training) {
+    if (o.training && !(o.y && o.mask_from_y)) {
         k = dropout_scale4((uint64_t)slab * (((uint64_t)o.N * o.C) >> 2) + (((uint64_t)node * o.C + c) >> 2), o.seed, off, o.thresh, o.keep_scale);
     }
     float s1 = 0.f, s2 = 0.f;
     if (o.y) {   // (uniform) sum g = sum mask dy gamma ; sum g xhat = sum_kept dy (y - keep_scale * beta)
         const f32x4 y = ldx4(et_ptr<ET>(o.y) + e), be = ld4(o.beta + (size_t)node * o.C + c);
         const float ks = o.training ? o.keep_scale : 1.f;
+        if (o.training && o.mask_from_y) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) k[i] = y[i] != 0.f ? o.keep_scale : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             s1 += dy[i] * k[i] * ga[i];
@@ -1148,9 +1155,18 @@ struct GconvFwdArgs {
 inline size_t gconv_fwd_lds_bytes(int NP, int sp, int waves, bool chain_out) {   // X0 transposed (+ one 16 x 20 transposition tile per wave for written-through G rows)
     return ((size_t)sp * 16 * (NP + 4) + (chain_out ? (size_t)waves * 16 * 20 : 0)) * sizeof(float);
 }
+// B16P (bf16 activations only): the operator products on v_mfma_f32_16x16x32_bf16 from the operator's bf16 fragment PLANE (stgcn_gso_prepare
+// writes it behind the fp32 fragments for stgcn_kernels_gcslab16.hip.h: F[((ht * KC32 + kc) * 64 + lane) * 8 + j] =
+// bf16(T_k[ht*16 + (lane & 15)][kc*32 + 8*(lane >> 4) + j])) and a bf16 copy of X0^T in LDS: half the operator bytes per product, half the
+// matrix instructions, no conversion of the fragments in the loop.  The values are those of the 16-deep bf16 form (bf16(T_k) is what
+// Mma<bf16>::cvt makes of the fp32 fragment); only the accumulation order inside a 32-deep instruction differs.
+__host__ __device__ inline int gc_np32(int N) { return (N + 31) / 32 * 32; }
+inline size_t gconv_fwd_b16p_lds_bytes(int NP, int N) { return (size_t)16 * (NP + 4) * 4 + (size_t)16 * (gc_np32(N) + 8) * 2; }
+__host__ __device__ inline size_t gc_plane_floats(int NP, int N) { return (size_t)(NP / 16) * (gc_np32(N) / 32) * 64 * 4; }   // one plane of one term (gs16_term_floats = two)
 // bid = (slab group, part) index of this workgroup, THREADS = threads of the role (the calling waves: threadIdx.x < THREADS)
-template <int MAXQ, int MAXW, typename ET, int SP>
+template <int MAXQ, int MAXW, typename ET, int SP, bool B16P = false>
 __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int bid, const int THREADS, const ChainCtl& chain) {
+    static_assert(!B16P || (sizeof(ET) == 2 && SP == 1), "the bf16-plane products are the bf16-activation form, one slab per workgroup");
     typedef Mma<ET> MM;
     extern __shared__ float stgcn_smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -1163,6 +1179,8 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
     const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4;
     const size_t MSZ = (size_t)NP * NP;
     float* const XT0 = stgcn_smem;   // X0 transposed: [SP][16][LDX]
+    const int NP32 = gc_np32(N), KC32 = NP32 >> 5, LDB = NP32 + 8;               // (B16P)
+    unsigned short* const XH = reinterpret_cast<unsigned short*>(XT0 + SP * 16 * LDX);   // (B16P) bf16 X0^T [16][LDB], rows 16-byte aligned
 
     STGCN_PHASE(4, 0);
     ET* const Xk_ = et_ptr<ET>(a.Xk);
@@ -1188,9 +1206,19 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
                     const f32x4 v = n < N ? cvt4(rw[u]) : zero4();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) XT0[(j * 16 + c4 * 4 + i) * LDX + n] = v[i];
+                    if constexpr (B16P) {   // (the values ARE bf16 numbers: the upper halves of their fp32 form)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float vi = v[i];   // (a copy: __builtin_bit_cast of the vector ELEMENT expression reads element 0 on the host compiler)
+                            XH[(c4 * 4 + i) * LDB + n] = (unsigned short)(__builtin_bit_cast(unsigned, vi) >> 16);
+                        }
+                    }
                 }
             }
         }
+    }
+    if constexpr (B16P) {   // zero the plane's padding columns NP .. NP32 + 7 (they meet zero operator columns, but 0 * NaN is NaN)
+        for (int idx = tid; idx < 16 * (LDB - NP); idx += THREADS) XH[(idx / (LDB - NP)) * LDB + NP + idx % (LDB - NP)] = 0;
     }
     __syncthreads();
     STGCN_PHASE(4, 1);
@@ -1241,8 +1269,11 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
         constexpr bool TWO = decltype(two_tag)::value;
         constexpr int NQ = decltype(nq_tag)::value;
         constexpr int RG = MAXQ == 2 ? 4 : gc_ring(MAXQ);
-        const float* T1 = a.Lp + (size_t)(k0 - 1) * MSZ;
-        const float* T2 = T1 + MSZ;
+        // B16P: the hi plane of term k0 (each term: hi plane, lo plane) behind the fp32 fragments of all terms
+        const size_t PSZ = gc_plane_floats(NP, N);
+        const float* T1 = B16P ? a.Lp + (size_t)(a.Ks - 1) * MSZ + (size_t)(k0 - 1) * 2 * PSZ : a.Lp + (size_t)(k0 - 1) * MSZ;
+        const float* T2 = T1 + (B16P ? 2 * PSZ : MSZ);
+        const int NCH = B16P ? KC32 : KCH;             // chunks of the k loop (32 or 16 nodes each)
         const typename MM::frag wf1 = MM::cvt(wfrag(k0)), wf2 = MM::cvt(TWO ? wfrag(k0 + 1) : zero4());
         STGCN_PHASE(4, 2 * k0);
         f32x4 acc1[NQ][SP], acc2[NQ][SP], r1[RG][NQ], r2[RG][NQ];
@@ -1254,15 +1285,27 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
                 acc1[q][j] = zero4();
                 acc2[q][j] = zero4();
             }
-            fo[q] = ((wave + WAVES * q) * KCH * 64 + lane) * 4;
+            fo[q] = ((wave + WAVES * q) * NCH * 64 + lane) * 4;
 #pragma unroll
             for (int d = 0; d < RG; ++d) {
-                const int dc = d < KCH ? d : KCH - 1;   // (graphs of fewer than RG chunks: a valid address, never used)
+                const int dc = d < NCH ? d : NCH - 1;   // (graphs of fewer than RG chunks: a valid address, never used)
                 r1[d][q] = ld4(T1 + fo[q] + 256 * dc);
                 if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * dc);
             }
         }
         auto chunk = [&](int kc, int d, auto load_tag) __attribute__((always_inline)) {   // d = kc % RG, as a constant after unrolling
+          if constexpr (B16P) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, ld4(reinterpret_cast<const float*>(XH + l15 * LDB + kc * 32 + 8 * g)));   // A[c = l15][node = kc*32 + 8g + j]
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                acc1[q][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, r1[d][q]), acc1[q][0], 0, 0, 0);
+                if (TWO) acc2[q][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, r2[d][q]), acc2[q][0], 0, 0, 0);
+                if (decltype(load_tag)::value) {   // this slot's next occupant
+                    r1[d][q] = ld4(T1 + fo[q] + 256 * (kc + RG));
+                    if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * (kc + RG));
+                }
+            }
+          } else {
             typename MM::frag af[SP];
 #pragma unroll
             for (int j = 0; j < SP; ++j) af[j] = MM::cvt(ld4(XT0 + (j * 16 + l15) * LDX + kc * 16 + 4 * g));   // A[c = l15][node = kc*16 + 4g + s]
@@ -1279,18 +1322,19 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
                     if (TWO) r2[d][q] = ld4(T2 + fo[q] + 256 * (kc + RG));
                 }
             }
+          }
             __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the refills of all RG slots to the end of the unrolled body)
         };
         int kc0 = 0;
-        for (; kc0 + 2 * RG <= KCH; kc0 += RG) {   // steady state: RG chunks, each refills its slot
+        for (; kc0 + 2 * RG <= NCH; kc0 += RG) {   // steady state: RG chunks, each refills its slot
 #pragma unroll
             for (int d = 0; d < RG; ++d) chunk(kc0 + d, d, std::true_type());
         }
-        for (; kc0 < KCH; kc0 += RG) {             // last chunks: refill only while there is something left to fetch
+        for (; kc0 < NCH; kc0 += RG) {             // last chunks: refill only while there is something left to fetch
 #pragma unroll
             for (int d = 0; d < RG; ++d) {
-                if (kc0 + d < KCH) {
-                    if (kc0 + d + RG < KCH) chunk(kc0 + d, d, std::true_type());
+                if (kc0 + d < NCH) {
+                    if (kc0 + d + RG < NCH) chunk(kc0 + d, d, std::true_type());
                     else chunk(kc0 + d, d, std::false_type());
                 }
             }
@@ -1366,6 +1410,10 @@ __device__ __forceinline__ void gconv_fwd_body(const GconvFwdArgs& a, const int 
 template <int MAXQ, int MAXW, typename ET, int SP>
 __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_kernel(GconvFwdArgs a) {
     gconv_fwd_body<MAXQ, MAXW, ET, SP>(a, (int)blockIdx.x, (int)blockDim.x, ChainCtl{nullptr, 0, 0u});
+}
+template <int MAXQ, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void gconv_fwd_b16p_kernel(GconvFwdArgs a) {
+    gconv_fwd_body<MAXQ, MAXW, bf16, 1, true>(a, (int)blockIdx.x, (int)blockDim.x, ChainCtl{nullptr, 0, 0u});
 }
 
 #ifdef STGCN_EXPERIMENTS   // operator-stationary graph conv (opt-in, STGCN_GC_REG=<workgroups per CU>)

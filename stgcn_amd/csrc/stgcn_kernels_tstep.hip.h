@@ -28,6 +28,7 @@ namespace stgcn {
 // kernel that produced dy) -- they need all N nodes of a slab, which no node tile sees.
 // ================================================================================================
 struct Tc2BwdArgs {
+    const float* y;           // [B][T2][N][C2]  the block's output (training: an element was kept iff y != 0 -- no Philox in the time step) or null
     const float* dy;          // [B][T2][N][C2]
     const float* U;           // [B][T2][N][C2]  saved gate inputs of tmp_conv2 (RECOMP = false)
     const float* S;
@@ -76,6 +77,8 @@ template <int C2, int KT, bool TRAINING, int ACT, bool RECOMP, typename ET>
 __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
     typedef Mma<ET> MM;
     const ET* const dy_ = et_ptr<ET>(a.dy);
+    const ET* const ym_ = et_ptr<ET>(a.y ? a.y : a.dy);   // (no y: a valid address of the same shape, the value is not used)
+    const bool mask_y = TRAINING && a.y != nullptr;      // uniform
     const ET* const U_ = et_ptr<ET>(a.U);
     const ET* const S_ = et_ptr<ET>(a.S);
     const ET* const G_ = et_ptr<ET>(a.G);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 
     if (roleE) {
         // =========================================== E waves ===========================================================
-        struct Tile { Raw4<ET> dy[IT], u[IT], s[IT]; };   // (raw: converted and masked where E consumes them, see tc1_bwd_kernel)
+        struct Tile { Raw4<ET> dy[IT], u[IT], s[IT], y[IT]; };   // (raw: converted and masked where E consumes them, see tc1_bwd_kernel)
         f32x4 dbu[IT], dbq[IT];                            // bias partials: over all items of this workgroup
 #pragma unroll
         for (int it = 0; it < IT; ++it) { dbu[it] = zero4(); dbq[it] = zero4(); }
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 t.dy[it] = ldraw4(dy_ + e0 + 64 * it);
+                if constexpr (TRAINING) t.y[it] = ldraw4(ym_ + e0 + 64 * it);   // (unconditional: a branch around a load resets the wait counts)
                 if constexpr (!RECOMP) {
                     t.u[it] = ldraw4(U_ + e0 + 64 * it);
                     t.s[it] = ldraw4(S_ + e0 + 64 * it);
@@ -193,9 +197,15 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                     s = rv ? cvt4(tl.s[it]) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 }
                 if constexpr (TRAINING) {
-                    const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
+                    if (mask_y) {   // (uniform) y = mask * (...): a dropped element is an exact zero
+                        const f32x4 yv = cvt4(tl.y[it]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+                        for (int i = 0; i < 4; ++i) dy[i] = yv[i] != 0.f ? dy[i] * a.keep_scale : 0.f;
+                    } else {
+                        const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dy[i] *= k[i];
+                    }
                 }
                 f32x4 du, dq;
 #pragma unroll
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     const size_t e = ((size_t)slab * N + rc) * CIN + 4 * (cq < CIN / 4 ? cq : CIN / 4 - 1);
                     h.y = ldraw4(hyp + e);
                     h.k[0] = 1.f; h.k[1] = 1.f; h.k[2] = 1.f; h.k[3] = 1.f;
-                    if (hk && a.rs.training) {
+                    if (hk && a.rs.training && !a.rs.mask_from_y) {
                         h.k = dropout_scale4((uint64_t)slab * (((uint64_t)N * CIN) >> 2) + (((uint64_t)rc * CIN + 4 * cq) >> 2), a.rs.seed, hoff,
                                              a.rs.thresh, a.rs.keep_scale);
                     }
@@ -598,10 +608,15 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                         float2 p = make_float2(0.f, 0.f);
                         if (rv) {
                             const f32x4 hy = cvt4(h.y);
+                            f32x4 kk = h.k;
+                            if (a.rs.training && a.rs.mask_from_y) {   // (uniform) kept iff the block output is not an exact zero: no Philox in the step
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) kk[i] = hy[i] != 0.f ? a.rs.keep_scale : 0.f;
+                            }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                p.x += v[i] * h.k[i] * hgam[i];
-                                if (h.k[i] > 0.f) p.y += v[i] * (hy[i] - hbks[i]);
+                                p.x += v[i] * kk[i] * hgam[i];
+                                if (kk[i] > 0.f) p.y += v[i] * (hy[i] - hbks[i]);
                             }
                         }
 #pragma unroll
@@ -974,12 +989,10 @@ template <int C0, int CIN, int KT, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
 }
-// the same body under a register budget that lets TWO workgroups share a CU (4 waves per SIMD: at most 128 VGPRs; the fp32 CIN = 64 instance
-// takes 133 on its own, i.e. 3 waves per SIMD = one 8-wave workgroup per CU whatever the grid asks for)
-template <int C0, int CIN, int KT, int ACT, typename ET>
-__global__ __launch_bounds__(512, 4) void tc1_fwd_kernel_2cu(Tc1FwdArgs a) {
-    tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
-}
+// (Round 4, pass r4-06: the same body under __launch_bounds__(512, 4) -- 128 VGPRs, two workgroups REALLY sharing a CU; the plain fp32
+//  CIN = 64 instance takes 133 VGPRs = 3 waves per SIMD, so "two per CU" had been two rounds of one -- measured 28.5 -> 30.5 us: the fp32
+//  matrix pipe of the CU is the limit, a second chain only doubles the prologues.  The instance was removed again;
+//  profiles/r4-06_tc1_fwd_two_per_cu.txt.)
 
 // ================================================================================================
 // F3+F4 fused: tmp_conv2 + GLU/GTU + LayerNorm([N, c2]) + Dropout of ONE (b, t2) slab per workgroup (layers.py:254-256).
