@@ -32,7 +32,7 @@ extern "C" {
  * backward entry points and `stored_US2` to the plan: 1 -> 2 in effect, never recorded; round 4: stgcn_set_gemm_big_nt, the
  * chained-launch control words in `ws`: 3).  stgcn_version() returns the value the LIBRARY was built with; a binding built
  * against another header must refuse to run (stgcn_amd/_lib.py does).                                                  */
-#define STGCN_ABI_VERSION 3
+#define STGCN_ABI_VERSION 4
 
 #define STGCN_OK 0
 #define STGCN_ERR_UNSUPPORTED 1 /* shape outside what the kernels cover (message says which) */
@@ -330,6 +330,10 @@ typedef struct stgcn_outblock_plan {
     int64_t sv_rowstat;               /* [rows][2]                                                              */
     int64_t ws_Wp, ws_Wd, ws_b, ws_W1p, ws_W1d;
     int64_t ws_rowstat_b, ws_dh1, ws_dyln, ws_dZ, ws_part, part_floats;
+    int64_t ws_chain;                 /* control words of the one-launch forward (uint32: 4 header words, then one arrival counter per
+                                         LayerNorm slab), chain_words of them.  Zeroed by the weight pack (stgcn_prepack or the forward's
+                                         own) and re-armed by the launch that used them.                                              */
+    int64_t chain_words;
 } stgcn_outblock_plan;
 
 int stgcn_outblock_plan_query(const stgcn_outblock_desc* desc, stgcn_outblock_plan* plan);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libstgcn_hip.so")
 
 STGCN_OK = 0
-ABI_VERSION = 3      # include/stgcn_hip.h: STGCN_ABI_VERSION (tests/test_capi_symbols.py keeps the two equal)
+ABI_VERSION = 4      # include/stgcn_hip.h: STGCN_ABI_VERSION (tests/test_capi_symbols.py keeps the two equal)
 ACT = {"glu": 0, "gtu": 1}
 GRAPH_CONV = {"cheb_graph_conv": 0, "graph_conv": 1}
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -91,7 +91,7 @@ class HeadLoss(C.Structure):           # stgcn_head_loss
 
 HEAD_PLAN_FIELDS = ["T1", "rows", "rows_in", "out_floats", "saved_floats", "ws_floats", "sv_U", "sv_S", "sv_mean", "sv_rstd", "sv_yln",
                     "sv_hd", "sv_rowstat", "ws_Wp", "ws_Wd", "ws_b", "ws_W1p", "ws_W1d", "ws_rowstat_b", "ws_dh1", "ws_dyln", "ws_dZ", "ws_part",
-                    "part_floats"]
+                    "part_floats", "ws_chain", "chain_words"]
 
 
 class OutblockPlan(C.Structure):

@@ -762,6 +762,16 @@ inline int fwd_chain_mode() {
     return e ? atoi(e) : kChainDefault;
 #endif
 }
+// The head's forward as ONE launch (head_fwd_kernel, stgcn_kernels_fwd.hip.h): default on; STGCN_HEAD_FUSE=0 restores the conv + fc launches
+// (A/B runs), 2 / 4 admit only the 32- / 64-row tile (tests).  The exchange of the row statistics relies on write-through stores.
+inline int head_fuse_mode() {
+#if !STGCN_WT_STORES
+    return 0;
+#else
+    const char* e = getenv("STGCN_HEAD_FUSE");
+    return e ? atoi(e) : 1;
+#endif
+}
 // job waves of gconv_bwd2_kernel: one per parameter-gradient job of the part (Ks weight terms + the bias, spread over the parts), but never
 // more than the kernel's __launch_bounds__(768) leaves beside the tile waves -- the job loop strides by the job-wave count, so fewer waves
 // only walk more jobs each (Ks >= 4 with one part asked for 13+ waves and the launch failed)

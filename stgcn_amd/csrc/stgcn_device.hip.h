@@ -609,6 +609,69 @@ __device__ __forceinline__ void chain_exit(const ChainCtl& c) {
         }
     }
 }
+// ---- symmetric exchange between the workgroups of ONE launch: every workgroup publishes, then waits for its PEERS (the row statistics of
+// a LayerNorm slab that several row tiles share).  The launcher guarantees that the whole grid is resident at once (grid <= occupancy x
+// compute units, nothing else on the stream), so every peer is running or about to; the wait is bounded like chain_wait.  The emulator
+// abandons a workgroup whose peers have not run yet and runs it again after the rest of the grid (tests/emu: peer_defer), without
+// repeating its counter bumps.
+__device__ __forceinline__ void chain_publish_peer(const ChainCtl& c, int idx, unsigned n = 1u) {
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIPCC__)
+    if (emu::peer_publish_done()) return;
+#endif
+    chain_add(c.words + kChainHdr + idx, n);
+}
+// item of this workgroup by start order (as chain_enter; the emulator hands a re-run workgroup the ticket its abandoned run drew)
+__device__ __forceinline__ int chain_enter_peer(const ChainCtl& c, unsigned* slot) {
+    if (threadIdx.x == 0) {
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIPCC__)
+        *slot = emu::peer_ticket(c.words);
+#else
+        *slot = chain_add(c.words, 1u);
+#endif
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane((int)*slot);
+}
+// ONE thread polls (no barrier here: the caller follows its last poll with __syncthreads())
+__device__ __forceinline__ void chain_poll_peer(const ChainCtl& c, int idx, unsigned expected) {
+    const unsigned* p = c.words + kChainHdr + idx;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (chain_ld(p) < expected) {
+        const long long t0 = wall_clock64();
+        while (chain_ld(p) < expected) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > kChainSpinTicks) {
+                chain_st(c.words + 2, 1u + (unsigned)idx);
+                break;
+            }
+        }
+    }
+#elif !defined(__HIPCC__)
+    if (chain_ld(p) < expected) emu::peer_defer();
+#else
+    (void)p; (void)expected;
+#endif
+}
+// one (x, y) pair of a hand-off array, written through / read past this CU's L1 (base wave-uniform, idx = element index)
+__device__ __forceinline__ void st2_wt(float2* p, float2 v) {
+#if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)
+    const u32x2_t r = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ float2 ld2_sc1(const float2* base, long nelem, int idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(nelem * 8), 0x00020000);
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, idx * 8, 0, 16);
+    const unsigned vx = v[0], vy = v[1];   // (scalar copies: __builtin_bit_cast of an ext-vector ELEMENT reads element 0 -- clang, host and device)
+    return make_float2(__builtin_bit_cast(float, vx), __builtin_bit_cast(float, vy));
+#else
+    (void)nelem;
+    return base[idx];
+#endif
+}
 // 4 consecutive elements of a hand-off tensor, never from this CU's L1 (sc1 buffer load; `base` must be wave-uniform: kernel arguments and
 // the virtual block index only).  off = element offset from base.
 template <typename ET> __device__ __forceinline__ Raw4<ET> ldraw4_sc1(const ET* base, long nelem, int off) {

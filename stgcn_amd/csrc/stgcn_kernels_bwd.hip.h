@@ -1587,10 +1587,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     const long n = (long)j.n0 * j.n1 * j.n2;
     f32x4 acc = zero4();
     long doff = 0;
+    // the optimizer state of this group, requested BEFORE the walk over the partials (the thread that combines the slices updates it: its
+    // loads would otherwise be a second dependent memory round trip at the end of every workgroup's life)
+    const int nw = j.vec ? 4 : 1;
+    f32x4 om = zero4(), ov = zero4(), op = zero4();
+    float ts = 0.f, lr = 0.f;
     if (e < n) {
         const int d2 = (int)(e % j.n2), d1 = (int)((e / j.n2) % j.n1), d0 = (int)(e / ((long)j.n1 * j.n2));
         const float* s = j.src + (long)d0 * j.s0 + (long)d1 * j.s1 + (long)d2 * j.s2;
         doff = (long)d0 * j.t0 + (long)d1 * j.t1 + (long)d2 * j.t2;
+        if (sl == 0 && j.p) {
+            ts = (float)(a.step_dev ? *a.step_dev : a.step);
+            lr = a.lr_dev ? *a.lr_dev : a.lr;
+            for (int i = 0; i < nw; ++i) {
+                const long o = doff + (long)i * j.t2;
+                om[i] = j.m[o];
+                ov[i] = j.v[o];
+                op[i] = j.p[o];
+            }
+        }
         int p = sl;
         if (j.vec) {
             f32x4 a0 = zero4(), a1 = zero4(), a2 = zero4(), a3 = zero4();   // 4 x 16 B in flight per thread
@@ -1619,22 +1634,19 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     if (sl == 0 && e < n) {
         f32x4 t = zero4();
         for (int k = 0; k < kReduceSlices; ++k) t += ld4(stgcn_smem + (k * kReduceElems + el) * 4);
-        const int nw = j.vec ? 4 : 1;
         for (int i = 0; i < nw; ++i) j.dst[doff + (long)i * j.t2] = t[i];
         if (j.p) {   // AdamW on the freshly reduced gradient (torch.optim.AdamW, see adamw_kernel)
-            const float ts = (float)(a.step_dev ? *a.step_dev : a.step);
-            const float lr = a.lr_dev ? *a.lr_dev : a.lr;
             const float bc1 = -expm1f(ts * a.lb1);
             const float rs2 = rsqrtf(-expm1f(ts * a.lb2));
             const float decay = 1.0f - lr * a.wd, step_size = lr / bc1;
             for (int i = 0; i < nw; ++i) {
                 const long o = doff + (long)i * j.t2;
                 const float g = t[i];
-                const float m = a.b1 * j.m[o] + (1.0f - a.b1) * g;
-                const float v = a.b2 * j.v[o] + (1.0f - a.b2) * g * g;
+                const float m = a.b1 * om[i] + (1.0f - a.b1) * g;
+                const float v = a.b2 * ov[i] + (1.0f - a.b2) * g * g;
                 j.m[o] = m;
                 j.v[o] = v;
-                j.p[o] = j.p[o] * decay - step_size * (m / (sqrtf(v) * rs2 + a.eps));
+                j.p[o] = op[i] * decay - step_size * (m / (sqrtf(v) * rs2 + a.eps));
             }
         }
     }

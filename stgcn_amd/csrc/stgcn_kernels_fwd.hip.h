@@ -928,8 +928,36 @@ struct Tconv4Args {
     LnGateBwdIn lnb;    // PLAIN: see above
 };
 
-template <int TM, int KC, bool PLAIN, typename ET>
-__global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
+// HEADF (gated form only): the rest of the head's forward in the SAME launch -- LayerNorm([N, 128]) + fc1 + ReLU + dropout + fc2
+// (layers.py:278-282) on the tile's gated rows while they are in LDS (the former fc_fwd launch: its re-read of U / S, its weight
+// prologue and one launch ramp).  A LayerNorm slab (T1 = 1: the N rows of one window) spans several row tiles, so the tiles exchange
+// their row statistics: write-through row partials -> arrival counter of the window -> wait for the window's other tiles (chain_*_peer,
+// stgcn_device.hip.h; the launcher checks that the whole grid is resident) -> slab statistics from the N partials (sc1 loads).
+struct HeadFcTail {
+    ChainCtl chain;       // header + one arrival counter per window (T1 = 1: slab = window)
+    const float* gamma;   // [N][128] LayerNorm weight / bias
+    const float* beta;
+    float* yln;           // [rows][128] LayerNorm output (the fc1 weight gradient reads it)
+    float* mean;          // [windows]
+    float* rstd;
+    float eps;
+    const float* W1p;     // packed PK_LIN_FWD: K = 128, cols = 128
+    const float* b1;      // [128] or null
+    const float* w2;      // [128]
+    const float* b2;      // [1] or null
+    float* hd;            // [rows][128] dropout(relu(fc1)), saved for backward
+    float* out;           // [rows]
+    int training;
+    float keep_scale;
+    uint32_t thresh;
+    uint64_t seed, offset;
+    const uint64_t* offset_dev;
+    int use_ticket;       // tiles by start order (chain_enter) instead of by blockIdx: grids beyond one resident round
+};
+
+template <int TM, int KC, bool PLAIN, typename ET, bool HEADF = false>
+__device__ __forceinline__ void tconv_fwd4_body(const Tconv4Args& aa, const HeadFcTail* ht) {
+    static_assert(!(PLAIN && HEADF), "the fused head tail follows the gated epilogue");
     constexpr int WAVES = 8, NT = 2, THREADS = 512, TR = TM * 16, NC = 256, COUT = 128, LDZ = NC + 4;
     const TconvFwdArgs& a = aa.f;
     ET* const U_ = et_ptr<ET>(a.U);
@@ -939,7 +967,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
     extern __shared__ float stgcn_smem[];
     float* At = stgcn_smem;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
+    long row0 = (long)xcd_item(blockIdx.x, gridDim.x) * TR;
     const int KCH = a.KCH, KP = KCH * 16, lda = KP + 4;
 
     f32x4 wA[KC][NT], wB[KC][NT];
@@ -951,6 +979,11 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                 w[kc][j] = (kc0 + kc < KCH) ? ld4(a.Wp + ((size_t)((wave + WAVES * j) * KCH + kc0 + kc) * 64 + lane) * 4) : zero4();
     };
     load_round(wA, 0);
+    if constexpr (HEADF) {
+        // more tiles than the device holds at once: the tile comes from a TICKET (start order), so that a tile only ever waits for tiles that
+        // run already or start as soon as earlier ones end (their peers lie at most two windows ahead: the launcher checks that span)
+        if (ht->use_ticket) row0 = (long)chain_enter_peer(ht->chain, reinterpret_cast<unsigned*>(stgcn_smem + TR * LDZ + 4 * WAVES)) * TR;
+    }
     bool staged = false;
     if constexpr (PLAIN) {
         if (aa.lnb.dy) {   // uniform
@@ -1086,6 +1119,7 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
         constexpr int C4N = COUT / 4, NIT = TR * C4N / THREADS;
         const int c4 = tid & (C4N - 1);
         const f32x4 bp = ld4(a.bias + 4 * c4), bq = ld4(a.bias + COUT + 4 * c4);
+        f32x4 uk[HEADF ? NIT : 1], sk[HEADF ? NIT : 1];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = (tid + it * THREADS) / C4N;
@@ -1098,11 +1132,24 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                 sg[i] = sigmoid_f(q[i] + bq[i]);
                 h[i] = gate_fwd(u[i], sg[i], a.act);
             }
-            if (R < a.ts.rows) {
+            if constexpr (HEADF) {   // (stored behind the publish of the row partials: the peers wait for those 8 bytes per row only)
+                uk[it] = u;
+                sk[it] = sg;
+            } else if (R < a.ts.rows) {
                 const size_t o = (size_t)R * COUT + 4 * c4;
                 if (a.U) stx4_wt(U_ + o, u);
                 if (a.S) stx4_wt(S_ + o, sg);
                 if (a.H) stx4_wt(H_ + o, h);
+            }
+            if constexpr (HEADF) {   // (in place: this thread alone reads p / q of (row, c4))
+                // the LayerNorm acts on what the saved tensors hold (the backward rebuilds xhat from U / S): with bf16 storage, the gate of the ROUNDED inputs
+                f32x4 hs = h;
+                if constexpr (sizeof(ET) == 2) {
+                    const f32x4 ur = et_round4<ET>(u), sr_ = et_round4<ET>(sg);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hs[i] = gate_fwd(ur[i], sr_[i], a.act);
+                }
+                st4(Zt + row * LDZ + 4 * c4, hs);
             }
             if (a.rowstat) {   // per-row LayerNorm partials: the C4N lanes holding one row are contiguous in the wave
                 float sr = (h[0] + h[1]) + (h[2] + h[3]);
@@ -1114,10 +1161,173 @@ __global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
                 for (int i = 0; i < 4; ++i) d2 += (h[i] - mr) * (h[i] - mr);
 #pragma unroll
                 for (int m = C4N >> 1; m >= 1; m >>= 1) d2 += __shfl_xor(d2, m);
-                if (c4 == 0 && R < a.ts.rows) a.rowstat[R] = make_float2(mr, d2);
+                if (c4 == 0 && R < a.ts.rows) {
+                    if constexpr (HEADF) st2_wt(a.rowstat + R, make_float2(mr, d2));
+                    else a.rowstat[R] = make_float2(mr, d2);
+                }
             }
         }
+        if constexpr (HEADF) {
+            // ---- publish this tile's row partials, request what the tail needs, wait for the windows' other tiles -------------------
+            const HeadFcTail& f = *ht;
+            const long rows = a.ts.rows;
+            const int N = a.ts.N;
+            const long rend = row0 + TR < rows ? row0 + TR : rows;
+            const int s_lo = (int)(row0 / N), s_hi = (int)((rend - 1) / N);   // the launcher admits N >= TR only: one or two windows
+            chain_drain_stores();
+            __syncthreads();
+            if (tid == 0)
+                for (int sw = s_lo; sw <= s_hi; ++sw) chain_publish_peer(f.chain, sw);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const long R = row0 + (tid + it * THREADS) / C4N;
+                if (R < rows) {
+                    const size_t o = (size_t)R * COUT + 4 * c4;
+                    if (a.U) stx4_wt(U_ + o, uk[it]);
+                    if (a.S) stx4_wt(S_ + o, sk[it]);
+                }
+            }
+            PreW<1, 8> w1;   // fc1 weight fragments of the whole K = 128: wave w owns output-channel tile w (the conv's weight rounds are done)
+            pre_load_weights<1, 8>(w1, f.W1p, 8, wave, 8);
+            f32x4 ga[NIT], be[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = (tid + it * THREADS) / C4N;
+                const long R = row0 + row < rows ? row0 + row : rows - 1;
+                const int n = (int)(R % N);
+                ga[it] = ld4(f.gamma + (size_t)n * COUT + 4 * c4);
+                be[it] = ld4(f.beta + (size_t)n * COUT + 4 * c4);
+            }
+            const f32x4 w2 = ld4(f.w2 + 4 * c4);
+            f32x4 b1 = zero4();
+            if (f.b1) b1 = ld4(f.b1 + 4 * c4);
+            const float b2 = f.b2 ? f.b2[0] : 0.f;
+            const uint64_t off = f.offset + (f.offset_dev ? *f.offset_dev : 0);
+            if (tid == 0)
+                for (int sw = s_lo; sw <= s_hi; ++sw) {
+                    const long w0 = (long)sw * N, w1r = w0 + N < rows ? w0 + N : rows;
+                    chain_poll_peer(f.chain, sw, (unsigned)((w1r - 1) / TR - w0 / TR + 1));
+                }
+            __syncthreads();
+            // ---- slab statistics of the one or two windows (as slab_stats_from_rows: sums about the first row's mean) ---------------
+            float* red = Zt + TR * LDZ;   // 4 * WAVES floats behind the tile
+            float mean2[2] = {0.f, 0.f}, rstd2[2] = {1.f, 1.f};
+            {
+                const bool two = s_hi > s_lo;   // (uniform)
+                const float2* rs0 = a.rowstat + (size_t)s_lo * N;
+                const float2* rs1 = a.rowstat + (size_t)s_hi * N;
+                const float xa = ld2_sc1(rs0, N, 0).x, xb = two ? ld2_sc1(rs1, N, 0).x : 0.f;
+                float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+                for (int r = tid; r < N; r += THREADS) {   // both windows' partials requested together
+                    const float2 va = ld2_sc1(rs0, N, r);
+                    float2 vb = make_float2(0.f, 0.f);
+                    if (two) vb = ld2_sc1(rs1, N, r);
+                    const float da = va.x - xa, db = vb.x - xb;
+                    sa1 += da;
+                    sa2 += va.y + (float)COUT * da * da;
+                    sb1 += db;
+                    sb2 += vb.y + (float)COUT * db * db;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    sa1 += __shfl_xor(sa1, m);
+                    sa2 += __shfl_xor(sa2, m);
+                    sb1 += __shfl_xor(sb1, m);
+                    sb2 += __shfl_xor(sb2, m);
+                }
+                if (lane == 0) {
+                    red[wave] = sa1;
+                    red[WAVES + wave] = sa2;
+                    red[2 * WAVES + wave] = sb1;
+                    red[3 * WAVES + wave] = sb2;
+                }
+                __syncthreads();
+                sa1 = sa2 = sb1 = sb2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) {
+                    sa1 += red[wv];
+                    sa2 += red[WAVES + wv];
+                    sb1 += red[2 * WAVES + wv];
+                    sb2 += red[3 * WAVES + wv];
+                }
+                const float nf = (float)N, nc = (float)N * (float)COUT;
+                const float dma = sa1 / nf, dmb = sb1 / nf;
+                mean2[0] = xa + dma;
+                mean2[1] = xb + dmb;
+                rstd2[0] = 1.0f / sqrtf(fmaxf(sa2 - nc * dma * dma, 0.f) / nc + f.eps);
+                rstd2[1] = 1.0f / sqrtf(fmaxf(sb2 - nc * dmb * dmb, 0.f) / nc + f.eps);
+                if (tid == 0) {   // the tile that holds a window's first row keeps its statistics for the backward
+                    if ((long)s_lo * N >= row0) {
+                        f.mean[s_lo] = mean2[0];
+                        f.rstd[s_lo] = rstd2[0];
+                    }
+                    if (two) {    // (a second window always starts inside the tile)
+                        f.mean[s_hi] = mean2[1];
+                        f.rstd[s_hi] = rstd2[1];
+                    }
+                }
+            }
+            // ---- LayerNorm in place (columns 0 .. 127 of the tile), yln to memory ----------------------------------------------------
+            ET* const yln_ = et_ptr<ET>(f.yln);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = (tid + it * THREADS) / C4N;
+                const long R = row0 + row;
+                f32x4 o = zero4();
+                if (R < rows) {
+                    const int wi = (int)(R / N) - s_lo;
+                    const float mean = wi ? mean2[1] : mean2[0], rstd = wi ? rstd2[1] : rstd2[0];
+                    const f32x4 h = ld4(Zt + row * LDZ + 4 * c4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (h[i] - mean) * rstd * ga[it][i] + be[it][i];
+                    stx4_wt(yln_ + (size_t)R * COUT + 4 * c4, o);
+                }
+                st4(Zt + row * LDZ + 4 * c4, o);
+            }
+            __syncthreads();
+            // ---- fc1 on the matrix cores: [TR x 128] @ [128 x 128], result to columns 128 .. 255 of the tile --------------------------
+            f32x4 acc1[TM][1];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc1[i][0] = zero4();
+            pre_mma<TM, 1, 8, ET>(acc1, Zt, LDZ, 0, 8, w1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Zt[(i * 16 + 4 * g + r) * LDZ + COUT + wave * 16 + l15] = acc1[i][0][r];   // (nobody reads these columns any more)
+            __syncthreads();
+            // ---- bias, ReLU, dropout, fc2 (a row's 32 lanes are half a wave) ---------------------------------------------------------------
+            ET* const hd_ = et_ptr<ET>(f.hd);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = (tid + it * THREADS) / C4N;
+                const long R = row0 + row;
+                f32x4 h = ld4(Zt + row * LDZ + COUT + 4 * c4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = fmaxf(h[i] + b1[i], 0.f);
+                if (f.training) {
+                    const f32x4 k = dropout_scale4((uint64_t)R * C4N + c4, f.seed, off, f.thresh, f.keep_scale);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] *= k[i];
+                }
+                float pd = h[0] * w2[0] + h[1] * w2[1] + h[2] * w2[2] + h[3] * w2[3];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) pd += __shfl_xor(pd, m);
+                if (R < rows) {
+                    stx4_wt(hd_ + (size_t)R * COUT + 4 * c4, h);
+                    if (c4 == 0) f.out[R] = pd + b2;
+                }
+            }
+            chain_exit(f.chain);
+        }
     }
+}
+template <int TM, int KC, bool PLAIN, typename ET>
+__global__ __launch_bounds__(512) void tconv_fwd4_kernel(Tconv4Args aa) {
+    tconv_fwd4_body<TM, KC, PLAIN, ET, false>(aa, nullptr);
+}
+template <int TM, int KC, typename ET>
+__global__ __launch_bounds__(512) void head_fwd_kernel(Tconv4Args aa, HeadFcTail ht) {
+    tconv_fwd4_body<TM, KC, false, ET, true>(aa, &ht);
 }
 
 // ================================================================================================

@@ -103,7 +103,12 @@ static void fiber_init(Fiber& f) {
     f.sp = sp;
 }
 
-void run_block() {
+void peer_defer() {
+    g.defer_req = true;
+    for (;;) yield();   // (the scheduler abandons the workgroup: this fiber is never resumed)
+}
+
+bool run_block() {
     const int n = g.nthreads;
     constexpr size_t kStack = 256 * 1024;
     while ((int)g.fibers.size() < n) {
@@ -113,6 +118,8 @@ void run_block() {
     g.waves.assign(n / kWave, WaveState());
     g.bar_arrived = 0;
     g.live = n;
+    g.defer_req = false;
+    g.pub_seen = 0;
     // poison LDS so that reads of never-written shared memory show up as NaN
     const float qnan = std::numeric_limits<float>::quiet_NaN();
     for (size_t i = 0; i < kLdsBytes / sizeof(float); ++i) stgcn::stgcn_smem[i] = qnan;
@@ -139,6 +146,7 @@ void run_block() {
             g.cur = &f;
             g.threadIdx_ = dim3((unsigned)t, 0, 0);
             emu_switch(&g.main_sp, f.sp);
+            if (g.defer_req) return false;   // (the fibers are re-initialised by the next run_block)
             ++resumed;
             if (!f.done) ++alive;
         }
@@ -147,5 +155,6 @@ void run_block() {
             abort();
         }
     }
+    return true;
 }
 }  // namespace emu

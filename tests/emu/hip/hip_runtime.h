@@ -98,12 +98,27 @@ struct State {
     int live = 0;                       // threads of the running workgroup that have not returned yet
     std::vector<WaveState> waves;
     long n_mfma = 0;
+    // workgroups that wait for PEERS of their own launch (symmetric exchanges: a tile needs the row statistics of tiles that have not run
+    // yet): the waiting workgroup is abandoned and run again from its start after the rest of the grid; the counter bumps it already made
+    // are not repeated (pub_skip of them are skipped in the re-run), its stores are idempotent
+    bool defer_req = false;
+    int pub_seen = 0, pub_skip = 0;
+    long ticket_fixed = -1, ticket_taken = -1;   // a re-run workgroup keeps the ticket of its abandoned run
 };
 extern State g;
 void yield();
 void block_barrier();
 void wave_barrier();
-void run_block();
+bool run_block();   // false: the workgroup deferred itself (peer_defer) and has to be run again
+// called by ONE thread of a workgroup whose peers have not all run yet; does not return
+[[noreturn]] void peer_defer();
+// counts the calls of the running workgroup; true = this bump was already made by an abandoned run of the same workgroup
+static inline bool peer_publish_done() { return g.pub_seen++ < g.pub_skip; }
+static inline unsigned peer_ticket(unsigned* word) {
+    if (g.ticket_fixed >= 0) return (unsigned)g.ticket_fixed;
+    g.ticket_taken = (long)(*word)++;
+    return (unsigned)g.ticket_taken;
+}
 }  // namespace emu
 
 // The one dynamic-LDS array every kernel (all live in namespace stgcn) declares as
@@ -249,10 +264,33 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
     emu::g.blockDim_ = block;
     emu::g.nthreads = (int)block.x;
     emu::g.body = [=]() { kernel(static_cast<KArgs>(args)...); };
+    struct Deferred { dim3 b; int pubs; long ticket; };
+    std::vector<Deferred> again;
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 emu::g.blockIdx_ = dim3(bx, by, bz);
-                emu::run_block();
+                emu::g.pub_skip = 0;
+                emu::g.ticket_fixed = emu::g.ticket_taken = -1;
+                if (!emu::run_block()) again.push_back(Deferred{dim3(bx, by, bz), emu::g.pub_seen, emu::g.ticket_taken});
             }
+    while (!again.empty()) {   // workgroups that waited for peers: from their start again, now that the rest of the grid has run
+        std::vector<Deferred> next;
+        bool progress = false;
+        for (const Deferred& d : again) {
+            emu::g.blockIdx_ = d.b;
+            emu::g.pub_skip = d.pubs;
+            emu::g.ticket_fixed = d.ticket;
+            emu::g.ticket_taken = d.ticket;
+            if (emu::run_block()) progress = true;
+            else {
+                if (emu::g.pub_seen > d.pubs) progress = true;
+                next.push_back(Deferred{d.b, emu::g.pub_seen > d.pubs ? emu::g.pub_seen : d.pubs, emu::g.ticket_taken});
+            }
+        }
+        if (!progress) { fprintf(stderr, "emu: deadlock: %zu workgroups wait for peer counters that nobody will complete\n", next.size()); abort(); }
+        again.swap(next);
+    }
+    emu::g.pub_skip = 0;
+    emu::g.ticket_fixed = -1;
 }

@@ -70,7 +70,7 @@ def test_big_operator_gemm_every_tile_width(nt):
     assert_bf16_errors(stored, f32)
 
 
-@pytest.mark.parametrize("N,B,training", [(21, 3, True), (40, 2, False)])
+@pytest.mark.parametrize("N,B,training", [(21, 3, True), (40, 2, False), (45, 3, True)])   # (N >= 32: the one-launch forward)
 def test_head_bf16_matches_bf16_oracle(N, B, training):
     bind_emulator()
     stored, f32 = run_head_case_bf16("cpu", N, B, training=training)

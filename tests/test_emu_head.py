@@ -13,6 +13,10 @@ CASES = [
     (64, (128, 128), 4, 21, 2, 4, "glu", True),
     (64, (128, 128), 3, 9, 1, 5, "gtu", False),      # T1 = 3 > 1
     (16, (64, 128), 2, 33, 2, 2, "glu", True),
+    # T1 = 1, 128 channels, N >= 32: the ONE-launch forward (head_fwd_kernel): 4 row tiles of 32 over 3 windows of 40 nodes (tiles that hold
+    # one window / straddle two, a ragged last tile); the emulator re-runs the tiles that had to wait for their windows' later tiles
+    (64, (128, 128), 4, 40, 3, 4, "glu", True),
+    (64, (128, 128), 4, 70, 2, 4, "gtu", False),
 ]
 
 
@@ -53,3 +57,12 @@ def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training):
             assert prm.grad is None, n
         else:
             assert prm.grad is not None and rel(prm.grad, g) < 2e-4, (n, rel(prm.grad, g))
+
+
+def test_head_forward_fused_tile_heights(monkeypatch):
+    """The one-launch forward with 64-row tiles (a head whose 32-row tiles do not fit one resident round), with 32-row tiles handed out by
+    start-order ticket (heads beyond that: the emulator re-runs a waiting tile under the ticket it drew), and switched off."""
+    for mode in ("4", "3", "0"):
+        monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
+        test_head_fwd_bwd(64, (128, 128), 4, 70, 2, 4, "glu", True)
+        test_head_fwd_bwd(64, (128, 128), 4, 40, 3, 4, "glu", True)
