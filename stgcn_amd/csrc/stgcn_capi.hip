@@ -910,24 +910,26 @@ int launch_reduce_list(const char* label, ReduceList& L, hipStream_t st) {
 void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived& v, const BwdGeom& bg, const float* part,
                        const stgcn_stblock_grads* G) {
     // dW_eff partials wp[P][..][NC] (ps floats apart), db_eff partials bp[P][NC] (pb floats apart)
-    auto add_tconv_at = [&](const float* wp, const float* bp, int Pn, long ps, long pb, int NC, int Cin, int Cout, float* gw, float* gb, float* gaw,
+    // The weight-gradient partials are stored TRANSPOSED, dW_eff^T[o][k*Cin + i] with LD floats per column o: the 4 rows a lane of the producing
+    // MFMA tile holds for its column are then 16 contiguous bytes (one write-through store instead of four scattered dwords)
+    auto add_tconv_at = [&](const float* wp, const float* bp, int Pn, long ps, long pb, int NC, long LD, int Cin, int Cout, float* gw, float* gb, float* gaw,
                             float* gab) {
-        // enumerate (k, i, o): src dW_eff[k*Cin + i][o] -> dst conv_w[o][i][k]
-        L.add(gw, wp, Pn, ps, d->Kt, Cin, NC, (long)Cin * NC, NC, 1, 1, d->Kt, (long)Cin * d->Kt);
+        // enumerate (o, k, i): src dW_eff^T[o][k*Cin + i] -> dst conv_w[o][i][k]
+        L.add(gw, wp, Pn, ps, NC, d->Kt, Cin, LD, Cin, 1, (long)Cin * d->Kt, 1, d->Kt);
         L.add_flat(gb, bp, Pn, pb, NC);
         if (Cin > Cout) {   // the residual branch is a live 1x1 conv: it shares tap Kt-1 of the P half
-            L.add(gaw, wp + (long)(d->Kt - 1) * Cin * NC, Pn, ps, 1, Cin, Cout, 0, NC, 1, 0, 1, Cin);   // aw[o][i] <- row i, col o
+            L.add(gaw, wp + (long)(d->Kt - 1) * Cin, Pn, ps, 1, Cout, Cin, 0, LD, 1, 0, Cin, 1);   // aw[o][i] <- column o, row (Kt-1)*Cin + i
             L.add_flat(gab, bp, Pn, pb, Cout);
         }
     };
     auto add_tconv = [&](const WgradGeom& w, int Cin, int Cout, float* gw, float* gb, float* gaw, float* gab) {
         const float* wp = part + w.off;
-        add_tconv_at(wp, wp + (long)w.chunks * w.Mpad * w.NC, w.chunks, (long)w.Mpad * w.NC, w.NC, w.NC, Cin, Cout, gw, gb, gaw, gab);
+        add_tconv_at(wp, wp + (long)w.chunks * w.Mpad * w.NC, w.chunks, (long)w.Mpad * w.NC, w.NC, w.NC, w.Mpad, Cin, Cout, gw, gb, gaw, gab);
     };
     if (bg.k3) {     // per-workgroup partials of tc1_bwd_kernel: dW_eff1 [Kt*c_in][NC1] | db_eff1 [NC1] | dWa [c0][c1] | dba [c1]
         const float* wp = part + bg.off_k3;
-        add_tconv_at(wp, wp + (long)d->Kt * d->c_in * v.NC1, bg.k3_wgs, bg.k3_stride, bg.k3_stride, v.NC1, d->c_in, d->c0, G->tc1_w, G->tc1_b, G->tc1_aw,
-                     G->tc1_ab);
+        add_tconv_at(wp, wp + (long)d->Kt * d->c_in * v.NC1, bg.k3_wgs, bg.k3_stride, bg.k3_stride, v.NC1, (long)d->Kt * d->c_in, d->c_in, d->c0, G->tc1_w,
+                     G->tc1_b, G->tc1_aw, G->tc1_ab);
     } else if (bg.thin) {   // dW_eff (16 padded rows) and db_eff sit behind dWa | dba in the per-workgroup partials
         const float* wp = part + bg.off_al + (long)d->c0 * 16 + 16;
         L.add(G->tc1_w, wp, bg.al_wgs, bg.al_stride, d->Kt, d->c_in, v.NC1, (long)d->c_in * v.NC1, v.NC1, 1, 1, d->Kt, (long)d->c_in * d->Kt);
@@ -937,8 +939,8 @@ void reduce_jobs_block(ReduceList& L, const stgcn_stblock_desc* d, const Derived
     }
     if (bg.k1) {   // per-(window, node tile) partials of tc2_bwd_kernel: [Kt*16][NC2] then [NC2]
         const float* wp = part + bg.off_k1;
-        add_tconv_at(wp, wp + (long)d->Kt * 16 * v.NC2, bg.k1_wgs, bg.k1_stride, bg.k1_stride, v.NC2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw,
-                     G->tc2_ab);
+        add_tconv_at(wp, wp + (long)d->Kt * 16 * v.NC2, bg.k1_wgs, bg.k1_stride, bg.k1_stride, v.NC2, (long)d->Kt * 16, d->c1, d->c2, G->tc2_w, G->tc2_b,
+                     G->tc2_aw, G->tc2_ab);
     } else {
         add_tconv(bg.w2, d->c1, d->c2, G->tc2_w, G->tc2_b, G->tc2_aw, G->tc2_ab);
     }

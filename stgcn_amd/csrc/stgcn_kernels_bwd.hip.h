@@ -1502,8 +1502,7 @@ __device__ __forceinline__ void tconv_bwd_weight_body(const TconvBwdWeightArgs& 
         for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[(size_t)(m0 + i * 16 + 4 * g + r) * NC + (wave * NTW + j) * 16 + l15] = acc[i][j][r];
+                st4_wt(part + (size_t)((wave * NTW + j) * 16 + l15) * a.Mpad + m0 + i * 16 + 4 * g, acc[i][j]);   // TRANSPOSED partial [NC][Mpad]: a lane's 4 rows are 16 contiguous bytes
     }
     if (mchunk == 0) {   // uniform per workgroup
         float* bp = a.part + (size_t)a.chunks * a.Mpad * NC + (size_t)chunk * NC;

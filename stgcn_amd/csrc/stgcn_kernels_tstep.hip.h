@@ -42,7 +42,7 @@ struct Tc2BwdArgs {
     const float* G;           // [B][T1][N][16]  tmp_conv2 input (relu output, also the relu mask)
     const float* Wd;          // [Kt*16][2*C2]   dense W_eff of tmp_conv2 (PK_TCONV_DENSE)
     float* dYg;               // [B][T1][N][16]
-    float* part;              // [wgs][Kt*16*NC + NC]  dW_eff2 | db_eff2 partials
+    float* part;              // [wgs][Kt*16*NC + NC]  dW_eff2 (transposed: [NC][Kt*16]) | db_eff2 partials
     float* dgam_part;         // [B][N*C2]
     float* dbet_part;
     int B, T1, T2, N, act, training, node_tiles;
@@ -402,8 +402,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         for (int k = 0; k < KT; ++k)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) part[(size_t)(k * 16 + 4 * g + rr) * NC + (w * NTW + j) * 16 + l15] = accw[k][j][rr];
+                st4_wt(part + (size_t)((w * NTW + j) * 16 + l15) * (KT * 16) + k * 16 + 4 * g, accw[k][j]);   // TRANSPOSED partial [NC][KT * 16]: a lane's 4 rows are 16 contiguous bytes
         __syncthreads();       // (D)
         __syncthreads();       // (E)
     }
@@ -436,7 +435,7 @@ struct Tc1BwdArgs {
     const float* WaD;         // [C0][16] dense Align map (PK_ALIGN_DENSE)
     const float* Wd;          // [KT*CIN][NC] dense W_eff1 (PK_TCONV_DENSE)
     float* dx;                // [B][T][N][CIN]
-    float* part;              // [wgs][KT*CIN*NC + NC + C0*16 + 16]  dW_eff1 | db_eff1 | dWa | dba
+    float* part;              // [wgs][KT*CIN*NC + NC + C0*16 + 16]  dW_eff1 (transposed: [NC][KT*CIN]) | db_eff1 | dWa | dba
     LnRowstatOut rs;          // hook: row partials of the LayerNorm in front of x (rs.rowstat == null: none)
     int B, T, T1, N, node_tiles;
 };
@@ -782,8 +781,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         for (int m = 0; m < KT * MI; ++m)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) part[(size_t)(m * 16 + 4 * g + rr) * NC + (2 * w + j) * 16 + l15] = accw[m][j][rr];
+                st4_wt(part + (size_t)((2 * w + j) * 16 + l15) * (KT * CIN) + m * 16 + 4 * g, accw[m][j]);   // TRANSPOSED partial [NC][KT * CIN] (16-byte write-through stores)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) part[(size_t)KT * CIN * NC + NC + (16 * w + 4 * g + rr) * 16 + l15] = acca[rr];
         __syncthreads();           // (D)
