@@ -122,7 +122,7 @@ struct BwdGeom {
     long off_k3;
 };
 
-inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
+inline WgradGeom wgrad_geom(long rows, int K, int NC, long off, int target_wgs = 256) {
     WgradGeom g;
     g.M = K;
     g.Mtiles = (K + 15) / 16;
@@ -130,8 +130,8 @@ inline WgradGeom wgrad_geom(long rows, int K, int NC, long off) {
     g.mchunks = (g.Mtiles + g.MTW - 1) / g.MTW;
     g.Mpad = g.mchunks * g.MTW * 16;
     g.NC = NC;
-    // aim at ~256 workgroups in total (one per CU; fewer partials to write and re-read), >= 64 rows per chunk
-    long target = 256 / g.mchunks;
+    // aim at ~target_wgs workgroups in total (256: one per CU; fewer partials to write and re-read), >= 64 rows per chunk
+    long target = target_wgs / g.mchunks;
     if (target < 1) target = 1;
     long rpc = (rows + target - 1) / target;
     rpc = (rpc + 63) / 64 * 64;   // whole 64-row reduction steps

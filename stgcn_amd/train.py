@@ -71,6 +71,18 @@ def probe_collective_capture(timeout_s: float = 60.0) -> Tuple[bool, str]:
     return ok, why
 
 
+def capture_child_env(env: dict) -> dict:
+    """Environment of the probe's child: the parent's rank variables, the rendezvous port shifted by 17, and WITHOUT the launcher's
+    TORCHELASTIC_* variables -- under ``torch.distributed.run`` TORCHELASTIC_USE_AGENT_STORE makes ``env://`` rendezvous attach to the
+    agent's store as a client; on the shifted port nobody serves one, so every child would wait for its timeout and the probe would
+    always say "hung".  Without them rank 0's child hosts its own store."""
+    env = {k: v for k, v in env.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
 def run_collective_capture_child(env: dict, timeout_s: float = 60.0) -> Tuple[bool, str]:
     """One rank's share of ``probe_collective_capture``: the experiment in a child process (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
     ``env``, port shifted by 17 so that it cannot meet the parent's group), killed after ``timeout_s``."""
@@ -96,10 +108,7 @@ def run_collective_capture_child(env: dict, timeout_s: float = 60.0) -> Tuple[bo
         "assert abs(float(t[0]) - want) < 1e-6 and abs(float(t[-1]) - want) < 1e-6, (float(t[0]), want)\n"
         "dist.destroy_process_group()\n"
         "print('CAPTURE_OK')\n")
-    env = dict(env)
-    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env = capture_child_env(env)
     ok, why = False, ""
     try:
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s)

@@ -176,3 +176,15 @@ def test_collective_capture_probe_declines_host_side_backends(tmp_path):
     mp.spawn(_probe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     ok, why = torch.load(out)
     assert ok is False and "gloo" in why
+
+
+def test_capture_probe_child_environment():
+    """The capture probe's child must host its own rendezvous store: the launcher's TORCHELASTIC_* variables (agent store) are dropped, the
+    port is shifted off the parent group's, the rank variables survive."""
+    from stgcn_amd.train import capture_child_env
+    env = {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29400",
+           "TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    c = capture_child_env(env)
+    assert not any(k.startswith("TORCHELASTIC_") for k in c)
+    assert c["MASTER_PORT"] == "29417" and c["RANK"] == "3" and c["WORLD_SIZE"] == "8" and c["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env["MASTER_PORT"] == "29400" and "TORCHELASTIC_RUN_ID" in env      # (the caller's mapping is untouched)
