@@ -1,4 +1,4 @@
 #!/bin/bash
-# scratch runner of the build -> measure loop: `gpurun -- 'bash tools/gpu_tmp.sh'` (edit freely)
+# scratch runner of the build -> measure loop: `gpurun -- 'bash tools/gpu_tmp.sh'` (edit freely; as committed: the evidence pass of a round)
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_bsweep.sh r4-24 2>&1 | tail -12
+bash tools/gpu_final.sh ${1:-rX} 2>&1 | grep -v "^ \|^{\|^}" | cut -c1-300
