@@ -48,6 +48,19 @@ def test_c3_head_bf16():
     assert_bf16_errors(*run_head_case_bf16("cuda:0", 325, 64))
 
 
+@pytest.mark.parametrize("mode", ["2", "3", "4", "0"])
+def test_head_forward_forms_bf16(mode, monkeypatch):
+    """Every form of the head's forward at the C3 size: one launch with 32-row tiles by blockIdx ("2": 650 tiles do NOT fit one resident round
+    at C3 -- the launcher falls back to two launches there, and takes the form at the small size), 32-row tiles by start-order ticket ("3":
+    650 tiles on ~512 resident slots: tiles wait for peers that start only after earlier tiles end), 64-row tiles ("4": what bench.py's C3
+    runs), two launches ("0") -- all against the bf16 stage oracle."""
+    from tests.bf16_util import assert_bf16_errors, run_head_case_bf16
+    _bind()
+    monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
+    assert_bf16_errors(*run_head_case_bf16("cuda:0", 325, 64))
+    assert_bf16_errors(*run_head_case_bf16("cuda:0", 70, 2, training=False))
+
+
 @pytest.mark.parametrize("blk", [0, 1])
 def test_c5_graph_8192_nodes_bf16(blk):
     """BASELINE.json configs[4] graph size (8192 nodes, dense operator, ChebConv Ks = 5) at batch 1 with bf16 activations: operand-form
