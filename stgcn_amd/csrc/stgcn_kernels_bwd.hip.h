@@ -1549,7 +1549,9 @@ struct ReduceJob {
     long pstride;
     int P;
     int vec;      // 1: n2, pstride, s0, s1 are multiples of 4 and src is 16-byte aligned
-    int slices;   // 8 or 32
+    int dvec;     // 1: vec and the 4 elements of a group are 16 contiguous, aligned bytes in dst / p / m / v too (t2 == 1: the flat jobs -- biases,
+                  //    LayerNorm parameters, which are most of the elements on big graphs): the write and the AdamW state move as 16-byte accesses
+    int slices;   // 4, 8 or 32
     int n0, n1, n2;
     int s0, s1, s2;
     int t0, t1, t2;
@@ -1569,8 +1571,13 @@ struct ReduceArgs {
 inline int reduce_job_setup(ReduceJob& j) {
     j.vec = (j.n2 % 4 == 0 && j.s2 == 1 && j.pstride % 4 == 0 && j.s0 % 4 == 0 && j.s1 % 4 == 0 &&
              (reinterpret_cast<uintptr_t>(j.src) & 15) == 0) ? 1 : 0;
-    j.slices = j.P >= 128 ? 32 : 8;
-    const long n = (long)j.n0 * j.n1 * j.n2, per = (long)(kThreads / j.slices) * (j.vec ? 4 : 1);
+    const long n = (long)j.n0 * j.n1 * j.n2;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    j.dvec = (n >= 65536 && j.vec && j.t2 == 1 && j.t0 % 4 == 0 && j.t1 % 4 == 0 && al16(j.dst) && (!j.p || (al16(j.p) && al16(j.m) && al16(j.v)))) ? 1 : 0;
+    // big tables with few partials (the LayerNorm parameters of an 8192-node graph: 524 288 elements x 16 windows): 4 slices -- twice the
+    // elements per workgroup, 4 loads in flight per thread, a quarter of the threads in the state update instead of an eighth
+    j.slices = j.P >= 128 ? 32 : (n >= 65536 && j.P <= 32) ? 4 : 8;
+    const long per = (long)(kThreads / j.slices) * (j.vec ? 4 : 1);
     return (int)((n + per - 1) / per);
 }
 
@@ -1598,6 +1605,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
         if (sl == 0 && j.p) {
             ts = (float)(a.step_dev ? *a.step_dev : a.step);
             lr = a.lr_dev ? *a.lr_dev : a.lr;
+            if (j.dvec) {
+                om = ld4(j.m + doff);
+                ov = ld4(j.v + doff);
+                op = ld4(j.p + doff);
+            } else
             for (int i = 0; i < nw; ++i) {
                 const long o = doff + (long)i * j.t2;
                 om[i] = j.m[o];
@@ -1633,20 +1645,31 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     if (sl == 0 && e < n) {
         f32x4 t = zero4();
         for (int k = 0; k < kReduceSlices; ++k) t += ld4(stgcn_smem + (k * kReduceElems + el) * 4);
-        for (int i = 0; i < nw; ++i) j.dst[doff + (long)i * j.t2] = t[i];
+        if (j.dvec) st4(j.dst + doff, t);
+        else
+            for (int i = 0; i < nw; ++i) j.dst[doff + (long)i * j.t2] = t[i];
         if (j.p) {   // AdamW on the freshly reduced gradient (torch.optim.AdamW, see adamw_kernel)
             const float bc1 = -expm1f(ts * a.lb1);
             const float rs2 = rsqrtf(-expm1f(ts * a.lb2));
             const float decay = 1.0f - lr * a.wd, step_size = lr / bc1;
+            f32x4 nm, nv, np_;
             for (int i = 0; i < nw; ++i) {
-                const long o = doff + (long)i * j.t2;
                 const float g = t[i];
-                const float m = a.b1 * om[i] + (1.0f - a.b1) * g;
-                const float v = a.b2 * ov[i] + (1.0f - a.b2) * g * g;
-                j.m[o] = m;
-                j.v[o] = v;
-                j.p[o] = op[i] * decay - step_size * (m / (sqrtf(v) * rs2 + a.eps));
+                nm[i] = a.b1 * om[i] + (1.0f - a.b1) * g;
+                nv[i] = a.b2 * ov[i] + (1.0f - a.b2) * g * g;
+                np_[i] = op[i] * decay - step_size * (nm[i] / (sqrtf(nv[i]) * rs2 + a.eps));
             }
+            if (j.dvec) {
+                st4(j.m + doff, nm);
+                st4(j.v + doff, nv);
+                st4(j.p + doff, np_);
+            } else
+                for (int i = 0; i < nw; ++i) {
+                    const long o = doff + (long)i * j.t2;
+                    j.m[o] = nm[i];
+                    j.v[o] = nv[i];
+                    j.p[o] = np_[i];
+                }
         }
     }
 }
