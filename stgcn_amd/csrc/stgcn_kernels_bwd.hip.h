@@ -1568,15 +1568,20 @@ struct ReduceArgs {
     const float* lr_dev;
 };
 // host: classify the job and return its workgroup count
+// element count from which a table takes the big-table forms below (STGCN_REDUCE_BIG: the emulator tests force them on small models)
+inline long reduce_big_threshold() {
+    static const long t = getenv("STGCN_REDUCE_BIG") ? atol(getenv("STGCN_REDUCE_BIG")) : 65536;
+    return t;
+}
 inline int reduce_job_setup(ReduceJob& j) {
     j.vec = (j.n2 % 4 == 0 && j.s2 == 1 && j.pstride % 4 == 0 && j.s0 % 4 == 0 && j.s1 % 4 == 0 &&
              (reinterpret_cast<uintptr_t>(j.src) & 15) == 0) ? 1 : 0;
     const long n = (long)j.n0 * j.n1 * j.n2;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    j.dvec = (n >= 65536 && j.vec && j.t2 == 1 && j.t0 % 4 == 0 && j.t1 % 4 == 0 && al16(j.dst) && (!j.p || (al16(j.p) && al16(j.m) && al16(j.v)))) ? 1 : 0;
+    j.dvec = (n >= reduce_big_threshold() && j.vec && j.t2 == 1 && j.t0 % 4 == 0 && j.t1 % 4 == 0 && al16(j.dst) && (!j.p || (al16(j.p) && al16(j.m) && al16(j.v)))) ? 1 : 0;
     // big tables with few partials (the LayerNorm parameters of an 8192-node graph: 524 288 elements x 16 windows): 4 slices -- twice the
     // elements per workgroup, 4 loads in flight per thread, a quarter of the threads in the state update instead of an eighth
-    j.slices = j.P >= 128 ? 32 : (n >= 65536 && j.P <= 32) ? 4 : 8;
+    j.slices = j.P >= 128 ? 32 : (n >= reduce_big_threshold() && j.P <= 32) ? 4 : 8;
     const long per = (long)(kThreads / j.slices) * (j.vec ? 4 : 1);
     return (int)((n + per - 1) / per);
 }

@@ -105,3 +105,11 @@ def test_chained_forward_launch(mode, monkeypatch):
     tb.test_block_backward(64, (64, 16, 64), 3, 2, "graph_conv", "glu", 20, 3, 6, False)
     bind_emulator()
     assert_bf16_errors(*run_block_case_bf16("cpu", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 37, 2, 8, True))
+
+
+def test_reduction_big_table_forms():
+    """reduce_kernel's forms for tables of >= 65 536 elements (16-byte gradient / AdamW state accesses of flat jobs, 4 slices for <= 32
+    partials -- C5's LayerNorm parameters) forced on the small models of the optimizer / model tests: fused reduce + AdamW against
+    torch.optim.AdamW, gradients against the reference's goldens."""
+    run_subset({"STGCN_REDUCE_BIG": "1"}, ["tests/test_emu_optim.py"], "trajectory or fused_step_tail or fused_into_the_head")
+    run_subset({"STGCN_REDUCE_BIG": "1"}, ["tests/test_emu_model.py"], "golden")
