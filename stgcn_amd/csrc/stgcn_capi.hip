@@ -406,8 +406,8 @@ inline int head_tile_rows() {
     return t == 16 ? 16 : 32;
 }
 inline int head_fc_tile_rows() {
-    static const int t = getenv("STGCN_HEAD_FC_TILE") ? atoi(getenv("STGCN_HEAD_FC_TILE")) : 16;
-    return t == 32 ? 32 : 16;
+    const char* e = getenv("STGCN_HEAD_FC_TILE");   // (read per call: the tests switch it)
+    return (e && atoi(e) == 32) ? 32 : 16;
 }
 template <bool PLAIN>
 int launch_tconv_fwd4(const char* label, const Tconv4Args& aa, hipStream_t st) {

@@ -66,3 +66,14 @@ def test_head_forward_fused_tile_heights(monkeypatch):
         monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
         test_head_fwd_bwd(64, (128, 128), 4, 70, 2, 4, "glu", True)
         test_head_fwd_bwd(64, (128, 128), 4, 40, 3, 4, "glu", True)
+
+
+def test_head_tile_height_variants(monkeypatch):
+    """The two-launch head with the other tile heights its kernels are instantiated for: 32-row tiles of the fc kernels (what heads of more
+    than 32 768 rows take in the forward: fc_fwd_kernel<2>) and 16-row tiles of the conv kernels."""
+    monkeypatch.setenv("STGCN_HEAD_FUSE", "0")
+    monkeypatch.setenv("STGCN_HEAD_FC_TILE", "32")
+    test_head_fwd_bwd(64, (128, 128), 4, 40, 3, 4, "glu", True)
+    test_head_fwd_bwd(64, (128, 128), 4, 21, 2, 4, "glu", True)
+    from tests.bf16_util import assert_bf16_errors, run_head_case_bf16
+    assert_bf16_errors(*run_head_case_bf16("cpu", 45, 3, training=True))
