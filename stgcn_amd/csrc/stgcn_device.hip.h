@@ -632,8 +632,9 @@ __device__ __forceinline__ int chain_enter_peer(const ChainCtl& c, unsigned* slo
     __syncthreads();
     return __builtin_amdgcn_readfirstlane((int)*slot);
 }
-// ONE thread polls (no barrier here: the caller follows its last poll with __syncthreads())
-__device__ __forceinline__ void chain_poll_peer(const ChainCtl& c, int idx, unsigned expected) {
+// ONE thread polls (no barrier here: the caller follows its last poll with __syncthreads()).  Returns false if the wait gave up (sticky error
+// word set): the caller must make that visible in what it computes -- a result built on missing peer data is garbage, and a NaN is louder.
+__device__ __forceinline__ bool chain_poll_peer(const ChainCtl& c, int idx, unsigned expected) {
     const unsigned* p = c.words + kChainHdr + idx;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (chain_ld(p) < expected) {
@@ -642,7 +643,7 @@ __device__ __forceinline__ void chain_poll_peer(const ChainCtl& c, int idx, unsi
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > kChainSpinTicks) {
                 chain_st(c.words + 2, 1u + (unsigned)idx);
-                break;
+                return false;
             }
         }
     }
@@ -651,6 +652,7 @@ __device__ __forceinline__ void chain_poll_peer(const ChainCtl& c, int idx, unsi
 #else
     (void)p; (void)expected;
 #endif
+    return true;
 }
 // one (x, y) pair of a hand-off array, written through / read past this CU's L1 (base wave-uniform, idx = element index)
 __device__ __forceinline__ void st2_wt(float2* p, float2 v) {

@@ -1203,12 +1203,19 @@ __device__ __forceinline__ void tconv_fwd4_body(const Tconv4Args& aa, const Head
             if (f.b1) b1 = ld4(f.b1 + 4 * c4);
             const float b2 = f.b2 ? f.b2[0] : 0.f;
             const uint64_t off = f.offset + (f.offset_dev ? *f.offset_dev : 0);
-            if (tid == 0)
+            float* const gaveup = Zt + TR * LDZ + 4 * WAVES + 1;   // (LDS word behind the reduction scratch and the ticket word)
+            if (tid == 0) {
+                bool ok = true;
                 for (int sw = s_lo; sw <= s_hi; ++sw) {
                     const long w0 = (long)sw * N, w1r = w0 + N < rows ? w0 + N : rows;
-                    chain_poll_peer(f.chain, sw, (unsigned)((w1r - 1) / TR - w0 / TR + 1));
+                    ok &= chain_poll_peer(f.chain, sw, (unsigned)((w1r - 1) / TR - w0 / TR + 1));
                 }
+                // a wait that gave up (a peer tile never arrived: the device was not this launch's alone for seconds): the tile's predictions
+                // become NaN -- the loss of the step says so -- instead of numbers normalised with incomplete statistics
+                *gaveup = ok ? 0.f : __builtin_nanf("");
+            }
             __syncthreads();
+            const float poison = *gaveup;
             // ---- slab statistics of the one or two windows (as slab_stats_from_rows: sums about the first row's mean) ---------------
             float* red = Zt + TR * LDZ;   // 4 * WAVES floats behind the tile
             float mean2[2] = {0.f, 0.f}, rstd2[2] = {1.f, 1.f};
@@ -1314,7 +1321,7 @@ __device__ __forceinline__ void tconv_fwd4_body(const Tconv4Args& aa, const Head
                 for (int m = 16; m >= 1; m >>= 1) pd += __shfl_xor(pd, m);
                 if (R < rows) {
                     stx4_wt(hd_ + (size_t)R * COUT + 4 * c4, h);
-                    if (c4 == 0) f.out[R] = pd + b2;
+                    if (c4 == 0) f.out[R] = pd + b2 + poison;
                 }
             }
             chain_exit(f.chain);
