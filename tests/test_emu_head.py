@@ -21,8 +21,9 @@ CASES = [
 
 
 @pytest.mark.parametrize("c_in,channels,Ko,N,B,T,act,training", CASES)
-def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training):
-    bind_emulator()
+def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training, dev="cpu"):
+    if dev == "cpu":
+        bind_emulator()
     T1 = T - Ko + 1
     n_his = Ko          # makes cfg.Ko == Ko with zero ST blocks
     cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=n_his, act_func=act, droprate=0.5, blocks=[[c_in], list(channels), [1]])
@@ -34,23 +35,23 @@ def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training):
     hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=c_in, channels=tuple(channels), end_channel=1, act_func=act, droprate=0.5)
     names = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight",
              "tmp_conv1.align.align_conv.bias", "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
-    params = [p["output." + n].clone().requires_grad_(True) for n in names]
-    x = torch.from_numpy(x_np).requires_grad_(True)
+    params = [p["output." + n].clone().to(dev).requires_grad_(True) for n in names]
+    x = torch.from_numpy(x_np).to(dev).requires_grad_(True)
     seed, offset = 77, 5
     out = ops.output_block(x, hcfg, params, training, seed, offset, ops.WorkspaceCache())
     assert out.shape == (B, 1, T1, N)
-    out.backward(torch.from_numpy(dout_np))
+    out.backward(torch.from_numpy(dout_np).to(dev))
 
     keep = None
     if training:
-        ks = ops.dropout_mask(B * T1 * N * channels[1], 0.5, seed, offset, "cpu").reshape(B, T1, N, channels[1])
+        ks = ops.dropout_mask(B * T1 * N * channels[1], 0.5, seed, offset, dev).cpu().reshape(B, T1, N, channels[1])
         keep = (ks > 0).double()
     leaves = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
     xr = torch.from_numpy(x_np).double().requires_grad_(True)
     ref = orc.output_block(xr, leaves, "output.", cfg, Ko, c_in, channels, 1, keep)
     gr = torch.autograd.grad(ref, [xr] + [leaves["output." + n] for n in names], torch.from_numpy(dout_np).double(), allow_unused=True)
-    assert (out.detach().double() - ref.detach()).abs().max() < 5e-5
-    rel = lambda a, b: float((a.double() - b).abs().max() / max(1e-30, float(b.abs().max())))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max() < 5e-5
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / max(1e-30, float(b.abs().max())))
     assert rel(x.grad, gr[0]) < 2e-4, "dx"
     for n, prm, g in zip(names, params, gr[1:]):
         if g is None:

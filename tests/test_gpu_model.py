@@ -173,3 +173,16 @@ def test_mae_rmse_match_reference_on_metr_la_windows():
     mae, rmse, wmape = data.evaluate_metric(model, sampler.batches(bs), z)
     mse_ref, mae_ref, rmse_ref, wmape_ref = fx["metrics"]
     assert abs(mse - mse_ref) <= 1e-4 and abs(mae - mae_ref) <= 1e-4 and abs(rmse - rmse_ref) <= 1e-4 and abs(wmape - wmape_ref) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", ["2", "3", "4", "0"])
+def test_head_forward_forms_f32(mode, monkeypatch):
+    """The fp32 output head in every form of its forward (one launch with 32-row tiles by blockIdx / by start-order ticket, 64-row tiles,
+    two launches) at the C2 size (207 nodes, bs 32, dropout on) and at a size whose tiles straddle windows raggedly, forward and every
+    gradient against the float64 autograd oracle (tests/test_emu_head.py's check, on the GPU)."""
+    from tests.gpu_util import bind_hip
+    from tests.test_emu_head import test_head_fwd_bwd
+    bind_hip()
+    monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
+    test_head_fwd_bwd(64, (128, 128), 4, 207, 32, 4, "glu", True, dev="cuda:0")
+    test_head_fwd_bwd(64, (128, 128), 4, 70, 3, 4, "gtu", False, dev="cuda:0")
