@@ -30,9 +30,9 @@ extern "C" {
 
 /* ABI revision: bumped whenever an entry point changes its argument list or a struct its layout (round 3 added `y` to the
  * backward entry points and `stored_US2` to the plan: 1 -> 2 in effect, never recorded; round 4: stgcn_set_gemm_big_nt, the
- * chained-launch control words in `ws`: 3).  stgcn_version() returns the value the LIBRARY was built with; a binding built
+ * chained-launch control words in `ws`: 3, then 4; round 5: stgcn_set_chain_spin_ticks, stgcn_outblock_chain_status: 5).  stgcn_version() returns the value the LIBRARY was built with; a binding built
  * against another header must refuse to run (stgcn_amd/_lib.py does).                                                  */
-#define STGCN_ABI_VERSION 4
+#define STGCN_ABI_VERSION 5
 
 #define STGCN_OK 0
 #define STGCN_ERR_UNSUPPORTED 1 /* shape outside what the kernels cover (message says which) */
@@ -340,6 +340,15 @@ int stgcn_outblock_plan_query(const stgcn_outblock_desc* desc, stgcn_outblock_pl
 /* out: (B, T1, N) (= logical (B, 1, T1, N)); dropout element index = row * c1 / 4 + c / 4                        */
 int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x, float* out,
                            float* saved, float* ws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
+/* The one-launch forward (head_fwd_kernel) lets the row tiles of a window wait for each other inside the launch; a wait is bounded
+ * (stgcn_set_chain_spin_ticks) and a tile whose wait ran out writes NaN predictions and sets a sticky word in `ws` (1 + the index of the
+ * window counter it waited on), which stays until the next weight pack of this module re-arms the control words.  This call SYNCHRONISES
+ * `stream` and returns that word (0: every wait of the last forward completed).  For tests and for callers that want more than the NaN loss. */
+int stgcn_outblock_chain_status(const stgcn_outblock_desc* desc, const float* ws, uint32_t* sticky, void* stream);
+/* Bound of one in-launch wait in ticks of the device's 100 MHz wall clock (default 200 000 000 = 2 s).  ticks < 0 is a TEST setting: the
+ * bound is |ticks| and the first tile of every launch withholds its arrival, so that the waits of its window's other tiles run out for
+ * certain (exercises the NaN / sticky-word path on the device); ticks == 0 only queries.  Returns the previous value.                  */
+int64_t stgcn_set_chain_spin_ticks(int64_t ticks);
 int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                             const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,
                             void* stream);

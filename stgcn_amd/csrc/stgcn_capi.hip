@@ -26,9 +26,24 @@ thread_local bool g_bf16 = false;
 // fits, so a graph-conv workgroup (73 VGPRs, ~5 per CU on its own) cannot start beside a tmp_conv1 workgroup at all and runs one per CU
 // afterwards.  The protocol itself is sound (0 wrong words in 600 launches of tools/ubench/chain_probe.hip, all GPU tests green with it).
 constexpr int kChainDefault = 0;   // (see fwd_chain_mode)
+long long g_chain_spin_ticks = kChainSpinTicks;   // bound of one in-launch wait (stgcn_set_chain_spin_ticks)
 int g_gemm_big_nt = 0;   // stgcn_set_gemm_big_nt: forced column extent of the big bf16 operator GEMM's tiles (0 = heuristic)
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Where the backward takes the dropout mask of a block's LayerNorm from (tc2_bwd_kernel, the stgcn_ln_hook epilogues):
+//   fp32 blocks: REGENERATED (Philox), the reference's semantics exactly -- reading it off the output costs nothing there (fp32 time steps
+//                wait for the matrix pipe, r4-09) and treats a kept element whose LayerNorm output is an exact zero (gamma = beta = 0 for
+//                that element: zero-initialised affine parameters) as dropped, after which its gamma could never leave zero;
+//   bf16 blocks: read off the block output y (kept iff y != 0): their time steps wait for the E waves' VALU work and the ~100 VALU
+//                instructions per 4 elements of Philox were 3 % of the C3 step.  Documented restriction of the bf16 mode.
+// STGCN_HOOK_MASK=philox / y forces one for both (tests run both forms of both types).
+inline bool hook_mask_from_y(bool is_bf16) {
+    const char* e = getenv("STGCN_HOOK_MASK");
+    if (e && e[0] == 'p') return false;
+    if (e && e[0] == 'y') return true;
+    return is_bf16;
+}
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -209,6 +224,18 @@ int check_desc(const stgcn_stblock_desc* d) {
     if (d->x_bstride < 0 || ((d->x_bstride != 0 || d->x_index_dev) && d->need_dx))
         return fail(STGCN_ERR_INVALID, "strided / indexed input windows (x_bstride, x_index_dev) need need_dx = 0 and x_bstride >= 0");
     return STGCN_OK;
+}
+
+// The thin first layer (K = Kt * c_in <= 4) as wave-per-tile kernels (round 5, stgcn_kernels_thin.hip.h); STGCN_THIN=0 selects the row-tile
+// kernels of rounds 1 - 4 (A/B runs; the stage tests run both).  Read per call: the tests switch it.
+inline bool thin_wave_tiles() {
+    const char* e = getenv("STGCN_THIN");
+    return !(e && e[0] == '0');
+}
+// workgroups (4 waves) of the forward: two 16-row tiles per wave, at most four workgroups per CU
+inline int thin_fwd_wgs(int64_t rows) {
+    const int64_t tiles = (rows + 15) / 16, want = (tiles + 7) / 8, cap = 4L * device_cus();
+    return (int)(want < 1 ? 1 : want < cap ? want : cap);
 }
 
 inline int terms(const stgcn_stblock_desc* d) { return d->graph_conv == STGCN_GC_KIPF ? 2 : d->Ks; }
@@ -706,6 +733,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     const size_t lds = (size_t)16 * (a.NP + 4) * sizeof(float);   // X0 transposed
     // STGCN_GC_SP=2 (opt-in): two slabs per workgroup, every operator fragment a wave loads feeds both.  Measured equal at C2 and 3 % slower at
     // C3 (r3-26 / r3-27): the product loop was bound by the latency of its own fragment loads, not by their volume
+#ifdef STGCN_EXPERIMENTS   // (retired from the product build in round 5: a knob that never won)
     static const int force_sp = getenv("STGCN_GC_SP") ? atoi(getenv("STGCN_GC_SP")) : 0;
     const bool sp2 = a.Ks > 1 && g.maxq <= 2 && force_sp == 2;
     if (sp2) {
@@ -714,6 +742,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
         else STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_kernel<2, 8, ET, 2>), grid2, blk, 2 * lds, a);
         return STGCN_OK;
     }
+#endif
     {   // bf16 activations: the operator products from the operator's bf16 fragment plane on 32-deep MFMAs (gconv_fwd_body B16P; STGCN_GC_B16P=0: the 16-deep form)
         const char* e = getenv("STGCN_GC_B16P");
         if (g_bf16 && a.Ks > 1 && g.maxq <= 2 && !(e && e[0] == '0')) {
@@ -968,10 +997,7 @@ LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
     o.N = h->N; o.C = h->C; o.training = h->training && h->droprate > 0.f;
     o.keep_scale = 1.0f / (1.0f - h->droprate); o.thresh = drop_thresh(h->droprate); o.seed = h->seed; o.offset = h->offset;
     o.offset_dev = h->offset_dev;
-    {   // STGCN_HOOK_MASK=philox regenerates the hooked LayerNorm's dropout mask instead of reading it off the block output (A/B knob)
-        const char* e = getenv("STGCN_HOOK_MASK");
-        o.mask_from_y = (e && e[0] == 'p') ? 0 : 1;
-    }
+    o.mask_from_y = hook_mask_from_y(h->dtype == STGCN_DTYPE_BF16) ? 1 : 0;
     return o;
 }
 }  // namespace
@@ -1082,6 +1108,12 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
 int stgcn_set_debug_stages(int32_t on) {
     const int prev = g_debug_stages;
     if (on == 0 || on == 1) g_debug_stages = on;
+    return prev;
+}
+
+int64_t stgcn_set_chain_spin_ticks(int64_t ticks) {
+    const long long prev = g_chain_spin_ticks;
+    if (ticks != 0) g_chain_spin_ticks = ticks;
     return prev;
 }
 
@@ -1220,6 +1252,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     rc = d->prepacked ? STGCN_OK : launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
 
+#ifdef STGCN_EXPERIMENTS   // (round 5: the chained launch of round 4 -- measured slower, DESIGN.md section 3c -- left the product build)
     // ---- chained forward: tmp_conv1 + Align -> graph conv [-> tmp_conv2 + LayerNorm + dropout] as roles of ONE launch -----------------
     {
         const int mode = fwd_chain_mode();
@@ -1270,6 +1303,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
                 cc.words = reinterpret_cast<unsigned*>(ws + pl.ws_chain);
                 cc.ncount = with_tc2 ? 2 * (int)v.slabs1 : (int)v.slabs1;
                 cc.total = (unsigned)(n1 + n2 + n3);
+                cc.spin = g_chain_spin_ticks;
                 const dim3 grid(cc.total);
                 if (with_tc2) STGCN_LAUNCH_ET("stblock_fwd", st, (stblock_fwd_chain_kernel<64, 3, 4, true, ET>), grid, dim3(1024), lds, f1, f2, f3, cc, n1, n2, gc_threads, slot);
                 else STGCN_LAUNCH_ET("tc1_gconv_fwd", st, (stblock_fwd_chain_kernel<64, 3, 4, false, ET>), grid, dim3(512), lds, f1, f2, f3, cc, n1, n2, gc_threads, slot);
@@ -1278,6 +1312,7 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
             }
         }
     }
+#endif
 
     {
     // ---- tmp_conv1 + GLU + Align(c0 -> c1) -----------------------------------------------------
@@ -1303,6 +1338,14 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         } while (0)
         if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
 #undef STGCN_TC1_FWD
+    } else if (pl.thin_tc1 && thin_wave_tiles()) {
+        // thin first layer (K = Kt * c_in <= 4): one wave per 16-row tile, no LDS, no barrier (stgcn_kernels_thin.hip.h)
+        ThinFwdArgs f;
+        memset(&f, 0, sizeof(f));
+        f.ts.src = x; f.ts.C = d->c_in; f.ts.taps = d->Kt; f.ts.N = d->N; f.ts.Tsrc = d->T; f.ts.Tdst = v.T1; f.ts.dir = 1; f.ts.rows = v.rows1;
+        f.ts.bstride = d->x_bstride; f.ts.idx_dev = reinterpret_cast<const long*>(d->x_index_dev); f.ts.idx_stride = d->x_index_stride;
+        f.Wd = ws + pl.ws_W1dense; f.bias = ws + pl.ws_b1; f.Wap = ws + pl.ws_Wap; f.ba = ws + pl.ws_ba; f.A = saved + pl.sv_A; f.act = d->act;
+        STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (thin_tc1_fwd_kernel<ET>), dim3(thin_fwd_wgs(v.rows1)), dim3(256), 0, f);
     } else
     {
         TconvFwdArgs t1;
@@ -1327,7 +1370,9 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     rc = launch_gconv_fwd(gc, st);
     if (rc) return rc;
     }
+#ifdef STGCN_EXPERIMENTS
 after_gconv:
+#endif
     if (tc2_ln_fwd_fused_ok(d->c1, d->c2, d->Kt, d->N)) {
         // ---- tmp_conv2 + GLU + LayerNorm([N, c2]) + dropout: one workgroup per (b, t2) slab ------------------------------------
         Tc2LnFwdArgs f;

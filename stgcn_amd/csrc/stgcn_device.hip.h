@@ -551,8 +551,9 @@ struct ChainCtl {
     unsigned* words;   // device words of this launch: header, then `ncount` arrival counters (null: the stage runs as its own launch)
     int ncount;
     unsigned total;    // workgroups of the launch
+    long long spin;    // bound of one wait in ticks of the 100 MHz wall clock (launchers: g_chain_spin_ticks, stgcn_set_chain_spin_ticks)
 };
-constexpr long long kChainSpinTicks = 200000000ll;   // 2 s of the 100 MHz wall clock
+constexpr long long kChainSpinTicks = 200000000ll;   // default bound: 2 s of the 100 MHz wall clock
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) unsigned chain_gu32;
 __device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return __hip_atomic_load((const chain_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -583,7 +584,7 @@ __device__ __forceinline__ void chain_wait(const ChainCtl& c, int idx, unsigned 
             const long long t0 = wall_clock64();
             while (chain_ld(p) < expected) {
                 __builtin_amdgcn_s_sleep(24);   // ~0.7 us between polls: hundreds of waiting workgroups share the counters' memory channels with the producers' bumps (tools/ubench/chain_probe.hip)
-                if (wall_clock64() - t0 > kChainSpinTicks) {   // never hang the device: flag it and go on (the results of this launch are void)
+                if (wall_clock64() - t0 > c.spin) {   // never hang the device: flag it and go on (the results of this launch are void)
                     chain_st(c.words + 2, 1u + (unsigned)idx);
                     break;
                 }
@@ -620,6 +621,9 @@ __device__ __forceinline__ void chain_publish_peer(const ChainCtl& c, int idx, u
 #endif
     chain_add(c.words + kChainHdr + idx, n);
 }
+// TEST setting (stgcn_set_chain_spin_ticks < 0): the launch's first item withholds its arrival, so that its peers' waits -- bounded by
+// |spin| ticks -- run out for certain and the give-up path (sticky word, poisoned results) can be tested on the device and in the emulator
+__device__ __forceinline__ bool chain_withhold(const ChainCtl& c, long item) { return c.spin < 0 && item == 0; }
 // item of this workgroup by start order (as chain_enter; the emulator hands a re-run workgroup the ticket its abandoned run drew)
 __device__ __forceinline__ int chain_enter_peer(const ChainCtl& c, unsigned* slot) {
     if (threadIdx.x == 0) {
@@ -641,14 +645,23 @@ __device__ __forceinline__ bool chain_poll_peer(const ChainCtl& c, int idx, unsi
         const long long t0 = wall_clock64();
         while (chain_ld(p) < expected) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > kChainSpinTicks) {
+            if (wall_clock64() - t0 > (c.spin < 0 ? -c.spin : c.spin)) {
                 chain_st(c.words + 2, 1u + (unsigned)idx);
                 return false;
             }
         }
     }
 #elif !defined(__HIPCC__)
-    if (chain_ld(p) < expected) emu::peer_defer();
+    if (chain_ld(p) < expected) {
+        if (c.spin < 0) {   // (test setting, see chain_withhold: a wait that no re-run of the grid completes runs out like the device's)
+            if (emu::g.peer_give_up) {
+                chain_st(c.words + 2, 1u + (unsigned)idx);
+                return false;
+            }
+            emu::g.peer_may_give_up = true;
+        }
+        emu::peer_defer();
+    }
 #else
     (void)p; (void)expected;
 #endif

@@ -13,6 +13,7 @@
 #include "stgcn_kernels_fwd.hip.h"
 #include "stgcn_kernels_gctile.hip.h"
 #include "stgcn_kernels_tstep.hip.h"
+#include "stgcn_kernels_thin.hip.h"
 
 namespace stgcn {
 
@@ -1279,6 +1280,12 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
         for (int pz = 0; pz < kThreads / NC; ++pz) sacc += red[pz * NC + tid];
         part[c0 * 16 + 16 + 16 * NC + tid] = sacc;
     }
+}
+
+// the wave-per-tile form of round 5 (stgcn_kernels_thin.hip.h): same arguments, same partial layout
+template <typename ET>
+__global__ __launch_bounds__(256) void thin_tc1_bwd2_kernel(ThinBwdArgs a) {
+    thin_tc1_bwd2_body<ET>(a);
 }
 
 // ================================================================================================

@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void tconv_fwd4_body(const Tconv4Args& aa, const Head
             const int s_lo = (int)(row0 / N), s_hi = (int)((rend - 1) / N);   // the launcher admits N >= TR only: one or two windows
             chain_drain_stores();
             __syncthreads();
-            if (tid == 0)
+            if (tid == 0 && !chain_withhold(f.chain, row0))
                 for (int sw = s_lo; sw <= s_hi; ++sw) chain_publish_peer(f.chain, sw);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {

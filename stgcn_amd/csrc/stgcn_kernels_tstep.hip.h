@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
         for (long item = it_lo; item < it_hi; ++item) {
         const int b = (int)(item / a.node_tiles), nt = (int)(item - (long)b * a.node_tiles), n0 = nt * 16;
         const bool rv = n0 + r < N;
-        // all G tiles of this (window, node tile), transposed (the previous item's last readers of GT / red are this role's own F(T1 - 1))
+        // all G tiles of this (window, node tile), transposed (the previous item's F(T1 - 1) reads `red` only: its GT value was taken before barrier (C))
         for (int idx = tid; idx < T1 * 64; idx += 256) {
             const int t = idx >> 6, rem = idx & 63, rr = rem >> 2, q = rem & 3;
             const f32x4 v = n0 + rr < N ? ldx4(G_ + (((size_t)b * T1 + t) * N + n0 + rr) * 16 + 4 * q) : zero4();
@@ -388,12 +388,16 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                 if (t1 + 2 < T2) R(t1 + 2);   // slot (t1 & 1): tile t1's gate inputs were last read by E(t1), before barrier (B) of this step
             }
         }
+        // (the ReLU mask of the last tile is read BEFORE barrier (C) -- behind it a wave that has finished F(T1 - 1) goes straight
+        //  into the next item's staging, which rewrites all of GT while a slower wave of this role could still be reading it; `red` is safe,
+        //  its next writer sits behind the next item's barriers (A) and (B))
+        const bool g_last = GT[((T1 - 1) * 16 + cq) * LDG + r] > 0.f;
         __syncthreads();       // (C)
         {
             const int t = T1 - 1;
             const float* rd = red + (t & 1) * RED;
             float v = (rd[(0 * 16 + r) * LDG + cq] + rd[(1 * 16 + r) * LDG + cq]) + (rd[(2 * 16 + r) * LDG + cq] + rd[(3 * 16 + r) * LDG + cq]);
-            if (!(GT[(t * 16 + cq) * LDG + r] > 0.f)) v = 0.f;
+            if (!g_last) v = 0.f;
             if (rv) stx1(dYg_ + (((size_t)b * T1 + t) * N + n0 + r) * 16 + cq, v);
         }
         }
@@ -1222,6 +1226,7 @@ __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
 // arrived)] in ONE launch.  Roles and items come from the ticket; waves beyond a role's width leave at once (a finished wave does not take
 // part in s_barrier); every workgroup reserves the widest role's threads and LDS.
 // ================================================================================================
+#ifdef STGCN_EXPERIMENTS
 template <int CIN, int KT, int NTI, bool WITH_TC2, typename ET>
 __global__ __launch_bounds__(WITH_TC2 ? 1024 : 512) void stblock_fwd_chain_kernel(Tc1FwdArgs a1, GconvFwdArgs a2, Tc2LnFwdArgs a3, ChainCtl chain, int n1, int n2,
                                                                                    int gc_threads, int slot) {
@@ -1238,5 +1243,6 @@ __global__ __launch_bounds__(WITH_TC2 ? 1024 : 512) void stblock_fwd_chain_kerne
     }
     chain_exit(chain);
 }
+#endif
 
 }  // namespace stgcn

@@ -194,6 +194,13 @@ def set_tc1_bwd_wgs(n: int) -> int:
     return prev
 
 
+def set_chain_spin_ticks(ticks: int) -> int:
+    """Bound of one in-launch wait of the head's one-launch forward, in ticks of the device's 100 MHz clock (default 2 s); negative (test
+    setting): bound |ticks| and the first tile of every launch withholds its arrival, so its peers' waits run out for certain.  0 only
+    queries.  Returns the previous value (``stgcn_set_chain_spin_ticks``)."""
+    return int(_lib.lib().dll.stgcn_set_chain_spin_ticks(int(ticks)))
+
+
 def set_gemm_big_nt(nt: int) -> int:
     """Force the column extent (32 * nt, nt in {4, 5, 6, 8, 10}) of the big bf16 operator GEMM's tiles, 0 = the grid-rounds heuristic
     (``stgcn_set_gemm_big_nt``; the parity tests run every instance the bs-16 8192-node configuration selects).  Returns the previous value."""
@@ -792,6 +799,20 @@ class _OutBlockFn(torch.autograd.Function):
             ctx.wsc.pending_sink = sink
             grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, *grads)
+
+
+def head_chain_status(cfg: HeadConfig, B: int, T: int, wsc: WorkspaceCache, dtype=torch.float32) -> int:
+    """Sticky word of the head's one-launch forward (``stgcn_outblock_chain_status``): 0 if every in-launch wait of the last forward on
+    ``wsc`` completed, else 1 + the window whose row statistics a tile gave up waiting for (that tile's predictions are NaN).
+    Synchronises the current stream."""
+    L = _lib.lib()
+    ws = wsc.buf
+    if ws is None:
+        return 0
+    desc = make_head_desc(cfg, B, T, False, False, dtype=dtype)
+    w = C.c_uint32(0)
+    L.check(L.dll.stgcn_outblock_chain_status(C.byref(desc), ws.data_ptr(), C.byref(w), _stream_of(ws)), "stgcn_outblock_chain_status")
+    return int(w.value)
 
 
 def output_block(x: torch.Tensor, cfg: HeadConfig, params, training: bool, seed: int, offset: int, wsc: WorkspaceCache,

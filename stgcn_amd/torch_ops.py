@@ -104,9 +104,9 @@ def _bwd(dy, x_cl, gso_t_pad, y, saved, ws, params, cfg, act, gc_type, droprate,
     ops._check_device(x_cl, "x_cl", activation=True)
     L = _lib.lib()
     bc = _cfg(cfg, act, gc_type, droprate)
-    B, T, N, c_in = x_cl.shape
     if x_cl.dim() != 4 or not x_cl.is_contiguous():
         raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
+    B, T, N, c_in = x_cl.shape
     if N != bc.n_vertex or c_in != bc.c_in:
         raise ValueError(f"x_cl is {tuple(x_cl.shape)}, cfg says N={bc.n_vertex}, c_in={bc.c_in}")
     desc = ops.make_desc(bc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
@@ -202,9 +202,9 @@ def _head_bwd(dout, x_cl, saved, ws, params, cfg, act, droprate, training, need_
     ops._check_device(x_cl, "x_cl", activation=True)
     L = _lib.lib()
     hc = _head_cfg(cfg, act, droprate)
-    B, T, N, c_in = x_cl.shape
     if x_cl.dim() != 4 or not x_cl.is_contiguous():
         raise ValueError("x_cl: expected a contiguous (B, T, N, c_in) tensor")
+    B, T, N, c_in = x_cl.shape
     desc = ops.make_head_desc(hc, B, T, bool(training), bool(need_dx), dtype=x_cl.dtype)
     hplan = ops.query_head_plan(ops.make_head_desc(hc, B, T, bool(training), True, dtype=x_cl.dtype))
     _buf(saved, "saved", x_cl.device, torch.float32, int(hplan.saved_floats))

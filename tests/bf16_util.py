@@ -50,11 +50,22 @@ def err_stored(got, ref):
                 mismatch=float((d > 0).mean()))
 
 
-def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, seed=99, offset=3, pdrop=0.5, gc_form=None):
+def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training, gso=None, seed=99, offset=3, pdrop=0.5, gc_form=None,
+                        ln_scale=None, consumer=None):
     """Returns ({name: stored-tensor error dict}, {name: relative-to-max error of an fp32 output}).
-    gc_form: "poly" (slab-resident graph conv) / "recursion" (tiled path); None = whichever the plan selects."""
+    gc_form: "poly" (slab-resident graph conv) / "recursion" (tiled path); None = whichever the plan selects.
+    ln_scale = (g, b): the block's LayerNorm parameters are drawn as gamma = g * U(-1, 1), beta = b * U(-1, 1) (the
+    backward rebuilds sum g * xhat from dy * (y - keep_scale * beta) with y in bf16, which amplifies y's rounding by |beta| / |gamma xhat|).
+    consumer = "block" / "head": the block's output feeds a second fused module and dy is what THAT module's backward produces, so the
+    LayerNorm-backward row partials come out of the consumer's hook epilogue (tc1_bwd_kernel / the head's transposed conv) instead of
+    ln_bwd_rowstats_kernel; everything is then checked as for an external dy."""
     L = _lib.lib()
     cfg, p = block_case(c_in, channels, Kt, Ks, gct, act, N, B, T)
+    if ln_scale is not None:
+        rl = np.random.RandomState(77)
+        shp = tuple(p["st_blocks.0.tc2_ln.weight"].shape)
+        p["st_blocks.0.tc2_ln.weight"] = torch.from_numpy((ln_scale[0] * rl.uniform(-1, 1, shp)).astype(np.float32))
+        p["st_blocks.0.tc2_ln.bias"] = torch.from_numpy((ln_scale[1] * rl.uniform(-1, 1, shp)).astype(np.float32))
     if gso is None:
         gso = nonsym_gso(N, 5)
     rs = np.random.RandomState(11)
@@ -68,7 +79,40 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     wsc = ops.WorkspaceCache()
     y = ops.st_conv_block(x, gp, gt, bcfg, params, training, seed, offset, wsc)
     assert y.dtype == torch.bfloat16
-    y.backward(bf16_tensor(dy_np, dev))
+    hooked = None
+    if consumer is None:
+        y.backward(bf16_tensor(dy_np, dev))
+    else:
+        y.retain_grad()
+        L.dll.stgcn_profile_enable(1)
+        if consumer == "block":
+            _, pc = block_case(channels[2], channels, Kt, Ks, gct, act, N, B, T2, seed=8)
+            ccfg = ops.BlockConfig(Kt=Kt, Ks=Ks, n_vertex=N, c_in=channels[2], channels=tuple(channels), act_func=act, graph_conv_type=gct, droprate=pdrop)
+            cparams = [None if t is None else t.clone().to(dev).requires_grad_(True) for t in params_in_field_order(pc, "st_blocks.0.", gct)]
+            out = ops.st_conv_block(y, gp, gt, ccfg, cparams, training, seed + 1, offset, ops.WorkspaceCache())
+            out.backward(bf16_tensor(Q(rs.standard_normal(tuple(out.shape))), dev))
+        else:
+            from oracle import stgcn_oracle as orc
+            hc = orc.OracleConfig(Kt=Kt, Ks=Ks, n_his=12, act_func=act, graph_conv_type=gct, droprate=pdrop,
+                                  blocks=[[1], [64, 16, 64], [64, 16, channels[2]], [128, 128], [1]])
+            hp_ = {k: v for k, v in orc.random_params(hc, N, seed=3, dtype=torch.float32).items() if k.startswith("output.")}
+            hn = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight", "tmp_conv1.align.align_conv.bias",
+                  "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+            assert tuple(hp_["output.tmp_conv1.causal_conv.weight"].shape)[2] >= 1
+            hparams = [hp_["output." + n].clone().to(dev).requires_grad_(True) for n in hn]
+            Ko = tuple(hp_["output.tmp_conv1.causal_conv.weight"].shape)[2]
+            assert Ko == T2, (Ko, T2)       # (the head consumes the whole remaining time axis: T - 2 (Kt - 1) must be the fixture's Ko)
+            hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=channels[2], channels=(128, 128), end_channel=1, act_func=act, droprate=pdrop)
+            out = ops.output_block(y, hcfg, hparams, training, seed + 1, offset, ops.WorkspaceCache())
+            out.backward(torch.from_numpy(rs.standard_normal(tuple(out.shape)).astype(np.float32)).to(dev))
+        buf = C.create_string_buffer(1 << 16)
+        L.dll.stgcn_profile_collect(buf, len(buf))
+        L.dll.stgcn_profile_enable(0)
+        import json
+        launched = json.loads(buf.value.decode())
+        n_rs = sum(v["calls"] for k, v in launched.items() if k.startswith("ln_bwd_rowstats"))
+        hooked = n_rs == (1 if consumer == "block" else 0)      # (a consumer BLOCK runs the pass for its own LayerNorm: its dy came from outside)
+        dy_np = bf16_numpy(y.grad)
     if str(dev).startswith("cuda"):
         torch.cuda.synchronize()
 
@@ -103,6 +147,8 @@ def run_block_case_bf16(dev, c_in, channels, Kt, Ks, gct, act, N, B, T, training
     c0, c1, c2 = channels
     terms = 2 if gct == "graph_conv" else Ks
     stored, f32 = {}, {}
+    if hooked is not None:
+        f32["grad_none_ok.hook_epilogue_used"] = 0.0 if hooked else 1.0      # (tolerance 0: the consumer's epilogue wrote the row partials, no ln_bwd_rowstats launch)
     if not plan.recompute_tc1:
         stored["fwd.U1"] = err_stored(seg_bf16(svn, plan.sv_U1, (B, T1, N, c0)), sv["U1"])
         stored["fwd.S1"] = err_stored(seg_bf16(svn, plan.sv_S1, (B, T1, N, c0)), sv["S1"])

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 EMU = os.path.join(ROOT, "tests", "emu")
 CSRC = os.path.join(ROOT, "stgcn_amd", "csrc")
 OUT = os.path.join(EMU, "_build", "libstgcn_emu.so")
+OUT_ASAN = os.path.join(EMU, "_build", "libstgcn_emu_asan.so")
 
 
 def find_clang():
@@ -20,7 +21,30 @@ def find_clang():
     return None
 
 
-def build(force=False):
+def asan_runtime():
+    """The shared AddressSanitizer runtime of the host clang: a python process that loads the --asan build needs it LD_PRELOADed."""
+    cxx = find_clang()
+    if cxx is None:
+        return None
+    r = subprocess.run([cxx, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def build(force=False, asan=False):
+    """asan=True: the same sources under -fsanitize=address (the emulator is the one place a sanitizer can look at these kernels: every
+    global / LDS access of a kernel is an ordinary host access there).  Run with tools/emu_asan.sh."""
+    global OUT
+    if asan:
+        saved, OUT = OUT, OUT_ASAN
+        try:
+            return _build(force, ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g", "-O1", "-DSTGCN_EMU_ASAN=1"])
+        finally:
+            OUT = saved
+    return _build(force, ["-O2"])
+
+
+def _build(force, opt):
     cxx = find_clang()
     if cxx is None:
         raise RuntimeError("host clang++ not found (needed for ext_vector_type)")
@@ -40,7 +64,7 @@ def build(force=False):
         try:
             if force or not fresh():
                 tmp = OUT + ".tmp.%d" % os.getpid()
-                cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
+                cmd = [cxx, "-std=c++17", *opt, "-fPIC", "-shared", "-x", "c++", "-I", EMU, "-DSTGCN_BACKEND_NAME=\"emu-cpu\"",
                        "-Wno-unused-value", "-Wno-vla-cxx-extension",
                        os.path.join(CSRC, "stgcn_capi.hip"), os.path.join(EMU, "emu_runtime.cpp"), "-o", tmp]
                 try:
@@ -55,4 +79,5 @@ def build(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    import sys
+    print(build(force=True, asan="--asan" in sys.argv))

@@ -90,7 +90,18 @@ void wave_barrier() {
     wait_for(&w.gen, my);
 }
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define STGCN_EMU_HAS_ASAN 1
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
+
 static void fiber_init(Fiber& f) {
+#ifdef STGCN_EMU_HAS_ASAN
+    // a fiber abandoned in the middle of a frame (peer_defer, the end of a workgroup) leaves its frames' redzones poisoned in this memory
+    __asan_unpoison_memory_region(f.stack.data(), f.stack.size());
+#endif
     // initial frame, as emu_switch expects to find it: [mxcsr | x87 cw] r15 r14 r13 r12 rbx rbp <return address = fiber_entry>; after the
     // `ret` the stack pointer is 8 below a 16-byte boundary, as at any function entry
     uintptr_t top = reinterpret_cast<uintptr_t>(f.stack.data() + f.stack.size()) & ~uintptr_t(15);

@@ -51,6 +51,9 @@ template <typename K>
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K, int threads, size_t) { *nb = 2048 / threads; return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum hipMemcpyKind { hipMemcpyDeviceToHost = 2 };
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }   // launches run synchronously
 
 // events are host timestamps (launches run synchronously): the library's per-launch timer then reports emulation time per kernel
 typedef double* hipEvent_t;
@@ -104,6 +107,9 @@ struct State {
     bool defer_req = false;
     int pub_seen = 0, pub_skip = 0;
     long ticket_fixed = -1, ticket_taken = -1;   // a re-run workgroup keeps the ticket of its abandoned run
+    // test setting of the bounded waits (stgcn_set_chain_spin_ticks < 0): a wait that no re-run can complete "times out" like the device's
+    // instead of aborting the emulation -- set by the waiting workgroup (may) and by the launch loop once nothing else makes progress (now)
+    bool peer_may_give_up = false, peer_give_up = false;
 };
 extern State g;
 void yield();
@@ -288,9 +294,13 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
                 next.push_back(Deferred{d.b, emu::g.pub_seen > d.pubs ? emu::g.pub_seen : d.pubs, emu::g.ticket_taken});
             }
         }
-        if (!progress) { fprintf(stderr, "emu: deadlock: %zu workgroups wait for peer counters that nobody will complete\n", next.size()); abort(); }
+        if (!progress) {
+            if (emu::g.peer_may_give_up && !emu::g.peer_give_up) emu::g.peer_give_up = true;   // (the next round's waits run out)
+            else { fprintf(stderr, "emu: deadlock: %zu workgroups wait for peer counters that nobody will complete\n", next.size()); abort(); }
+        }
         again.swap(next);
     }
+    emu::g.peer_may_give_up = emu::g.peer_give_up = false;
     emu::g.pub_skip = 0;
     emu::g.ticket_fixed = -1;
 }

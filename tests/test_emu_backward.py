@@ -17,6 +17,7 @@ CASES = [
     (32, (64, 16, 128), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5, False),
     (128, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 10, 1, 5, True),
     (4, (64, 16, 64), 3, 3, "cheb_graph_conv", "gtu", 10, 1, 6, False),     # thin first layer (K = 12) WITH an input gradient
+    (2, (64, 16, 64), 2, 3, "cheb_graph_conv", "glu", 19, 2, 5, True),      # K = Kt * c_in = 4: the wave-per-tile thin kernels with all four taps, dZ1 written for the input gradient
 ]
 
 

@@ -19,6 +19,7 @@ CASES = [
     (16, (128, 16, 64), 2, 5, "cheb_graph_conv", "glu", 9, 2, 5),
     (1, (64, 16, 64), 3, 1, "cheb_graph_conv", "glu", 16, 1, 5),
     (1, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 300, 6, 12),   # >= 256 row tiles: exercises the 64-row tile path
+    (2, (64, 16, 64), 2, 3, "cheb_graph_conv", "gtu", 19, 2, 5),     # thin first layer with K = Kt * c_in = 4 taps (two channels x two steps)
 ]
 
 

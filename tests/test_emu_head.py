@@ -63,7 +63,7 @@ def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training, dev="cpu"):
 def test_head_forward_fused_tile_heights(monkeypatch):
     """The one-launch forward with 64-row tiles (a head whose 32-row tiles do not fit one resident round), with 32-row tiles handed out by
     start-order ticket (heads beyond that: the emulator re-runs a waiting tile under the ticket it drew), and switched off."""
-    for mode in ("4", "3", "0"):
+    for mode in ("4", "2", "3", "0"):      # ("3" is also the default since round 5; "2" / "4": tiles by blockIdx, the whole grid resident)
         monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
         test_head_fwd_bwd(64, (128, 128), 4, 70, 2, 4, "glu", True)
         test_head_fwd_bwd(64, (128, 128), 4, 40, 3, 4, "glu", True)
@@ -78,3 +78,40 @@ def test_head_tile_height_variants(monkeypatch):
     test_head_fwd_bwd(64, (128, 128), 4, 21, 2, 4, "glu", True)
     from tests.bf16_util import assert_bf16_errors, run_head_case_bf16
     assert_bf16_errors(*run_head_case_bf16("cpu", 45, 3, training=True))
+
+
+def head_wait_give_up_case(dev):
+    """The bounded wait of the one-launch forward: with the bound set to "give up at once" a tile that finds its window's
+    counter short writes NaN predictions and sets the sticky word; the NEXT forward (bound restored) is clean.  Shared by the emulator test
+    and tests/test_gpu_model.py."""
+    N, B, Ko, c_in, channels = 70, 4, 4, 64, (128, 128)
+    cfg = orc.OracleConfig(Kt=3, Ks=3, n_his=Ko, act_func="glu", droprate=0.5, blocks=[[c_in], list(channels), [1]])
+    p = {k: v for k, v in orc.random_params(cfg, N, seed=5, dtype=torch.float32).items() if k.startswith("output.")}
+    names = ["tmp_conv1.causal_conv.weight", "tmp_conv1.causal_conv.bias", "tmp_conv1.align.align_conv.weight",
+             "tmp_conv1.align.align_conv.bias", "tc1_ln.weight", "tc1_ln.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    params = [p["output." + n].clone().to(dev) for n in names]
+    x = torch.from_numpy(np.random.RandomState(2).standard_normal((B, c_in, Ko, N)).astype(np.float32)).to(dev)
+    hcfg = ops.HeadConfig(Ko=Ko, n_vertex=N, c_in=c_in, channels=channels, end_channel=1, act_func="glu", droprate=0.5)
+    wsc = ops.WorkspaceCache()
+    good = ops.output_block(x, hcfg, params, False, 1, 0, wsc)
+    assert ops.head_chain_status(hcfg, B, Ko, wsc) == 0 and bool(torch.isfinite(good).all())
+    prev = ops.set_chain_spin_ticks(-2000)      # test setting: waits bounded by 20 us, the first tile withholds its arrival
+    try:
+        assert ops.set_chain_spin_ticks(0) == -2000
+        bad = ops.output_block(x, hcfg, params, False, 1, 0, wsc)
+        word = ops.head_chain_status(hcfg, B, Ko, wsc)
+    finally:
+        ops.set_chain_spin_ticks(prev)
+    assert word == 1, word                                     # 1 + the counter index (window 0) the starved tiles gave up on
+    # window 0's tiles are rows 0 .. 95 (32-row tiles 0, 1 and 2; tile 2 straddles windows 0 / 1): all of THEIR predictions are NaN,
+    # every other tile found its windows complete and is untouched
+    nan = torch.isnan(bad).flatten()
+    assert bool(nan[:96].all()) and not bool(nan[96:].any()), nan.nonzero().flatten().tolist()
+    assert torch.equal(bad.flatten()[96:], good.flatten()[96:])
+    again = ops.output_block(x, hcfg, params, False, 1, 0, wsc)
+    assert ops.head_chain_status(hcfg, B, Ko, wsc) == 0 and torch.equal(again, good)
+
+
+def test_head_forward_wait_give_up_is_loud_and_not_sticky_across_launches():
+    bind_emulator()
+    head_wait_give_up_case("cpu")

@@ -69,14 +69,6 @@ def test_bf16_gemm_64_deep_steps():
     run_subset({"STGCN_GEMM_BF16_BK": "64"}, ["tests/test_emu_gctile.py"], "rounded or (bf16x3 and graph_conv)")
 
 
-def test_graph_conv_two_slabs_per_workgroup():
-    # forward graph conv with every operator fragment feeding two (b, t) slabs (gconv_fwd_kernel<.., SP = 2>): even and odd slab counts
-    # (the last group is short), Chebyshev Ks = 3 / 5 and Kipf, two tiles per wave (300 nodes), fp32 and bf16 activations
-    run_subset({"STGCN_GC_SP": "2"}, [FWD], "17-1-6 or 35-1-5 or 9-2-5 or 300-6-12")
-    run_subset({"STGCN_GC_SP": "2"}, ["tests/test_emu_bf16.py"], "block")
-    run_subset({"STGCN_GC_SP": "1"}, [FWD], "17-1-6 or 35-1-5")
-
-
 def test_big_bf16_gemm_32_deep_steps():
     # the 256-row-tile bf16 operator GEMM on its 4-buffer ring of 32-deep steps (the default is 64-deep steps on two buffers)
     run_subset({"STGCN_GEMM_BIG_BK": "32"}, ["tests/test_emu_gctile.py"], "bf16_gemm or tiled_block")
@@ -91,25 +83,27 @@ def test_layernorm_slab_statistics_prepass():
     run_subset({"STGCN_LN_STATS_MIN_CHUNKS": "1"}, ["tests/test_emu_bf16.py"], "tiled_block_bf16 and 37-2-6")
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_chained_forward_launch(mode, monkeypatch):
-    """STGCN_CHAIN (opt-in): tmp_conv1 + Align -> graph conv [-> tmp_conv2 + LayerNorm + dropout] as ticketed roles of
-    ONE launch with per-slab arrival counters (write-through hand-off tensors, sc1 loads).  The emulator runs the workgroups in ticket order,
-    so what is checked here is the role dispatch, the early exit of surplus waves, the counter bookkeeping (a short count aborts) and the
-    16-byte hand-off store layouts -- every forward stage and gradient against the oracle, fp32 and bf16."""
-    from tests import test_emu_backward as tb
-    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
-    from tests.emu_util import bind_emulator
-    monkeypatch.setenv("STGCN_CHAIN", mode)
-    tb.test_block_backward(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 37, 2, 8, True)
-    tb.test_block_backward(64, (64, 16, 64), 3, 2, "graph_conv", "glu", 20, 3, 6, False)
-    bind_emulator()
-    assert_bf16_errors(*run_block_case_bf16("cpu", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 37, 2, 8, True))
-
-
 def test_reduction_big_table_forms():
     """reduce_kernel's forms for tables of >= 65 536 elements (16-byte gradient / AdamW state accesses of flat jobs, 4 slices for <= 32
     partials -- C5's LayerNorm parameters) forced on the small models of the optimizer / model tests: fused reduce + AdamW against
     torch.optim.AdamW, gradients against the reference's goldens."""
     run_subset({"STGCN_REDUCE_BIG": "1"}, ["tests/test_emu_optim.py"], "trajectory or fused_step_tail or fused_into_the_head")
     run_subset({"STGCN_REDUCE_BIG": "1"}, ["tests/test_emu_model.py"], "golden")
+
+
+@pytest.mark.parametrize("mask", ["y", "philox"])
+def test_dropout_mask_source_of_the_layernorm_backward(mask):
+    """Where the backward takes a block's dropout mask from: read off the block output (kept iff y != 0: the bf16 default) or regenerated
+    with Philox (the fp32 default, the reference's semantics exactly); STGCN_HOOK_MASK forces either for both types -- fp32 and bf16 blocks in
+    training mode, and the whole model (hook epilogues of the next block / the head)."""
+    run_subset({"STGCN_HOOK_MASK": mask}, [BWD], "17-2-6-True")
+    run_subset({"STGCN_HOOK_MASK": mask}, ["tests/test_emu_bf16.py"], "block_bf16 and 17-2-6")
+    run_subset({"STGCN_HOOK_MASK": mask}, ["tests/test_emu_model.py"], "golden and tiny_cheb_f32")
+
+
+def test_thin_first_layer_row_tile_kernels():
+    """STGCN_THIN=0: the thin first layer (K = Kt * c_in <= 4) on the row-tile kernels of rounds 1 - 4 (tconv_fwd_kernel with K padded to 16,
+    thin_tc1_bwd_kernel) instead of the wave-per-tile kernels of round 5 (stgcn_kernels_thin.hip.h, the default): fp32, bf16, bf16x3 backward."""
+    run_subset({"STGCN_THIN": "0"}, [FWD], "1-channels0 or 2-channels6")
+    run_subset({"STGCN_THIN": "0"}, [BWD], "1-channels0 or 2-channels7")
+    run_subset({"STGCN_THIN": "0"}, ["tests/test_emu_bf16.py"], "block_bf16 and 21-2-7")

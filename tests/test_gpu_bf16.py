@@ -212,3 +212,16 @@ def test_c2_backward_bf16x3_products_inside_the_gradient_bar(blk):
     assert err.pop("fwd.y") <= 1e-4
     assert max(err.values()) <= 1e-3, err
     print("bf16x3 backward errors:", {k: f"{v:.2e}" for k, v in err.items()})
+
+
+@pytest.mark.parametrize("consumer", [None, "block", "head"])
+def test_gpu_bf16_layernorm_backward_with_large_beta(consumer):
+    """|beta| >> |gamma| (beta = 5 U, gamma = 0.05 U) -- the regime in which rebuilding sum g * xhat from
+    dy * (y - keep_scale * beta) with a bf16 y loses the most -- for the stand-alone row pass and both hook epilogues (the next block's
+    tc1_bwd, the head's transposed conv), at the C2 / C3 node counts with the real operators, same bars as everywhere else (tests/bf16_util.py)."""
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    N, B, name = (325, 6, "pems_bay.cheb_sym_norm_lap") if consumer == "block" else (207, 8, "metr_la.cheb_sym_norm_lap")
+    T = {None: 8, "block": 10, "head": 8}[consumer]
+    assert_bf16_errors(*run_block_case_bf16("cuda:0", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", N, B, T, True, gso=real_gso(name),
+                                            ln_scale=(0.05, 5.0), consumer=consumer))

@@ -45,18 +45,6 @@ def test_ks5_slab_path_more_slabs_than_one_round():
     assert_errors(run_block_case(64, (64, 16, 64), 3, 4, "cheb_graph_conv", "glu", 207, 64, 8, True, gso=gso))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_chained_forward_launch_c2_block1(mode, monkeypatch):
-    """The opt-in chained forward (STGCN_CHAIN) at the full C2 size on the hardware: consumers really wait for producers here (768 graph-conv
-    workgroups poll while 256 tmp_conv1 workgroups walk the time axis), so this checks visibility of the written-through hand-off tensors,
-    that no wait gives up (sticky error word) and that the control words are re-armed -- all through run_block_case's usual comparison."""
-    from tests.gpu_util import assert_errors, run_block_case
-    monkeypatch.setenv("STGCN_CHAIN", mode)
-    gso = real_gso("metr_la.cheb_sym_norm_lap")
-    for _ in range(2):
-        assert_errors(run_block_case(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, 8, True, gso=gso))
-
-
 def test_c1_shapes_kipf():
     """BASELINE.json configs[0] shapes (PeMSD7(M) 228 nodes, graph_conv, bs 8) on the GPU path."""
     from tests.gpu_util import assert_errors, run_block_case

@@ -186,3 +186,13 @@ def test_head_forward_forms_f32(mode, monkeypatch):
     monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
     test_head_fwd_bwd(64, (128, 128), 4, 207, 32, 4, "glu", True, dev="cuda:0")
     test_head_fwd_bwd(64, (128, 128), 4, 70, 3, 4, "gtu", False, dev="cuda:0")
+
+
+def test_head_forward_wait_give_up_on_the_device():
+    """the bounded in-launch wait of the head's one-launch forward, starved on purpose (the first tile withholds its
+    arrival, waits bounded by 20 us): the starved tiles' predictions are NaN, the sticky word names the window, the other tiles are
+    untouched and the NEXT launch is clean."""
+    from tests.gpu_util import bind_hip
+    from tests.test_emu_head import head_wait_give_up_case
+    bind_hip()
+    head_wait_give_up_case("cuda:0")
