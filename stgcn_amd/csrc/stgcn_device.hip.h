@@ -320,6 +320,21 @@ template <typename ET> __device__ __forceinline__ f32x4 et_round4(f32x4 v) {
     else return v;
 }
 
+// ---- dropout encoding of a block output (round 5) --------------------------------------------------------------------------------
+// The backward reads a block's dropout mask OFF ITS OUTPUT y instead of regenerating it (~100 VALU instructions of Philox per 4 elements).
+// Rounds 4's test "kept iff y != 0" took a kept element whose LayerNorm output is an exact zero (gamma = beta = 0 for it: zero-initialised
+// affine parameters) for dropped -- its gamma could then never leave zero.  Now the two zeros are told apart by their SIGN:
+//     dropped element          -> stored as -0.0
+//     kept element, value == 0 -> stored as +0.0        (decided on the value the tensor will hold: a bf16 store may round a tiny value to zero)
+// Numerically nothing changes (-0.0 == +0.0 everywhere downstream; the reference's own dropped elements are +-0 by the sign of the value the
+// mask multiplies), and the mask test is one integer compare.
+template <typename ET> __device__ __forceinline__ float et_round(float v);
+template <typename ET> __device__ __forceinline__ float drop_encode(float v, bool kept) {
+    const float vr = et_round<ET>(v);
+    return kept ? (vr == 0.f ? 0.f : vr) : -0.f;
+}
+__device__ __forceinline__ bool drop_kept(float y) { return __builtin_bit_cast(unsigned, y) != 0x80000000u; }   // (pass a scalar copy, not a vector element expression)
+
 // ---- one 16-deep matrix-product step on a wave's 16 x 16 accumulator tile ----------------------------------------------------------
 // Operand fragments: a lane's 4 consecutive k values (k = 4 * (lane >> 4) + s) of one row (A) / column (B).
 //   Mma<float>: frag = f32x4, mma = 4 x v_mfma_f32_16x16x4_f32 (step s contracts component s)

@@ -1283,9 +1283,9 @@ __global__ __launch_bounds__(256) void thin_tc1_bwd_kernel(ThinBwdArgs a) {
 }
 
 // the wave-per-tile form of round 5 (stgcn_kernels_thin.hip.h): same arguments, same partial layout
-template <typename ET>
-__global__ __launch_bounds__(256) void thin_tc1_bwd2_kernel(ThinBwdArgs a) {
-    thin_tc1_bwd2_body<ET>(a);
+template <typename ET, int ACT>
+__global__ __launch_bounds__(256, 3) void thin_tc1_bwd2_kernel(ThinBwdArgs a) {   // (3 workgroups per CU = 3 waves per SIMD: 170 registers)
+    thin_tc1_bwd2_body<ET, ACT>(a);
 }
 
 // ================================================================================================

@@ -841,9 +841,9 @@ struct LnRowstatOut {
     const float* mean;    // [slabs]
     const float* rstd;
     int N, C, act, training;
-    int mask_from_y;      // training, y given: an element was kept iff y != 0 (y = mask * (...): a dropped element is an exact zero, a kept one is zero
-                          // only if xhat * gamma + beta is -- never, for data) instead of regenerating the Philox mask: ~100 VALU instructions per
-                          // 4 elements less in the consumer's epilogue, which in the bf16 configurations is what its time steps wait for
+    int mask_from_y;      // training, y given: an element was dropped iff y is -0.0 (drop_encode: the forward stores dropped elements as -0.0 and kept
+                          // exact zeros as +0.0) instead of regenerating the Philox mask: ~100 VALU instructions per 4 elements less in the consumer's
+                          // epilogue, which in the bf16 configurations is what its time steps wait for
     float keep_scale;
     uint32_t thresh;
     uint64_t seed, offset;
@@ -869,7 +869,10 @@ __device__ __forceinline__ float2 ln_rowstat4(const LnRowstatOut& o, uint64_t of
         const float ks = o.training ? o.keep_scale : 1.f;
         if (o.training && o.mask_from_y) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) k[i] = y[i] != 0.f ? o.keep_scale : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const float yi = y[i];
+                k[i] = drop_kept(yi) ? o.keep_scale : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1862,7 +1865,7 @@ __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
         if (a.training) {
             const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] *= k[i];
+            for (int i = 0; i < 4; ++i) o[i] = drop_encode<ET>(o[i] * k[i], k[i] > 0.f);   // dropped: -0.0, kept zero: +0.0
         }
         stx4(y + 4 * q, o);
     }

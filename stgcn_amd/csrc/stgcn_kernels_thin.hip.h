@@ -74,10 +74,9 @@ struct ThinFwdArgs {
     const float* Wap;    // PK_ALIGN_FWD fragments: K = 64 (4 chunks), 16 columns
     const float* ba;     // [16]
     float* A;            // [rows][16]
-    int act;
 };
 
-template <typename ET>
+template <typename ET, int ACT>
 __global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
     typedef Mma<ET> MM;
     const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
         for (int kc = 0; kc < 4; ++kc) {
             f32x4 h;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) h[s] = gate_fwd(acc[kc][s], sigmoid_f(acc[4 + kc][s]), a.act);
+            for (int s = 0; s < 4; ++s) h[s] = gate_fwd(acc[kc][s], sigmoid_f(acc[4 + kc][s]), ACT);   // (compile-time: no branch per element)
             out = MM::mma(waf[kc], MM::cvt(h), out);   // B[k = c = 16 kc + 4 g + s][n = row = l15]
         }
         const long R = t * 16 + l15;
@@ -140,11 +139,16 @@ __global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
 struct ThinBwdArgs;   // (stgcn_kernels_bwd.hip.h: shared with the row-tile kernel this one replaces)
 
 constexpr int kThinLdT = 68, kThinLdD = 20, kThinLdX = 16;
-constexpr int kThinWaveLds = 16 * kThinLdT + 16 * kThinLdD + 16 * kThinLdX;   // floats per wave: transposition tile, dA tile, tap tile
+// floats per wave: transposition tile | dA tile | tap tile | bias of the 128 conv outputs | the 4 Align fragments (64 lanes x 4 floats each)
+constexpr int kThinWaveLds = 16 * kThinLdT + 16 * kThinLdD + 16 * kThinLdX + 128 + 4 * 256;
 inline size_t thin_bwd2_lds_bytes() { return (size_t)4 * kThinWaveLds * sizeof(float); }   // (>= the 2 x 12 x 64 float4 of the final combine)
 static_assert(4 * kThinWaveLds >= 2 * 12 * 64 * 4 + 2 * 16, "the end-of-kernel combine reuses the waves' tiles");
 
-template <typename ET, typename ARGS>
+// Register budget (pass r5-01: the first version held every per-tile value at once -- 186 VGPRs + 80 AGPRs, ONE wave per SIMD, so the 2048
+// waves of the launch ran in two rounds and it was slower than the kernel it replaced): per-tile constants that are touched once per tile (the
+// conv bias, the Align fragments) live in the wave's LDS, the gate backward runs channel tile by channel tile and its h values go straight to
+// the transposition tile; what stays in registers across tiles is the 48 accumulator registers and the 8 conv weights.
+template <typename ET, int ACT, typename ARGS>
 __device__ __forceinline__ void thin_tc1_bwd2_body(const ARGS& a) {
     typedef Mma<ET> MM;
     constexpr bool kF32 = sizeof(ET) == 4;   // float / f32x storage
@@ -154,6 +158,8 @@ __device__ __forceinline__ void thin_tc1_bwd2_body(const ARGS& a) {
     float* const Tt = stgcn_smem + wave * kThinWaveLds;   // [16 rows][68]  values in D layout written row major, read back transposed
     float* const Dt = Tt + 16 * kThinLdT;                 // [16 rows][20]  dA tile
     float* const Xt = Dt + 16 * kThinLdD;                 // [16 rows][16]  taps 0 .. K-1, a column of ones (-> db_eff), zeros
+    float* const Bs = Xt + 16 * kThinLdX;                 // [128]          b_eff
+    float* const Ws = Bs + 128;                           // [4][64 lanes][4]  PK_ALIGN_BWD fragments
     const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
     const long rows = a.rows, tiles = (rows + 15) >> 4;
     const int K = a.ts.taps * a.ts.C, C = a.ts.C, N = a.ts.N;
@@ -165,13 +171,16 @@ __device__ __forceinline__ void thin_tc1_bwd2_body(const ARGS& a) {
 
     ThinConv<ST> cw;
     cw.load(a.Wd, K, g, l15);
-    f32x4 bz[8];
+    {   // wave-private constants -> LDS
+        const f32x4 b0 = ld4(a.bias + 4 * (lane & 31));
+        f32x4 wf[4];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) bz[mt] = ld4(a.bias + 16 * mt + 4 * g);
-    typename MM::frag wat[4];   // dH^T = Wa dA^T: A[m = c = 16 mt + l15][k = j = 4 g + s] = Wa[c][j] (PK_ALIGN_BWD fragments, K = 16: one chunk)
+        for (int mt = 0; mt < 4; ++mt) wf[mt] = ld4(a.WaT + ((size_t)mt * 64 + lane) * 4);   // dH^T = Wa dA^T: A[m = c = 16 mt + l15][k = j = 4 g + s] = Wa[c][j]
+        if (lane < 32) st4(Bs + 4 * lane, b0);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) wat[mt] = MM::cvt(ld4(a.WaT + ((size_t)mt * 64 + lane) * 4));
-    for (int i = lane; i < 16 * kThinLdX; i += 64) Xt[i] = 0.f;   // (columns K + 1 .. 15 stay zero)
+        for (int mt = 0; mt < 4; ++mt) st4(Ws + (mt * 64 + lane) * 4, wf[mt]);
+        for (int i = lane; i < 16 * kThinLdX; i += 64) Xt[i] = 0.f;   // (columns K + 1 .. 15 stay zero)
+    }
     wave_lds_sync();
 
     f32x4 accW[8], accA[4], dba = zero4();   // dW_eff^T[o][k] (column K: db_eff), dWa[c][j], dba (lane-local over rows)
@@ -206,29 +215,28 @@ __device__ __forceinline__ void thin_tc1_bwd2_body(const ARGS& a) {
         st4(Dt + l15 * kThinLdD + 4 * g, da);
         Xt[l15 * kThinLdX + g] = g < K ? (g == 0 ? xk[0] : g == 1 ? xk[1] : g == 2 ? xk[2] : xk[3]) : (g == K ? 1.f : 0.f);
         if (g == 0) Xt[l15 * kThinLdX + 4] = K == 4 ? 1.f : 0.f;
-        // dH[c = 16 mt + 4 g + r][row = l15]
-        f32x4 dh[4];
+        // recomputed gate inputs z = [u | q] of channels 16 mt + 4 g + r, row l15
+        f32x4 z[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) z[mt] = ld4(Bs + 16 * mt + 4 * g);
+        cw.run(xk, g, z);
+        // channel tile by channel tile: dH = Wa dA^T, gate backward; z becomes [dU | dQ], h goes to the transposition tile
         {
             const typename MM::frag db = MM::cvt(da);   // B[k = j = 4 g + s][n = row = l15]
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) dh[mt] = MM::mma(wat[mt], db, zero4());
-        }
-        // recomputed gate inputs, gate backward
-        f32x4 z[8];
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 dh = MM::mma(MM::cvt(ld4(Ws + (mt * 64 + lane) * 4)), db, zero4());
+                f32x4 hq;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) z[mt] = bz[mt];
-        cw.run(xk, g, z);
-        f32x4 hv[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float u = z[mt][s], sg = sigmoid_f(z[4 + mt][s]);
-                float du, dq;
-                gate_bwd(dh[mt][s], u, sg, a.act, du, dq);
-                hv[mt][s] = gate_fwd(u, sg, a.act);
-                z[mt][s] = du;
-                z[4 + mt][s] = dq;
+                for (int s = 0; s < 4; ++s) {
+                    const float u = z[mt][s], sg = sigmoid_f(z[4 + mt][s]);
+                    float du, dq;
+                    gate_bwd(dh[s], u, sg, ACT, du, dq);
+                    hq[s] = gate_fwd(u, sg, ACT);
+                    z[mt][s] = du;
+                    z[4 + mt][s] = dq;
+                }
+                st4(Tt + l15 * kThinLdT + 16 * mt + 4 * g, hq);
             }
         }
         if (a.dZ && rv) {
@@ -237,8 +245,6 @@ __device__ __forceinline__ void thin_tc1_bwd2_body(const ARGS& a) {
         }
         // ---- row contractions: the D-layout values go through the wave's tile, row major, and come back as A operands [m][k = row] ----
         // dWa[c][j] += sum_rows h[row][c] dA[row][j]
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) st4(Tt + l15 * kThinLdT + 16 * mt + 4 * g, hv[mt]);
         wave_lds_sync();
         {
             const typename MM::frag bd = MM::cvt(gather4(Dt + (4 * g) * kThinLdD + l15, kThinLdD));   // B[k = row = 4 g + s][n = j = l15]

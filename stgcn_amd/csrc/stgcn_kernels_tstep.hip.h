@@ -28,7 +28,7 @@ namespace stgcn {
 // kernel that produced dy) -- they need all N nodes of a slab, which no node tile sees.
 // ================================================================================================
 struct Tc2BwdArgs {
-    const float* y;           // [B][T2][N][C2]  the block's output (training: an element was kept iff y != 0 -- no Philox in the time step) or null
+    const float* y;           // [B][T2][N][C2]  the block's output (training: an element was dropped iff y is -0.0, drop_encode -- no Philox in the time step) or null
     const float* dy;          // [B][T2][N][C2]
     const float* U;           // [B][T2][N][C2]  saved gate inputs of tmp_conv2 (RECOMP = false)
     const float* S;
@@ -197,10 +197,13 @@ __global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
                     s = rv ? cvt4(tl.s[it]) : zero4();   // rows beyond N: s = 0 makes every product of the gate backward vanish
                 }
                 if constexpr (TRAINING) {
-                    if (mask_y) {   // (uniform) y = mask * (...): a dropped element is an exact zero
+                    if (mask_y) {   // (uniform) a dropped element of y is -0.0 (drop_encode)
                         const f32x4 yv = cvt4(tl.y[it]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) dy[i] = yv[i] != 0.f ? dy[i] * a.keep_scale : 0.f;
+                        for (int i = 0; i < 4; ++i) {
+                            const float yi = yv[i];
+                            dy[i] = drop_kept(yi) ? dy[i] * a.keep_scale : 0.f;
+                        }
                     } else {
                         const f32x4 k = dropout_scale4(((uint64_t)b * T2 + t) * n4 + q0 + 16 * it, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
@@ -612,9 +615,12 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                         if (rv) {
                             const f32x4 hy = cvt4(h.y);
                             f32x4 kk = h.k;
-                            if (a.rs.training && a.rs.mask_from_y) {   // (uniform) kept iff the block output is not an exact zero: no Philox in the step
+                            if (a.rs.training && a.rs.mask_from_y) {   // (uniform) dropped iff the block output is -0.0 (drop_encode): no Philox in the step
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) kk[i] = hy[i] != 0.f ? a.rs.keep_scale : 0.f;
+                                for (int i = 0; i < 4; ++i) {
+                                    const float yi = hy[i];
+                                    kk[i] = drop_kept(yi) ? a.rs.keep_scale : 0.f;
+                                }
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
@@ -1207,7 +1213,7 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 o[i] = (hh[j][i] - mean) * rstd * ga[j][i] + be[j][i];
-                if (a.training) o[i] = ((kb >> i) & 1u) ? o[i] * a.keep_scale : 0.f;
+                if (a.training) o[i] = drop_encode<ET>(o[i] * a.keep_scale, ((kb >> i) & 1u) != 0u);   // dropped: -0.0, kept zero: +0.0
             }
             stx4_wt(y_ + (size_t)slab * N * C2 + e, o);
         }

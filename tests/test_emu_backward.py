@@ -124,3 +124,22 @@ def test_gconv_bwd2_job_waves_fit_the_launch_bounds(monkeypatch):
     monkeypatch.setattr(me, "nonsym_gso", sym_gso)
     monkeypatch.setenv("STGCN_GCBWD2_PARTS", "2")
     test_block_backward(64, (64, 16, 64), 3, 8, "cheb_graph_conv", "glu", 250, 1, 5, True)
+
+
+@pytest.mark.parametrize("mask", ["y", "philox"])
+def test_zero_initialised_layernorm_affine_still_gets_gradients(mask, monkeypatch):
+    """with gamma = beta = 0 every element of the block output is an exact zero, kept or dropped.  The backward reads the dropout
+    mask off the output; the forward therefore stores dropped elements as -0.0 and kept zeros as +0.0 (drop_encode) -- d gamma / d beta must
+    come out as the oracle's (a test on "y != 0" would make them identically zero and gamma could never leave zero).  Both mask sources."""
+    import tests.test_emu_backward as me
+    orig = me.block_case
+
+    def zeroed(*a, **k):
+        cfg, p = orig(*a, **k)
+        p["st_blocks.0.tc2_ln.weight"] = torch.zeros_like(p["st_blocks.0.tc2_ln.weight"])
+        p["st_blocks.0.tc2_ln.bias"] = torch.zeros_like(p["st_blocks.0.tc2_ln.bias"])
+        return cfg, p
+
+    monkeypatch.setattr(me, "block_case", zeroed)
+    monkeypatch.setenv("STGCN_HOOK_MASK", mask)
+    test_block_backward(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 17, 2, 6, True)

@@ -63,7 +63,7 @@ def test_head_fwd_bwd(c_in, channels, Ko, N, B, T, act, training, dev="cpu"):
 def test_head_forward_fused_tile_heights(monkeypatch):
     """The one-launch forward with 64-row tiles (a head whose 32-row tiles do not fit one resident round), with 32-row tiles handed out by
     start-order ticket (heads beyond that: the emulator re-runs a waiting tile under the ticket it drew), and switched off."""
-    for mode in ("4", "2", "3", "0"):      # ("3" is also the default since round 5; "2" / "4": tiles by blockIdx, the whole grid resident)
+    for mode in ("4", "2", "3", "5", "0"):      # ("3" / "5": 32- / 64-row tiles by start-order ticket -- the default picks one of them since round 5; "2" / "4": tiles by blockIdx, the whole grid resident)
         monkeypatch.setenv("STGCN_HEAD_FUSE", mode)
         test_head_fwd_bwd(64, (128, 128), 4, 70, 2, 4, "glu", True)
         test_head_fwd_bwd(64, (128, 128), 4, 40, 3, 4, "glu", True)

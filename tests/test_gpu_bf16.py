@@ -48,7 +48,7 @@ def test_c3_head_bf16():
     assert_bf16_errors(*run_head_case_bf16("cuda:0", 325, 64))
 
 
-@pytest.mark.parametrize("mode", ["2", "3", "4", "0"])
+@pytest.mark.parametrize("mode", ["2", "3", "4", "5", "0"])
 def test_head_forward_forms_bf16(mode, monkeypatch):
     """Every form of the head's forward at the C3 size: one launch with 32-row tiles by blockIdx ("2": 650 tiles do NOT fit one resident round
     at C3 -- the launcher falls back to two launches there, and takes the form at the small size), 32-row tiles by start-order ticket ("3":

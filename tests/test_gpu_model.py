@@ -175,7 +175,7 @@ def test_mae_rmse_match_reference_on_metr_la_windows():
     assert abs(mse - mse_ref) <= 1e-4 and abs(mae - mae_ref) <= 1e-4 and abs(rmse - rmse_ref) <= 1e-4 and abs(wmape - wmape_ref) <= 1e-5
 
 
-@pytest.mark.parametrize("mode", ["2", "3", "4", "0"])
+@pytest.mark.parametrize("mode", ["2", "3", "4", "5", "0"])
 def test_head_forward_forms_f32(mode, monkeypatch):
     """The fp32 output head in every form of its forward (one launch with 32-row tiles by blockIdx / by start-order ticket, 64-row tiles,
     two launches) at the C2 size (207 nodes, bs 32, dropout on) and at a size whose tiles straddle windows raggedly, forward and every
