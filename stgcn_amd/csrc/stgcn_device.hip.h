@@ -325,15 +325,15 @@ template <typename ET> __device__ __forceinline__ f32x4 et_round4(f32x4 v) {
 // Rounds 4's test "kept iff y != 0" took a kept element whose LayerNorm output is an exact zero (gamma = beta = 0 for it: zero-initialised
 // affine parameters) for dropped -- its gamma could then never leave zero.  Now the two zeros are told apart by their SIGN:
 //     dropped element          -> stored as -0.0
-//     kept element, value == 0 -> stored as +0.0        (decided on the value the tensor will hold: a bf16 store may round a tiny value to zero)
+//     kept element, value == 0 -> stored as +0.0: the keep-scale multiply is fma(v, keep_scale, +0.0), and (-0.0) + (+0.0) = +0.0 in
+//                                 round-to-nearest (the same instruction count as the plain multiply; not folded without fast-math)
 // Numerically nothing changes (-0.0 == +0.0 everywhere downstream; the reference's own dropped elements are +-0 by the sign of the value the
-// mask multiplies), and the mask test is one integer compare.
-template <typename ET> __device__ __forceinline__ float et_round(float v);
-template <typename ET> __device__ __forceinline__ float drop_encode(float v, bool kept) {
-    const float vr = et_round<ET>(v);
-    return kept ? (vr == 0.f ? 0.f : vr) : -0.f;
-}
-__device__ __forceinline__ bool drop_kept(float y) { return __builtin_bit_cast(unsigned, y) != 0x80000000u; }   // (pass a scalar copy, not a vector element expression)
+// mask multiplies), and the mask test is two compares.  (bf16 storage: a kept value below the smallest bf16 subnormal, |v| < 2^-134, could still
+// round to -0.0 at the store -- that needs gamma and beta themselves denormal.)
+__device__ __forceinline__ float drop_encode(float v, float keep_scale, bool kept) { return kept ? __builtin_fmaf(v, keep_scale, 0.f) : -0.f; }
+// dropped iff y is -0.0, i.e. kept iff y != 0 or its sign bit is clear (this form -- a float compare and a signed-integer compare against 0 -- instead
+// of one compare against the literal 0x80000000 keeps tc2_bwd_kernel's C2 instance inside its 128 registers: the literal form spilled 3 dwords)
+__device__ __forceinline__ bool drop_kept(float y) { return (y != 0.f) | (__builtin_bit_cast(int, y) >= 0); }   // (pass a scalar copy, not a vector element expression)
 
 // ---- one 16-deep matrix-product step on a wave's 16 x 16 accumulator tile ----------------------------------------------------------
 // Operand fragments: a lane's 4 consecutive k values (k = 4 * (lane >> 4) + s) of one row (A) / column (B).

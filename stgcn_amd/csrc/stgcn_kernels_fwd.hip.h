@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(256) void ln_norm_kernel(LnFwdArgs a) {
         if (a.training) {
             const f32x4 k = dropout_scale4((uint64_t)slab * n4 + q, a.seed, off, a.thresh, a.keep_scale);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = drop_encode<ET>(o[i] * k[i], k[i] > 0.f);   // dropped: -0.0, kept zero: +0.0
+            for (int i = 0; i < 4; ++i) o[i] = drop_encode(o[i], k[i], k[i] > 0.f);   // dropped: -0.0, kept zero: +0.0
         }
         stx4(y + 4 * q, o);
     }

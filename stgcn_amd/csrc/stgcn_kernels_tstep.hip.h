@@ -73,8 +73,11 @@ inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2, bool recomp = tr
 // The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
 // walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
 // spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
+// (Round 5, pass r5-02: the C2 instance sat at exactly 128 VGPRs -- two workgroups per CU, which the launch geometry counts on -- and an
+//  unrelated edit moved it to 129: one workgroup per CU, two rounds, 26.0 + 18.0 -> 31.3 + 22.4 us.  The instances the stated configurations
+//  run in fp32 now ASK for four waves per SIMD; the others keep the compiler's choice, they would spill.)
 template <int C2, int KT, bool TRAINING, int ACT, bool RECOMP, typename ET>
-__global__ __launch_bounds__(512) void tc2_bwd_kernel(Tc2BwdArgs a) {
+__global__ __launch_bounds__(512, (C2 == 64 && KT == 3 && ACT == 0 && !RECOMP) ? 4 : 1) void tc2_bwd_kernel(Tc2BwdArgs a) {
     typedef Mma<ET> MM;
     const ET* const dy_ = et_ptr<ET>(a.dy);
     const ET* const ym_ = et_ptr<ET>(a.y ? a.y : a.dy);   // (no y: a valid address of the same shape, the value is not used)
@@ -1213,7 +1216,7 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 o[i] = (hh[j][i] - mean) * rstd * ga[j][i] + be[j][i];
-                if (a.training) o[i] = drop_encode<ET>(o[i] * a.keep_scale, ((kb >> i) & 1u) != 0u);   // dropped: -0.0, kept zero: +0.0
+                if (a.training) o[i] = drop_encode(o[i], a.keep_scale, ((kb >> i) & 1u) != 0u);   // dropped: -0.0, kept zero: +0.0
             }
             stx4_wt(y_ + (size_t)slab * N * C2 + e, o);
         }
