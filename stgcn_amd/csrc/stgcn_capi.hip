@@ -233,7 +233,8 @@ inline bool thin_wave_tiles() {
 }
 // workgroups (4 waves) of the forward: two 16-row tiles per wave, at most four workgroups per CU
 inline int thin_fwd_wgs(int64_t rows) {
-    const int64_t tiles = (rows + 15) / 16, want = (tiles + 7) / 8, cap = 4L * device_cus();
+    static const int tpw = getenv("STGCN_THIN_FWD_TPW") ? atoi(getenv("STGCN_THIN_FWD_TPW")) : 2;   // tiles per wave (sweep knob)
+    const int64_t tiles = (rows + 15) / 16, want = (tiles + 4 * tpw - 1) / (4 * tpw), cap = 4L * device_cus();
     return (int)(want < 1 ? 1 : want < cap ? want : cap);
 }
 

@@ -173,7 +173,11 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     // grid-stride workgroups of align_gate_bwd (23.5 KB of LDS each: several per CU for latency hiding).  The thin
     // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there
     // (measured; 512 = 2 resident workgroups per CU at 62 KB of LDS -- a 513th would wait for a second round).
-    const int al_cap = g.thin ? 512 : 1024;
+    // (round 5: the wave-per-tile thin kernel holds 3 workgroups per CU; STGCN_THIN_WGS overrides the cap for sweeps)
+    static const int thin_cap_env = getenv("STGCN_THIN_WGS") ? atoi(getenv("STGCN_THIN_WGS")) : 0;
+    // (pass r5-04: 256 / 384 / 512 / 768 workgroups are within noise at C2 and C3; at the 1.3 M rows of the 8192-node graph 768 -- three per
+    //  CU, its residency -- take 74 us against 81)
+    const int al_cap = g.thin ? (thin_cap_env > 0 ? thin_cap_env : (rows1 >= (1L << 18) ? 768 : 512)) : 1024;
     g.al_wgs = (int)(tiles1 < al_cap ? tiles1 : al_cap);
     long o = 0;
     auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };
