@@ -703,7 +703,9 @@ __device__ __forceinline__ float2 ld2_sc1(const float2* base, long nelem, int id
 #endif
 }
 // 4 consecutive elements of a hand-off tensor, never from this CU's L1 (sc1 buffer load; `base` must be wave-uniform: kernel arguments and
-// the virtual block index only).  off = element offset from base.
+// the virtual block index only).  off = element offset from base.  LIMIT: the descriptor's size and the byte offset are 32-bit --
+// the window [base, base + nelem) must stay below 2 GiB; callers rebase per slab (the head's row partials: N elements; the experimental
+// chained forward: one slab / KT slabs), a whole-tensor window on a big B * T * N would clamp silently.
 template <typename ET> __device__ __forceinline__ Raw4<ET> ldraw4_sc1(const ET* base, long nelem, int off) {
     Raw4<ET> r;
 #if defined(__HIP_DEVICE_COMPILE__)

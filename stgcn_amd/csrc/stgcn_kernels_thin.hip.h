@@ -13,7 +13,7 @@
 //     4 consecutive output channels of one row = one 16-byte store.  Forward: no LDS at all, no barrier;
 //   * backward: dH^T = Wa dA^T the same way; the weight gradients contract over ROWS, i.e. need the D-layout values transposed -- through a
 //     wave-private LDS tile (wave_lds_sync only); dW_eff, db_eff (as the "tap" column of ones), dWa accumulate in MFMA accumulators over all
-//     tiles of the wave; the four waves of a workgroup are combined once, at the end (the only two workgroup barriers of the kernel).
+//     tiles of the wave; the four waves of a workgroup are combined once, at the end (a fixed-order tree through LDS: the kernel's only workgroup barriers).
 // Every global load of a tile is requested one tile ahead (raw, clamped, unconditional).
 #pragma once
 #include <type_traits>
