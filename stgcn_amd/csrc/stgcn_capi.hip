@@ -86,6 +86,9 @@ inline void prof_end(int i, hipStream_t st) {
 // STGCN_LAUNCH_LOG=<file>: one line "label@tag <kernel> <workgroups> <threads>" per launch, so that an external profile
 // (rocprofv3 counters are keyed by kernel symbol + grid) can be joined with the library's labels (tools/pmc_traffic.py)
 inline void launch_log(const char* label, const char* kernel, dim3 grid, dim3 block) {
+#ifdef STGCN_EMU_RACE
+    emu::g.kname = kernel;   // (LDS race-check build of the CPU emulator: names the launch in its reports)
+#endif
     static FILE* f = getenv("STGCN_LAUNCH_LOG") ? fopen(getenv("STGCN_LAUNCH_LOG"), "w") : nullptr;
     if (f) {
         fprintf(f, "%s@%d\t%s\t%u\t%u\n", label, g_prof_tag, kernel, grid.x * grid.y * grid.z, block.x * block.y * block.z);

@@ -12,6 +12,7 @@ EMU = os.path.join(ROOT, "tests", "emu")
 CSRC = os.path.join(ROOT, "stgcn_amd", "csrc")
 OUT = os.path.join(EMU, "_build", "libstgcn_emu.so")
 OUT_ASAN = os.path.join(EMU, "_build", "libstgcn_emu_asan.so")
+OUT_RACE = os.path.join(EMU, "_build", "libstgcn_emu_race.so")
 
 
 def find_clang():
@@ -31,10 +32,19 @@ def asan_runtime():
     return p if os.path.isabs(p) and os.path.exists(p) else None
 
 
-def build(force=False, asan=False):
+def build(force=False, asan=False, race=False):
     """asan=True: the same sources under -fsanitize=address (the emulator is the one place a sanitizer can look at these kernels: every
-    global / LDS access of a kernel is an ordinary host access there).  Run with tools/emu_asan.sh."""
+    global / LDS access of a kernel is an ordinary host access there).  Run with tools/emu_asan.sh.
+    race=True: the LDS race check -- the sources compiled with -fsanitize=thread, whose __tsan_read / __tsan_write hooks are the emulator's OWN
+    (emu_runtime.cpp: no ThreadSanitizer runtime is linked): every LDS access is checked for a conflicting access of another wave with no
+    workgroup barrier in between.  STGCN_EMU_RACE=1 makes tests/emu_util.py bind this build (tools/emu_race.sh)."""
     global OUT
+    if race:
+        saved, OUT = OUT, OUT_RACE
+        try:
+            return _build(force, ["-fsanitize=thread", "-O1", "-g", "-DSTGCN_EMU_RACE=1"])
+        finally:
+            OUT = saved
     if asan:
         saved, OUT = OUT, OUT_ASAN
         try:
@@ -80,4 +90,4 @@ def _build(force, opt):
 
 if __name__ == "__main__":
     import sys
-    print(build(force=True, asan="--asan" in sys.argv))
+    print(build(force=True, asan="--asan" in sys.argv, race="--race" in sys.argv))

@@ -110,12 +110,19 @@ struct State {
     // test setting of the bounded waits (stgcn_set_chain_spin_ticks < 0): a wait that no re-run can complete "times out" like the device's
     // instead of aborting the emulation -- set by the waiting workgroup (may) and by the launch loop once nothing else makes progress (now)
     bool peer_may_give_up = false, peer_give_up = false;
+    // LDS race check (build_emu.py --race): per-thread counts of the workgroup / wave barriers passed, the name of the running kernel
+    std::vector<unsigned> bpass, wpass;
+    const char* kname = "?";
+    size_t lds_used = kLdsBytes;
+    long races = 0, races_intra = 0;
 };
 extern State g;
 void yield();
 void block_barrier();
 void wave_barrier();
 bool run_block();   // false: the workgroup deferred itself (peer_defer) and has to be run again
+bool same_bytes(const void* a, const void* b, size_t n);   // (uninstrumented compare, LDS race check build)
+void race_launch_end();   // LDS race check build: abort if the launch that just ended had a cross-wave LDS race (no-op otherwise)
 // called by ONE thread of a workgroup whose peers have not all run yet; does not return
 [[noreturn]] void peer_defer();
 // counts the calls of the running workgroup; true = this bump was already made by an abandoned run of the same workgroup
@@ -221,7 +228,13 @@ static inline emu_f32x4 emu_mfma_f32_16x16x16bf16_1k(emu_s16x4 a, emu_s16x4 b, e
 #define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) emu_mfma_f32_16x16x16bf16_1k((a), (b), (c))
 // global_load_lds: lane i copies `size` bytes from its own global pointer to (wave-uniform LDS base) + size * i + offset
 static inline void emu_global_load_lds(const void* g, void* lds_base, unsigned size, int off) {
-    memcpy(static_cast<char*>(lds_base) + (emu::g.threadIdx_.x % emu::kWave) * size + off, g, size);
+    char* dst = static_cast<char*>(lds_base) + (emu::g.threadIdx_.x % emu::kWave) * size + off;
+#ifdef STGCN_EMU_RACE
+    // LDS race check: a copy that leaves the destination as it is (the pipelined GEMM's copy slots past the last block repeat that block:
+    // "same bytes to the same place" from another wave, benign by construction) is not an access at all
+    if (emu::same_bytes(dst, g, size)) return;
+#endif
+    memcpy(dst, g, size);
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size), (off))
 #define __builtin_amdgcn_readfirstlane(x) (x)
@@ -269,6 +282,7 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
     emu::g.gridDim_ = grid;
     emu::g.blockDim_ = block;
     emu::g.nthreads = (int)block.x;
+    emu::g.lds_used = shmem;
     emu::g.body = [=]() { kernel(static_cast<KArgs>(args)...); };
     struct Deferred { dim3 b; int pubs; long ticket; };
     std::vector<Deferred> again;
@@ -303,4 +317,5 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
     emu::g.peer_may_give_up = emu::g.peer_give_up = false;
     emu::g.pub_skip = 0;
     emu::g.ticket_fixed = -1;
+    emu::race_launch_end();
 }

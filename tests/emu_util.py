@@ -11,7 +11,8 @@ from tests.emu.build_emu import build
 def bind_emulator():
     import os
     # STGCN_EMU_LIB: emulated build of an experiment variant; STGCN_EMU_ASAN=1: the AddressSanitizer build (tools/emu_asan.sh preloads its runtime)
-    L = _lib.use_library(os.environ.get("STGCN_EMU_LIB") or build(asan=os.environ.get("STGCN_EMU_ASAN") == "1"))
+    # STGCN_EMU_RACE=1: the LDS race-check build (tools/emu_race.sh)
+    L = _lib.use_library(os.environ.get("STGCN_EMU_LIB") or build(asan=os.environ.get("STGCN_EMU_ASAN") == "1", race=os.environ.get("STGCN_EMU_RACE") == "1"))
     assert L.is_emulator
     return L
 
