@@ -152,7 +152,11 @@ struct SideStream { hipStream_t s; hipEvent_t fork, join; int state; };   // sta
 SideStream g_side = {nullptr, nullptr, nullptr, 0};
 hipStream_t side_fork(hipStream_t st) {
     if (g_side.state == 0) {
+#ifdef STGCN_EXPERIMENTS   // (round 5: measured slower on this stack -- cross-queue dependencies, r19-r33 / r3-37 -- and out of the product build)
         const char* e = getenv("STGCN_SIDE_STREAM");
+#else
+        const char* e = nullptr;
+#endif
         g_side.state = -1;
         if (e && atoi(e) == 1 && hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) == hipSuccess &&
@@ -181,7 +185,11 @@ void defer_join(hipStream_t st) {
 }
 hipStream_t defer_fork(hipStream_t st) {
     if (g_defer.state == 0) {
+#ifdef STGCN_EXPERIMENTS
         const char* e = getenv("STGCN_SIDE_WGRAD");
+#else
+        const char* e = nullptr;
+#endif
         g_defer.state = -1;
         if (e && atoi(e) == 1 && hipStreamCreateWithFlags(&g_defer.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&g_defer.fork, hipEventDisableTiming) == hipSuccess &&
@@ -1329,7 +1337,11 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         const long items = (long)d->B * f.node_tiles;
         // workgroups per CU: one for fp32 (its steps are bound by the fp32 matrix pipe: a second chain on the CU made it 12 % slower), two for
         // bf16 activations (8 x cheaper MFMAs leave a latency chain: C3 34.2 -> 27.1 us, r3-31); STGCN_TC1_FWD_PER_CU forces
+#ifdef STGCN_EXPERIMENTS
         static const int force_per_cu = getenv("STGCN_TC1_FWD_PER_CU") ? atoi(getenv("STGCN_TC1_FWD_PER_CU")) : 0;
+#else
+        constexpr int force_per_cu = 0;   // (round 5: the per-CU count is decided by the activation type; the knob left the product build)
+#endif
         const int fwd_per_cu = force_per_cu > 0 ? force_per_cu : (g_bf16 ? 2 : 1);
         const long want = (long)device_cus() * fwd_per_cu;                                    // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
         const dim3 grid((unsigned)(items < want ? items : want)), blk(512);                   // equal (item, step) ranges, one workgroup per CU

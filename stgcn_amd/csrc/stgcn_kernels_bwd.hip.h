@@ -205,7 +205,11 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     g.k3_wb = 0;
     {   // one workgroup per CU walking an equal-weight range of the (window, node tile, output step) sequence
         const long items = (long)B * g.node_tiles;
+#ifdef STGCN_EXPERIMENTS
         static const int per_cu = getenv("STGCN_TC1_BWD_PER_CU") ? atoi(getenv("STGCN_TC1_BWD_PER_CU")) : 1;   // (tuning: 2 = two interleaved chains per CU, twice the partials)
+#else
+        constexpr int per_cu = 1;
+#endif
         long wgs = (long)device_cus() * (per_cu > 0 ? per_cu : 1);
         if (wgs > items) wgs = items;
         g.k3_wgs = (int)wgs;
