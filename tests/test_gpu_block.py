@@ -17,6 +17,7 @@ SMALL = [
     (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 1, 1, 5, True),        # single vertex
     (1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 300, 1, 5, False),      # 19 node tiles (MAXQ 6 path), ragged rows
     (4, (64, 16, 64), 3, 3, "cheb_graph_conv", "gtu", 33, 2, 6, True),        # thin first layer (K = 12) with an input gradient
+    (2, (64, 16, 64), 2, 3, "cheb_graph_conv", "glu", 19, 2, 5, True),        # K = Kt * c_in = 4: the wave-per-tile thin kernels with four taps, dZ1 written for dx
 ]
 
 
@@ -34,6 +35,16 @@ def test_c2_full_size(blk, training):
     gso = real_gso("metr_la.cheb_sym_norm_lap")
     c_in, T = ((1, 12), (64, 8))[blk]
     assert_errors(run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, training, gso=gso))
+
+
+def test_thin_first_layer_row_tile_kernels_on_the_device(monkeypatch):
+    """STGCN_THIN=0: the thin first layer on the row-tile kernels of rounds 1 - 4 (still in the library as the A/B form of the round-5
+    wave-per-tile kernels, which every other test of a 1-channel block runs): full C2 block 0 and a small K = 4 case."""
+    from tests.gpu_util import assert_errors, run_block_case
+    monkeypatch.setenv("STGCN_THIN", "0")
+    gso = real_gso("metr_la.cheb_sym_norm_lap")
+    assert_errors(run_block_case(1, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, 12, True, gso=gso))
+    assert_errors(run_block_case(2, (64, 16, 64), 2, 3, "cheb_graph_conv", "glu", 19, 2, 5, True))
 
 
 def test_ks5_slab_path_more_slabs_than_one_round():
