@@ -891,6 +891,10 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
     const long item0 = u_lo / T1, item1 = u_hi / T1;
     const int s0 = (int)(u_lo - item0 * T1), s1 = (int)(u_hi - item1 * T1);
     const bool chained = chain.words != nullptr && a.chain_out >= 0;
+    STGCN_PHASE(11, 0);
+#ifdef STGCN_PHASE_TIMING   // (diagnostic build: thread 0 = M wave 0; cycles of MFMA issue / epilogue / barrier wait / item transitions, tools/gpu_phases.py kid 11)
+    long long pt_mma = 0, pt_epi = 0, pt_wait = 0, pt_a = 0, pt_b = 0, pt_c = 0, pt_steps = 0, pt_trans = 0;
+#endif
 
     if (roleM) {
         // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
@@ -912,8 +916,18 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
             const int b = (int)(item / a.node_tiles), n0 = (int)(item - (long)b * a.node_tiles) * 16;
             const bool rowv = n0 + l15 < N;
             __syncthreads();   // (A) x tiles sb .. sb + KT - 1 of this item staged
+#ifdef STGCN_PHASE_TIMING
+            if (pt_c == 0) STGCN_PHASE(11, 1);       // end of the first prologue
+            else pt_trans += clock64() - pt_c;       // item transitions: barrier (C) .. barrier (A)
+            pt_c = clock64();
+#endif
             for (int i = sb; i < se; ++i) {
                 __syncthreads();   // (B) x tile i + KT - 1 visible; partial tiles of step i - 1 visible to the E waves
+#ifdef STGCN_PHASE_TIMING
+                pt_a = clock64();
+                pt_wait += pt_a - pt_c;
+                ++pt_steps;
+#endif
                 f32x4 accP = zero4(), accQ = zero4();
 #pragma unroll
                 for (int kc = 0; kc < KCH; ++kc) {
@@ -921,6 +935,12 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
                     // B[k = ci][n = row]
                     MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g)), accP, accQ);
                 }
+#ifdef STGCN_PHASE_TIMING
+                __builtin_amdgcn_sched_barrier(0);
+                pt_b = clock64();
+                __builtin_amdgcn_sched_barrier(0);
+                pt_mma += pt_b - pt_a;
+#endif
                 f32x4 u, sg, h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -936,9 +956,28 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
                 // this wave's share of A^T[j][row]: its 16 channels of the K = C0 contraction
                 const f32x4 pa = MM::mma(waT, MM::cvt(h), zero4());
                 st4(red + (i & 1) * RED + (w * 16 + l15) * 20 + 4 * g, pa);   // D[m = j = 4g + r][n = row = l15]
+#ifdef STGCN_PHASE_TIMING
+                __builtin_amdgcn_sched_barrier(0);
+                pt_c = clock64();
+                pt_epi += pt_c - pt_b;
+#endif
             }
             __syncthreads();       // (C) last partial tiles visible
+#ifdef STGCN_PHASE_TIMING
+            pt_wait += clock64() - pt_c;   // (the wait at (C) counts as barrier wait)
+            pt_c = clock64();
+#endif
         }
+        STGCN_PHASE(11, 2);
+#ifdef STGCN_PHASE_TIMING
+        if (stgcn_phase_kid == 11 && threadIdx.x == 0 && blockIdx.x < 4096) {
+            stgcn_phase_buf[blockIdx.x * 16 + 8] = pt_mma;
+            stgcn_phase_buf[blockIdx.x * 16 + 9] = pt_epi;
+            stgcn_phase_buf[blockIdx.x * 16 + 10] = pt_wait;
+            stgcn_phase_buf[blockIdx.x * 16 + 11] = pt_steps;
+            stgcn_phase_buf[blockIdx.x * 16 + 12] = pt_trans;
+        }
+#endif
     } else {
         // =========================================== E waves ===========================================================
         const int r = tid >> 4, cq = tid & 15;         // x tiles: row r, float4 column cq (< CIN / 4)
