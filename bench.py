@@ -293,6 +293,8 @@ def main():
         ops.set_slab_gc_precision("bf16x3")          # (opt-in: forward operator products of the slab-resident graph conv)
 
     ops.set_bwd_precision(args.bwd_precision)
+    if os.environ.get("STGCN_BENCH_TC2LN_PP"):      # (env: A/B runs of tools/gpu_ab.sh, not the headline -- default: the library's own rule)
+        ops.set_tc2ln_peers(int(os.environ["STGCN_BENCH_TC2LN_PP"]))
     gso_np, gso_src = load_gso(cfg)
     N = gso_np.shape[0]
     gso_t = torch.from_numpy(gso_np).to(dev)
@@ -380,6 +382,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
     loss_val = float(loss.item())
+    from stgcn_amd.train import check_in_launch_waits
+    check_in_launch_waits(model)      # (after the timed region: a starved in-launch wait would have made the loss NaN -- this says where)
     assert np.isfinite(loss_val), "training diverged"
     replay_ms = None
     if args.replay_times:   # diagnostic (after the timed region): the GPU time of each of the first steps after a synchronisation

@@ -30,9 +30,9 @@ extern "C" {
 
 /* ABI revision: bumped whenever an entry point changes its argument list or a struct its layout (round 3 added `y` to the
  * backward entry points and `stored_US2` to the plan: 1 -> 2 in effect, never recorded; round 4: stgcn_set_gemm_big_nt, the
- * chained-launch control words in `ws`: 3, then 4; round 5: stgcn_set_chain_spin_ticks, stgcn_outblock_chain_status: 5).  stgcn_version() returns the value the LIBRARY was built with; a binding built
+ * chained-launch control words in `ws`: 3, then 4; round 5: stgcn_set_chain_spin_ticks, stgcn_outblock_chain_status: 5; round 6: stgcn_set_tc2ln_peers, stgcn_stblock_chain_status, the exchange words of tmp_conv2 + LayerNorm in `ws`: 6).  stgcn_version() returns the value the LIBRARY was built with; a binding built
  * against another header must refuse to run (stgcn_amd/_lib.py does).                                                  */
-#define STGCN_ABI_VERSION 5
+#define STGCN_ABI_VERSION 6
 
 #define STGCN_OK 0
 #define STGCN_ERR_UNSUPPORTED 1 /* shape outside what the kernels cover (message says which) */
@@ -192,6 +192,19 @@ int stgcn_set_debug_stages(int32_t on);
  * small-device branches (ranges cut inside items, 8-wave workgroups), which the emulator tests exercise that way.  Changes the
  * partial-sum arena of stgcn_stblock_plan_query.  Returns the previous value; n < 0 only queries.                              */
 int stgcn_set_tc1_bwd_wgs(int32_t n);
+
+/* When several workgroups share a (b, t) slab of the fused tmp_conv2 + LayerNorm + dropout forward (stgcn_set_tc2ln_peers; the default on
+ * launches that would otherwise leave compute units idle), the parts of a slab wait for each other's LayerNorm statistics inside the
+ * launch.  A wait is bounded (stgcn_set_chain_spin_ticks); a part whose wait ran out writes NaN outputs for its rows and sets a sticky
+ * word in `ws` (1 + the index of the (b, t) slab), which stays until the next weight pack of this module re-arms the control words.
+ * This call SYNCHRONISES `stream` and returns that word (0: every wait of the last forward completed).                              */
+int stgcn_stblock_chain_status(const stgcn_stblock_desc* desc, const float* ws, uint32_t* sticky, void* stream);
+
+/* Tuning / test knob: workgroups per (b, t) slab of the fused tmp_conv2 + LayerNorm + dropout forward (model/layers.py:254-256).
+ * 0 (default) = by the device: 1 when the slabs alone fill the compute units, 2 or 4 when a launch would otherwise leave them idle
+ * (the parts of a slab exchange their LayerNorm statistics inside the launch); 1 / 2 / 4 force a form (graphs beyond 384 nodes always
+ * run 1).  Returns the previous value; any other n only queries.                                                                 */
+int stgcn_set_tc2ln_peers(int32_t n);
 
 /* Tuning / test knob: graphs with at least n nodes use the tiled graph conv (default 513).  Returns the previous value;
  * n < 1 only queries.  Operators prepared under one setting must be used under the same setting.                        */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libstgcn_hip.so")
 
 STGCN_OK = 0
-ABI_VERSION = 5      # include/stgcn_hip.h: STGCN_ABI_VERSION (tests/test_capi_symbols.py keeps the two equal)
+ABI_VERSION = 6      # include/stgcn_hip.h: STGCN_ABI_VERSION (tests/test_capi_symbols.py keeps the two equal)
 ACT = {"glu": 0, "gtu": 1}
 GRAPH_CONV = {"cheb_graph_conv": 0, "graph_conv": 1}
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -153,6 +153,10 @@ class _Lib:
         d.stgcn_set_slab_gc_precision.restype = C.c_int
         d.stgcn_set_tc1_bwd_wgs.argtypes = [C.c_int32]
         d.stgcn_set_tc1_bwd_wgs.restype = C.c_int
+        d.stgcn_set_tc2ln_peers.argtypes = [C.c_int32]
+        d.stgcn_set_tc2ln_peers.restype = C.c_int
+        d.stgcn_stblock_chain_status.argtypes = [C.POINTER(StblockDesc), C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+        d.stgcn_stblock_chain_status.restype = C.c_int
         d.stgcn_set_debug_stages.argtypes = [C.c_int32]
         d.stgcn_set_debug_stages.restype = C.c_int
         d.stgcn_set_gc_precision.argtypes = [C.c_int32]
@@ -244,4 +248,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
                     "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
                     "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss", "stgcn_set_bwd_precision", "stgcn_set_gemm_big_nt",
-                    "stgcn_set_chain_spin_ticks", "stgcn_outblock_chain_status"]
+                    "stgcn_set_chain_spin_ticks", "stgcn_outblock_chain_status", "stgcn_set_tc2ln_peers", "stgcn_stblock_chain_status"]

@@ -731,6 +731,18 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
         }
     }
 #endif
+#ifdef STGCN_EXPERIMENTS
+    {   // persistent operator-stationary form: one workgroup per CU walking >= 2 slabs (gconv_fwd_pers_kernel; measured slower, pass r6-09)
+        static const int pers = getenv("STGCN_GC_PERS") ? atoi(getenv("STGCN_GC_PERS")) : 0;
+        const int nterm = a.Ks - 1;
+        const long sets = device_cus() / 4;
+        if (pers && (nterm == 1 || nterm == 2) && HT <= 16 && !(g_slab_gc_precision > 0 && !g_bf16) && a.slabs >= 2 * sets &&
+            gconv_fwd_pers_lds_bytes(a.NP, a.Ks) <= 160 * 1024) {
+            STGCN_LAUNCH_ET("gconv_fwd", st, (gconv_fwd_pers_kernel<ET>), dim3((unsigned)(4 * sets)), dim3(256), gconv_fwd_pers_lds_bytes(a.NP, a.Ks), a, (int)sets);
+            return STGCN_OK;
+        }
+    }
+#endif
     const GcGeom g = gc_geom(HT, pf);
     a.parts = g.parts;
     const dim3 grid((unsigned)(a.slabs * g.parts)), blk(g.waves * 64);
@@ -1083,7 +1095,9 @@ int stgcn_stblock_plan_query(const stgcn_stblock_desc* d, stgcn_stblock_plan* p)
     o = 0;
     // control words of the chained launches FIRST: their offset must not depend on need_dx / training, because the pack launch that zeroes
     // them may have been planned with other flags than the forward that uses them (stgcn_prepack packs a whole model with need_dx = 1)
-    p->chain_words = kChainHdr + 2 * v.slabs1;   // forward chain: arrival counters of A[slab] and G[slab]
+    // control words of the forward: header, the arrival counters of A[slab] and G[slab] (chained launches, experiments), then the exchange
+    // words of tmp_conv2 + LayerNorm when several workgroups share a slab (64-bit, up to kTc2LnMaxPeers per slab)
+    p->chain_words = kChainHdr + 2 * v.slabs1 + 2 * kTc2LnMaxPeers * v.slabs2;
     p->ws_chain = take(p->chain_words);
     p->ws_W1p = take((int64_t)v.NC1 * v.KP1);
     p->ws_W1d = take((int64_t)d->Kt * v.NC1 * v.CP_in);
@@ -1131,6 +1145,12 @@ int64_t stgcn_set_chain_spin_ticks(int64_t ticks) {
 int stgcn_set_tc1_bwd_wgs(int32_t n) {
     const int prev = g_tc1_bwd_wgs;
     if (n >= 0) g_tc1_bwd_wgs = n;
+    return prev;
+}
+
+int stgcn_set_tc2ln_peers(int32_t n) {
+    const int prev = g_tc2ln_peers;
+    if (n == 0 || n == 1 || n == 2 || n == 4) g_tc2ln_peers = n;
     return prev;
 }
 
@@ -1244,6 +1264,19 @@ int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_param
     return STGCN_OK;
 }
 
+int stgcn_stblock_chain_status(const stgcn_stblock_desc* d, const float* ws, uint32_t* sticky, void* stream) {
+    stgcn_stblock_plan pl;
+    int rc = stgcn_stblock_plan_query(d, &pl);
+    if (rc) return rc;
+    if (!ws || !sticky) return fail(STGCN_ERR_INVALID, "stgcn_stblock_chain_status: NULL argument");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(STGCN_ERR_LAUNCH, "stgcn_stblock_chain_status: stream synchronisation failed");
+    unsigned w = 0;
+    if (hipMemcpy(&w, reinterpret_cast<const unsigned*>(ws + pl.ws_chain) + 2, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(STGCN_ERR_LAUNCH, "stgcn_stblock_chain_status: copy failed");
+    *sticky = w;
+    return STGCN_OK;
+}
+
 int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, const float* x, const float* gso_pad, float* y,
                           float* saved, float* ws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
     stgcn_stblock_plan pl;
@@ -1344,7 +1377,8 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
 #endif
         const int fwd_per_cu = force_per_cu > 0 ? force_per_cu : (g_bf16 ? 2 : 1);
         const long want = (long)device_cus() * fwd_per_cu;                                    // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
-        const dim3 grid((unsigned)(items < want ? items : want)), blk(512);                   // equal (item, step) ranges, one workgroup per CU
+        const long by_steps = items * (long)v.T1 / tc1_min_steps(), most = items > by_steps ? items : by_steps;   // (small batches: ranges cut inside items)
+        const dim3 grid((unsigned)(most < want ? most : want)), blk(512);                     // equal (item, step) ranges, one workgroup per CU
         const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \
         do {                                                                                                  \
@@ -1400,7 +1434,13 @@ after_gconv:
         f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
         f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;
         const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N);
-        const dim3 grid((unsigned)v.slabs2);
+        // workgroups per slab (round 6): a slab is one serial chain of ~15 us whatever the batch, so a launch that leaves compute units idle
+        // (block 1 of C2: 128 slabs; every small batch) cuts the slab's node tiles over PP workgroups that exchange their statistics
+        const int pp = tc2_ln_peers(d->N, v.slabs2);
+        f.peer.words = reinterpret_cast<unsigned*>(ws + pl.ws_chain); f.peer.ncount = (int)(pp * v.slabs2); f.peer.total = (unsigned)(pp * v.slabs2);
+        f.peer.spin = g_chain_spin_ticks;
+        f.peer_slots = reinterpret_cast<unsigned long long*>(ws + pl.ws_chain + kChainHdr + 2 * v.slabs1);
+        const dim3 grid((unsigned)(v.slabs2 * pp));
         // 16 waves (4 tile groups) when the grid leaves room for it: at most ~2 workgroups per CU (measured at C2: 25.8 -> ?? us)
         static const int hv_force = getenv("STGCN_TC2LN_HV") ? atoi(getenv("STGCN_TC2LN_HV")) : 0;
         // (up to 384 nodes = 6 tiles per wave of a four-group workgroup: C3's 325-node slabs ran on 8 waves, one workgroup per CU, two rounds)
@@ -1409,10 +1449,14 @@ after_gconv:
         const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (wide && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4, ET>), grid, dim3(1024), lds, f); \
-            else if (wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 6, 4, bf16>), grid, dim3(1024), lds, f); \
-            else if (small) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2, ET>), grid, dim3(512), lds, f); \
-            else STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2, ET>), grid, dim3(512), lds, f);           \
+            if (pp == 2 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 2, ET>), grid, dim3(1024), lds, f); \
+            else if (pp == 4 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 1, 4, 4, ET>), grid, dim3(1024), lds, f); \
+            else if (pp == 2) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 3, 4, 2, ET>), grid, dim3(1024), lds, f); \
+            else if (pp == 4) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 4, ET>), grid, dim3(1024), lds, f); \
+            else if (wide && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 4, 4, 1, ET>), grid, dim3(1024), lds, f); \
+            else if (wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 6, 4, 1, bf16>), grid, dim3(1024), lds, f); \
+            else if (small) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 7, 2, 1, ET>), grid, dim3(512), lds, f); \
+            else STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 14, 2, 1, ET>), grid, dim3(512), lds, f);           \
         } while (0)
         if (d->Kt == 2) STGCN_TC2LN(2); else if (d->Kt == 3) STGCN_TC2LN(3); else STGCN_TC2LN(4);
 #undef STGCN_TC2LN

@@ -682,6 +682,50 @@ __device__ __forceinline__ bool chain_poll_peer(const ChainCtl& c, int idx, unsi
 #endif
     return true;
 }
+// ---- one-word exchange between the P workgroups that share a LayerNorm slab (tc2_ln_fwd_kernel, PP > 1): a peer's (mean, M2) travels as
+// ONE 64-bit word whose top bit (the sign of M2 >= 0, never set by a value) says "written" -- no counter, no drain, no second round trip.
+// The words are zero when the launch starts (pack launch / the launch's last workgroup, chain_exit_slots).
+__device__ __forceinline__ unsigned long long peer_word(float mean, float M2) {
+    return ((unsigned long long)(__builtin_bit_cast(unsigned, M2) | 0x80000000u) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, mean);
+}
+__device__ __forceinline__ float peer_word_mean(unsigned long long w) { return __builtin_bit_cast(float, (unsigned)w); }
+__device__ __forceinline__ float peer_word_m2(unsigned long long w) { return __builtin_bit_cast(float, (unsigned)(w >> 32) & 0x7fffffffu); }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
+__device__ __forceinline__ unsigned long long chain_ld64(const unsigned long long* p) { return __hip_atomic_load((const chain_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store((chain_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ __forceinline__ unsigned long long chain_ld64(const unsigned long long* p) { return *p; }
+__device__ __forceinline__ void chain_st64(unsigned long long* p, unsigned long long v) { *p = v; }
+#endif
+// ONE thread waits for a peer's word (bounded like chain_poll_peer; a give-up sets the sticky word and returns 0: the caller poisons its result)
+__device__ __forceinline__ unsigned long long chain_poll_word(const ChainCtl& c, const unsigned long long* p, int idx) {
+    unsigned long long w = chain_ld64(p);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!(w >> 63)) {
+        const long long t0 = wall_clock64();
+        while (!((w = chain_ld64(p)) >> 63)) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > (c.spin < 0 ? -c.spin : c.spin)) {
+                chain_st(c.words + 2, 1u + (unsigned)idx);
+                return 0ull;
+            }
+        }
+    }
+#elif !defined(__HIPCC__)
+    if (!(w >> 63)) {
+        if (c.spin < 0) {   // (test setting: a wait that no re-run of the grid completes runs out like the device's)
+            if (emu::g.peer_give_up) {
+                chain_st(c.words + 2, 1u + (unsigned)idx);
+                return 0ull;
+            }
+            emu::g.peer_may_give_up = true;
+        }
+        emu::peer_defer();
+    }
+#endif
+    return w;
+}
 // one (x, y) pair of a hand-off array, written through / read past this CU's L1 (base wave-uniform, idx = element index)
 __device__ __forceinline__ void st2_wt(float2* p, float2 v) {
 #if STGCN_WT_STORES && defined(__HIP_DEVICE_COMPILE__)

@@ -48,12 +48,30 @@ inline int device_cus() {
     }
     return cus;
 }
+// workgroups per slab of tc2_ln_fwd_kernel (round 6): 1 when the slabs alone fill the device; 2 / 4 when PP * slabs workgroups still fit the
+// compute units one each (the peers exchange their LayerNorm statistics through L2).  stgcn_set_tc2ln_peers forces 1 / 2 / 4 (0 = this rule).
+constexpr int kTc2LnMaxPeers = 4;
+inline int g_tc2ln_peers = 0;
+inline int tc2_ln_peers(int N, long slabs2) {
+    const int tiles = (N + 15) / 16;
+    int pp = 1;
+    if (g_tc2ln_peers > 0) pp = g_tc2ln_peers;
+    else if (4 * slabs2 <= device_cus()) pp = 4;
+    else if (2 * slabs2 <= device_cus()) pp = 2;
+    if (N > 384) pp = 1;                       // (the peer instances hold at most 24 node tiles per slab)
+    while (pp > 1 && tiles < 2 * pp) pp >>= 1;   // at least two node tiles per workgroup
+    return pp;
+}
 // tc2_bwd_kernel recomputes the gate inputs of tmp_conv2 (and the forward does not store them) for bf16 activations, reads the stored
 // ones for fp32 (see the kernel's header comment for the measurement); STGCN_TC2_RECOMP=0/1 forces one
 inline bool tc2_recompute(int dtype_bf16) {
     static const int force = getenv("STGCN_TC2_RECOMP") ? atoi(getenv("STGCN_TC2_RECOMP")) : -1;
     return force >= 0 ? force != 0 : dtype_bf16 != 0;
 }
+// fewest output steps a range of the two tc1 time-stepping kernels is cut down to when a batch offers fewer (window, node tile) items than
+// the device has compute units (measured at C2 shapes, profiles/r6-08_tc1_small_batch_ranges.txt: bs 4 tc1_bwd 36.0 -> 21.6 us, tc1_fwd
+// 17.6 -> 11.2 us with 2; 1 and 3 are slower -- more partial blocks for the reduction / longer chains)
+inline int tc1_min_steps() { return 2; }
 inline bool tc1_ts_shape(int c_in, int c0, int c1, int Kt) { return c0 == 64 && c1 == 16 && Kt == 3 && (c_in == 16 || c_in == 32 || c_in == 64); }
 inline bool tc1_bwd_shape_ok(int c_in, int c0, int c1, int Kt) {
     return (fuse_mask() & FUSE_TC1_BWD) && tc1_ts_shape(c_in, c0, c1, Kt) && tc1_bwd_lds_bytes(c0, c_in, Kt) <= 150 * 1024;
@@ -211,7 +229,11 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
         constexpr int per_cu = 1;
 #endif
         long wgs = (long)device_cus() * (per_cu > 0 ? per_cu : 1);
-        if (wgs > items) wgs = items;
+        // (round 6) small batches: fewer items than compute units -- the ranges are then cut INSIDE items (at least kTc1MinSteps output steps
+        // each) instead of leaving one workgroup to walk a whole item alone: the launch is one workgroup's chain, whatever the batch
+        const long by_steps = items * (long)T / tc1_min_steps();
+        const long most = items > by_steps ? items : by_steps;
+        if (wgs > most) wgs = most;
         g.k3_wgs = (int)wgs;
     }
     g.k3_stride = tc1_bwd_part_floats(c0, c_in, Kt);

@@ -1638,6 +1638,135 @@ __global__ __launch_bounds__(MAXW * 64) void gconv_fwd_b16p_kernel(GconvFwdArgs 
 
 #ifdef STGCN_EXPERIMENTS   // operator-stationary graph conv (opt-in, STGCN_GC_REG=<workgroups per CU>)
 // ================================================================================================
+// F2, persistent operator-stationary form (round 6): ONE workgroup per compute unit walks several (b, t) slabs.
+// The slab-per-workgroup kernel above runs its 1280 / 768 workgroups of C2 as exactly one resident round: all five workgroups of a CU
+// stage X0 together (matrix pipe idle), multiply together and store together -- 19.5 us for 7.2 us of matrix time.  Here
+//   * wave w of workgroup (set, part) owns node tile part + 4 w for the whole launch: the fragments of T_1 .. T_{Ks-1} of THAT tile
+//     (KCH chunks of 1 KiB per term: 26 KiB for the 207-node graph at Ks = 3) are copied ONCE into a wave-private LDS region and
+//     every product reads them from there (the operator crosses L2 -> CU once per workgroup, not once per slab);
+//   * the workgroup walks slabs set, set + S, set + 2 S, ..: X0 of the NEXT slab is requested into registers before the products of the
+//     current one and written to the other LDS buffer behind them -- one barrier per slab, and it does NOT drain vmcnt (barrier_only):
+//     round 2's register-stationary experiment (gconv_fwd_reg_kernel below) put __syncthreads() right behind its prefetch, i.e. waited for
+//     the load it had just issued and for the previous slab's write-through stores in every iteration (4.4 us per slab for 1.8 us of MFMAs);
+//   * the epilogue is the slab kernel's (X_k tiles are at once store layout and A operand of the 16 x 16 weight contraction).
+// grid = 4 * S workgroups of 256 threads (S slab sets, parts = 4: up to 16 node tiles = 256 nodes), LDS = 4 waves x (Ks - 1) x KCH KiB + two
+// transposed X0 buffers (C2: 133 KB: one workgroup per CU).  Same arithmetic, same summation order per element as gconv_fwd_kernel.
+// MEASURED SLOWER (pass r6-09, profiles/r6-09_gconv_fwd_persistent.txt: C2 24.7 + 18.3 us against 21.6 + 14.9 for the slab kernel, results equal,
+// all stage tests green): with ONE wave per SIMD the ~300 VALU / SALU instructions a wave spends per slab outside its 116 MFMAs (X0 commit,
+// fetch addresses, epilogue stores) issue at one per ~7.5 cycles (tools/ubench/overlap.hip) and nothing fills the gaps -- 6.5 k cycles per
+// slab for 3.7 k of matrix time -- while the slab kernel's five co-resident workgroups per CU give every SIMD five waves to interleave.  A second
+// wave group per workgroup does not fit (104 KB of fragments + 4 X0 buffers = the whole LDS) and five slabs per set cut 2 + 2 + 1.  Opt-in
+// (-DSTGCN_EXPERIMENTS, STGCN_GC_PERS=1), like round 2's register-stationary form below.
+// ================================================================================================
+inline size_t gconv_fwd_pers_lds_bytes(int NP, int terms) { return ((size_t)4 * (terms - 1) * (NP / 16) * 256 + (size_t)2 * 16 * (NP + 4)) * sizeof(float); }
+template <typename ET>
+__global__ __launch_bounds__(256) void gconv_fwd_pers_kernel(GconvFwdArgs a, int S) {
+    typedef Mma<ET> MM;
+    extern __shared__ float stgcn_smem[];
+    constexpr int THREADS = 256, NV = 4;   // float4 per thread and slab (NP * 4 <= 1024)
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = (int)(blockIdx.x & 3u), set = (int)(blockIdx.x >> 2);
+    const int N = a.N, NP = a.NP, LDX = NP + 4, HT = NP >> 4, KCH = NP >> 4, NT = a.Ks - 1;   // NT operator terms (1 or 2)
+    const size_t MSZ = (size_t)NP * NP;
+    const int ht = part + 4 * w;           // this wave's node tile
+    const bool own = ht < HT;              // (wave-uniform)
+    float* const Fr = stgcn_smem + (size_t)w * NT * KCH * 256;      // [NT][KCH][64 lanes][4]: this wave's operator fragments
+    float* const XTb = stgcn_smem + (size_t)4 * NT * KCH * 256;     // [2][16][LDX]: X0 transposed, two buffers
+    ET* const Xk_ = et_ptr<ET>(a.Xk);
+    ET* const G_ = et_ptr<ET>(a.G);
+    const ET* const A_ = et_ptr<ET>(a.A);
+
+    // ---- X0 slabs: registers (one slab ahead) -> LDS, transposed [c][node] ------------------------------------------------------
+    Raw4<ET> xv[NV];
+    auto fetch = [&](long slab) __attribute__((always_inline)) {   // (unconditional, clamped: a branch around a load resets the compiler's wait counts)
+        const ET* Asl = A_ + (size_t)(slab < a.slabs ? slab : a.slabs - 1) * N * 16;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS, n = idx >> 2, c4 = idx & 3;
+            xv[i] = ldraw4(Asl + (size_t)(n < N ? n : N - 1) * 16 + c4 * 4);
+        }
+    };
+    auto commit = [&](float* XT) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * THREADS, n = idx >> 2, c4 = idx & 3;
+            if (idx < NP * 4) {
+                const f32x4 v = n < N ? cvt4(xv[i]) : zero4();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) XT[(c4 * 4 + j) * LDX + n] = v[j];
+            }
+        }
+    };
+    fetch(set);
+    // ---- this wave's operator fragments -> its LDS region (lane-linear 16-byte stores: conflict free), in batches of 8 loads ---------
+    if (own) {
+        for (int c0 = 0; c0 < NT * KCH; c0 += 8) {
+            f32x4 fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < NT * KCH ? c0 + u : NT * KCH - 1, k = c / KCH, kc = c - k * KCH;
+                fv[u] = ld4(a.Lp + (size_t)k * MSZ + ((size_t)(ht * KCH + kc) * 64 + lane) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < NT * KCH) st4(Fr + (size_t)(c0 + u) * 256 + lane * 4, fv[u]);
+        }
+    }
+    // weight fragments B[kk = c][col = j] = W_k[c = 4g + s][j = l15] of the (up to) three terms, bias
+    typename MM::frag wf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        f32x4 v = zero4();
+        if (k <= NT && !(a.kipf && k == 0)) {
+            const float* Wk = a.W + (a.kipf ? 0 : (size_t)k * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = Wk[(4 * g + s) * 16 + l15];
+        }
+        wf[k] = MM::cvt(v);
+    }
+    const float bb = a.bias ? a.bias[l15] : 0.f;
+    commit(XTb);
+    barrier_only();
+
+    int it = 0;
+    for (long slab = set; slab < a.slabs; slab += S, ++it) {
+        const float* const XT0 = XTb + (it & 1) * 16 * LDX;
+        fetch(slab + S);                   // the next slab of this set (clamped beyond the end: never committed)
+        if (own) {
+            const int h = ht * 16 + l15;
+            const f32x4 res = ld4(XT0 + l15 * LDX + ht * 16 + 4 * g);   // residual X0[h = ht*16 + 4g + r][j = l15] (D layout of the weight contraction)
+            f32x4 yacc = MM::mma(MM::cvt(gather4(XT0 + (4 * g) * LDX + h, LDX)), wf[0], zero4());   // term 0: X0 W0
+            f32x4 acc1 = zero4(), acc2 = zero4();
+            if (NT == 2) {
+#pragma unroll 4
+                for (int kc = 0; kc < KCH; ++kc) {
+                    const typename MM::frag af = MM::cvt(ld4(XT0 + l15 * LDX + kc * 16 + 4 * g));   // A[c = l15][node = kc*16 + 4g + s]
+                    MM::mma_b2(af, MM::cvt(ld4(Fr + (size_t)kc * 256 + lane * 4)), MM::cvt(ld4(Fr + (size_t)(KCH + kc) * 256 + lane * 4)), acc1, acc2);
+                }
+            } else {
+#pragma unroll 4
+                for (int kc = 0; kc < KCH; ++kc)
+                    acc1 = MM::mma(MM::cvt(ld4(XT0 + l15 * LDX + kc * 16 + 4 * g)), MM::cvt(ld4(Fr + (size_t)kc * 256 + lane * 4)), acc1);
+            }
+            // acc[r] = X_k[h][c = 4g + r]: store layout and A operand of the weight contraction
+            if (a.Xk && h < N) {
+                stx4_wt(Xk_ + ((size_t)slab * N + h) * 16 + 4 * g, acc1);
+                if (NT == 2) stx4_wt(Xk_ + (((size_t)a.slabs + slab) * N + h) * 16 + 4 * g, acc2);
+            }
+            if (NT == 2) MM::mma_ab2(MM::cvt(acc1), wf[1], MM::cvt(acc2), wf[2], yacc);
+            else yacc = MM::mma(MM::cvt(acc1), wf[1], yacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = ht * 16 + 4 * g + r;
+                if (hh < N) stx1(G_ + ((size_t)slab * N + hh) * 16 + l15, fmaxf(yacc[r] + bb + res[r], 0.f));
+            }
+        }
+        if (slab + S < a.slabs) commit(XTb + ((it & 1) ^ 1) * 16 * LDX);   // (uniform) the other buffer: its last readers are behind the previous barrier
+        barrier_only();
+    }
+}
+
+// ================================================================================================
 // F2 (operator-stationary variant): the fragments of T_1 .. T_{Ks-1} a wave needs for ITS node tile (KCH chunks per term,
 // 1 KiB each: 26 KiB for the 207-node graph, Ks = 3) are loaded into registers ONCE and the workgroup then walks `spw`
 // slabs: per MFMA of the slab-per-workgroup kernel a wave pulls 256 B of operator through its CU's vector-memory path

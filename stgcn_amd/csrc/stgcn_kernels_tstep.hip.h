@@ -1075,12 +1075,19 @@ struct Tc2LnFwdArgs {
     uint32_t thresh;
     uint64_t seed, offset;
     const uint64_t* offset_dev;
+    ChainCtl peer;                 // PP > 1: ticket / finished / sticky words of the launch (header only, ncount = 0)
+    unsigned long long* peer_slots;   // PP > 1: [slabs][PP] exchange words (peer_word), zero at launch start
 };
 constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
 inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 64) * sizeof(float); }
 
 // bid = the (b, t2) slab of this workgroup; chained launch: the KT input slabs G[b][t2 + tap] are awaited on counters chain_in + b * T1 + t2 + tap
-template <int C2, int KT, int NTI, int HV, typename ET>
+// PP > 1 (round 6): PP workgroups share a slab, each owns a contiguous range of its node tiles (the per-slab chain -- staging, tile passes,
+// statistics, normalise -- is what a launch of few slabs costs, whatever the batch: 15 us per workgroup at 207 nodes, half the chip idle
+// when block 1 offers 128 slabs).  Slab and part come from a start-order TICKET (peers hold consecutive tickets: a workgroup only ever
+// waits for workgroups that have started or are next to start -- no residency assumption); the parts' (mean, M2) meet through one 64-bit
+// word each (peer_word) and are merged in part order by every peer: bitwise the same statistics in all of them, run to run.
+template <int C2, int KT, int NTI, int HV, int PP, typename ET>
 __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int bid, const ChainCtl& chain) {
     static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
     typedef Mma<ET> MM;
@@ -1089,36 +1096,42 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
     ET* const y_ = et_ptr<ET>(a.y);
     constexpr int NC = 2 * C2, MT = C2 / 16;
     extern __shared__ float stgcn_smem[];
-    float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]
-    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [3 * 4 * HV]
+    float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]  (NPR = this workgroup's rows)
+    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [3 * 4 * HV] wave statistics | [2 * PP] peers' (mean, M2) | ticket word
     const int tid = threadIdx.x, wv = tid >> 6, p = wv & (MT - 1), hf = wv >> 2, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
-    const long slab = bid;
-    const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N, NPR = a.NPR, ntiles = NPR >> 4;
-    const bool cin = chain.words != nullptr && a.chain_in >= 0;
-
     STGCN_PHASE(9, 0);
-    // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)
+    // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)  (requested before the ticket: one wait covers both)
     typename MM::frag wP[KT], wQ[KT];
 #pragma unroll
     for (int kc = 0; kc < KT; ++kc) {
         wP[kc] = MM::cvt(ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4));
         wQ[kc] = MM::cvt(ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4));
     }
-    // stage the KT input slabs G[b][t2 + tap] (zero rows beyond N)
+    int vb = bid;
+    if constexpr (PP > 1) vb = chain_enter_peer(a.peer, reinterpret_cast<unsigned*>(red + 3 * 4 * HV + 2 * PP));
+    const long slab = PP > 1 ? vb / PP : vb;
+    const int part = PP > 1 ? vb % PP : 0;
+    const int b = (int)(slab / a.T2), t2 = (int)(slab - (long)b * a.T2), N = a.N;
+    // this workgroup's node tiles [tile0, tile0 + ntiles) of the slab's NPR / 16 (balanced cut), staged as NPR = 16 * ntiles local rows
+    const int alltiles = a.NPR >> 4, tile0 = PP > 1 ? part * alltiles / PP : 0, ntiles = PP > 1 ? (part + 1) * alltiles / PP - tile0 : alltiles;
+    const int NPR = ntiles << 4, row0 = tile0 << 4;
+    const bool cin = chain.words != nullptr && a.chain_in >= 0;
+
+    // stage this workgroup's rows of the KT input slabs G[b][t2 + tap] (zero rows beyond N)
     const ET* Gb = et_ptr<ET>(a.G) + ((size_t)b * a.T1 + t2) * N * 16;
     if (cin) {   // (the weight loads above are in flight while the last of the KT slabs arrives)
 #pragma unroll
         for (int tap = 0; tap < KT; ++tap) chain_wait(chain, a.chain_in + b * a.T1 + t2 + tap, a.chain_expect);
         for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
-            const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
-            const int eo = (tap * N + (rr < N ? rr : N - 1)) * 16 + 4 * q;
+            const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR, gr = row0 + rr;
+            const int eo = (tap * N + (gr < N ? gr : N - 1)) * 16 + 4 * q;
             const f32x4 v = cvt4(ldraw4_sc1(Gb, (long)KT * N * 16, eo));
-            st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? v : zero4());
+            st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, gr < N ? v : zero4());
         }
     } else
     for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
-        const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR;
-        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, rr < N ? ldx4(Gb + ((size_t)tap * N + rr) * 16 + 4 * q) : zero4());
+        const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR, gr = row0 + rr;
+        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, gr < N ? ldx4(Gb + ((size_t)tap * N + gr) * 16 + 4 * q) : zero4());
     }
     const int c = 16 * p + 4 * g;   // this lane's 4 channels
     const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C2 + c);
@@ -1126,63 +1139,103 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
     STGCN_PHASE(9, 1);
 
     unsigned kbits2 = 0;
-    // LayerNorm parameters of this lane's elements: requested now, consumed after the statistics (in flight during the MFMA phase).
+    // LayerNorm parameters of this lane's elements: consumed after the statistics.  Requested before the tile passes (interleaved form) or
+    // between the matrix phase and the VALU phase (phased form: the accumulators of all tiles are live during the matrix phase).
     // (Kept as an always-inline lambda: with the same loop written in place the register allocator of ROCm 7.2 spills 17 VGPRs in the
     //  16-wave variant -- 128 VGPRs + 72 bytes of scratch, 23 -> 35 us -- and with the lambda it settles at 116 VGPRs.)
     f32x4 ga[NTI], be[NTI];
     auto load_affine = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NTI; ++j) {
-            const int row = (hf + HV * j) * 16 + l15, rcl = row < N ? row : N - 1;
+            const int row = row0 + (hf + HV * j) * 16 + l15, rcl = row < N ? row : N - 1;
             ga[j] = ld4(a.gamma + (size_t)rcl * C2 + c);
             be[j] = ld4(a.beta + (size_t)rcl * C2 + c);
         }
     };
-    load_affine();
+    // PHASED (round 6, the forms of up to 4 tiles per wave): ALL matrix products of the wave first, then the VALU work of all its tiles.
+    // What the hardware does with it (tools/ubench/overlap.hip, profiles/r6-01_valu_mfma_overlap.txt): an fp32 MFMA and a VALU instruction
+    // of the same SIMD never overlap -- not across waves either -- so a SIMD's time here is the SUM of its 13 tile passes' 24 MFMAs x 32
+    // cycles (10 k) and their ~250 VALU instructions at ~3.5 cycles (14 k with four waves issuing), whatever the order: phase stamps of both
+    // forms agree (profiles/r6-05_phases_tc2_ln_fwd.txt: matrix phase 9.1 k, VALU phase 7.6 k, wait for the SIMD's other waves 9.3 k cycles
+    // for wave 0), and the launch times are equal within noise.  Kept because the phased form is what the PP > 1 instances were built and
+    // tested on; the lever of this kernel is its VALU instruction count (the GTU / GLU branch below: - 0.3 us per launch).
+    constexpr bool PHASED = NTI <= 4;
+    if constexpr (!PHASED) load_affine();
     const uint64_t off = a.offset + (a.offset_dev ? *a.offset_dev : 0);
     const uint64_t n4 = ((uint64_t)N * C2) >> 2;
     // Per row tile: MFMAs, then the gate (U = P + b, S = sigmoid(Q + b), h = act(U) * S, kept in hh) and the keep bits of the dropout mask.
-    // The two waves of a SIMD (hf = 0 / 1) fall into anti-phase: one issues MFMAs while the other runs the VALU work of its previous tile.
     f32x4 hh[NTI];
     unsigned kbits = 0;
     float sum = 0.f, cnt_l = 0.f;
+    f32x4 aP[PHASED ? NTI : 1], aQ[PHASED ? NTI : 1];
+    auto tile_mma = [&](int nt, f32x4& accP, f32x4& accQ) __attribute__((always_inline)) {
+        accP = zero4();
+        accQ = zero4();
+#pragma unroll
+        for (int kc = 0; kc < KT; ++kc) {
+            // B[k = 4g + s][n = row]
+            MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g)), accP, accQ);
+        }
+    };
+    auto tile_valu = [&](int j, int row, const f32x4& accP, const f32x4& accQ) __attribute__((always_inline)) {
+        if (a.training) {
+            const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (((size_t)(row < N ? row : 0) * C2 + c) >> 2), a.seed, off, a.thresh, 1.0f);
+            kbits |= ((k[0] > 0.f ? 1u : 0u) | (k[1] > 0.f ? 2u : 0u) | (k[2] > 0.f ? 4u : 0u) | (k[3] > 0.f ? 8u : 0u)) << (4 * (j & 7));
+        }
+        if (row < N) {
+            f32x4 u, sg, h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = accP[i] + bp[i];
+                sg[i] = sigmoid_f(accQ[i] + bq[i]);
+            }
+            // (a real branch on the uniform `act`: written as a select, both gates were computed for every element -- 8 more
+            //  transcendentals per lane and tile in the GLU blocks, on a SIMD whose VALU time adds to its fp32 MFMA time)
+            if (a.act == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = u[i] * sg[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = tanh_f(u[i]) * sg[i];
+            }
+            const size_t o = ((size_t)slab * N + row) * C2 + c;
+            if (a.U) {   // (uniform) only when a consumer of the stored gate inputs exists: the stage tests, the unfused backward
+                stx4_wt(U_ + o, u);
+                stx4_wt(S_ + o, sg);
+            }
+            hh[j] = h;
+            sum += (h[0] + h[1]) + (h[2] + h[3]);
+            cnt_l += 4.f;
+        }
+    };
+    if constexpr (PHASED) {
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+            aP[j] = zero4();
+            aQ[j] = zero4();
+            if (hf + HV * j < ntiles) tile_mma(hf + HV * j, aP[j], aQ[j]);   // uniform per wave
+        }
+        load_affine();
+        STGCN_PHASE(9, 2);
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+            hh[j] = zero4();
+            if (hf + HV * j < ntiles) tile_valu(j, row0 + (hf + HV * j) * 16 + l15, aP[j], aQ[j]);
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int nt = hf + HV * j, row = nt * 16 + l15;
+        const int nt = hf + HV * j, row = row0 + nt * 16 + l15;   // nt: tile of this workgroup's range (its LDS rows), row: row of the slab
         hh[j] = zero4();
         if (nt < ntiles) {   // uniform per wave
-            f32x4 accP = zero4(), accQ = zero4();
-#pragma unroll
-            for (int kc = 0; kc < KT; ++kc) {
-                // B[k = 4g + s][n = row]
-                MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g)), accP, accQ);
-            }
-            if (a.training) {
-                const f32x4 k = dropout_scale4((uint64_t)slab * n4 + (((size_t)(row < N ? row : 0) * C2 + c) >> 2), a.seed, off, a.thresh, 1.0f);
-                kbits |= ((k[0] > 0.f ? 1u : 0u) | (k[1] > 0.f ? 2u : 0u) | (k[2] > 0.f ? 4u : 0u) | (k[3] > 0.f ? 8u : 0u)) << (4 * (j & 7));
-            }
-            if (row < N) {
-                f32x4 u, sg, h;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    u[i] = accP[i] + bp[i];
-                    sg[i] = sigmoid_f(accQ[i] + bq[i]);
-                    h[i] = gate_fwd(u[i], sg[i], a.act);
-                }
-                const size_t o = ((size_t)slab * N + row) * C2 + c;
-                if (a.U) {   // (uniform) only when a consumer of the stored gate inputs exists: the stage tests, the unfused backward
-                    stx4_wt(U_ + o, u);
-                    stx4_wt(S_ + o, sg);
-                }
-                hh[j] = h;
-                sum += (h[0] + h[1]) + (h[2] + h[3]);
-                cnt_l += 4.f;
-            }
+            tile_mma(nt, aP[0], aQ[0]);
+            tile_valu(j, row, aP[0], aQ[0]);
         }
         if ((j & 7) == 7 && j + 1 < NTI) {   // (NTI = 14: the keep bits of the first 8 tiles move to the upper word)
             kbits2 = kbits;
             kbits = 0;
         }
+    }
     }
     STGCN_PHASE(9, 3);
     // slab statistics with ONE barrier: per-wave (count, mean, M2) about the wave's own mean, merged exactly (Chan et al.)
@@ -1195,8 +1248,8 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + HV * j) * 16 + l15;
-        if (row < N) {
+        const int row = row0 + (hf + HV * j) * 16 + l15;
+        if (row < N && hf + HV * j < ntiles) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) m2 += (hh[j][i] - mean_w) * (hh[j][i] - mean_w);
         }
@@ -1239,16 +1292,51 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
             M2 += red[3 * k + 2] + red[3 * k] * d * d;
         }
     }
+    unsigned fin = 0u;
+    if constexpr (PP > 1) {
+        // ---- the parts of the slab exchange their (mean, M2): thread 0 publishes this part's word, threads q < PP fetch part q's (this
+        // part's own comes back from the registers: same bits), every thread merges the PP triples in part order (Chan et al.)
+        float* const pr = red + 3 * 4 * HV;   // [PP][2]
+        unsigned long long* const slots = a.peer_slots + (size_t)slab * PP;
+        if (tid == 0 && !chain_withhold(a.peer, vb)) chain_st64(slots + part, peer_word(mean, M2));   // (test setting: the launch's first workgroup withholds its word)
+        if (wv == 0) __builtin_amdgcn_wave_barrier();   // (no instruction: orders the publish before the polls for the compiler -- and for the emulator's fibers)
+        if (tid < PP) {
+            float pm = mean, pq = M2;
+            if (tid != part) {
+                const unsigned long long w = chain_poll_word(a.peer, slots + tid, (int)slab);
+                pm = peer_word_mean(w);
+                pq = w ? peer_word_m2(w) : __builtin_nanf("");   // a wait that gave up: NaN statistics -> NaN outputs of this part (and the sticky word)
+            }
+            pr[2 * tid] = pm;
+            pr[2 * tid + 1] = pq;
+        }
+        barrier_only();
+        // every poll of this workgroup is done: it counts as finished with the exchange words NOW (the reply is only looked at after the
+        // stores below: the atomic's round trip stays off the critical path)
+        if (tid == 0) fin = chain_add(a.peer.words + 1, 1u);
+        nn = 0.f; mean = 0.f; M2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            const int r0 = (q * alltiles / PP) << 4, r1 = ((q + 1) * alltiles / PP) << 4;
+            const float nw = (float)(((r1 < N ? r1 : N) - (r0 < N ? r0 : N)) * C2), mw = pr[2 * q], qw = pr[2 * q + 1];
+            if (nw > 0.f) {
+                const float d = mw - mean, nt2 = nn + nw;
+                mean += d * (nw / nt2);
+                M2 += qw + d * d * (nn * nw / nt2);
+                nn = nt2;
+            }
+        }
+    }
     const float rstd = 1.0f / sqrtf(M2 / nn + a.eps);
-    if (tid == 0) {
+    if (tid == 0 && part == 0) {
         a.mean[slab] = mean;
         a.rstd[slab] = rstd;
     }
     STGCN_PHASE(9, 4);
 #pragma unroll
     for (int j = 0; j < NTI; ++j) {
-        const int row = (hf + HV * j) * 16 + l15;
-        if (row < N) {
+        const int row = row0 + (hf + HV * j) * 16 + l15;
+        if (row < N && hf + HV * j < ntiles) {
             const size_t e = (size_t)row * C2 + c;
             const unsigned kb = ((NTI > 8 && j < 8) ? kbits2 : kbits) >> (4 * (j & 7));
             f32x4 o;
@@ -1261,10 +1349,24 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
         }
     }
     STGCN_PHASE(9, 5);
+    if constexpr (PP > 1) {
+        // the launch's last workgroup to finish its exchange zeroes the words, the ticket and the count: the next launch finds them clean
+        // (all threads of that workgroup take a word each: one thread's 2 * slabs dependent-issue stores were microseconds of kernel tail)
+        float* const lastw = red + 3 * 4 * HV + 2 * PP + 1;
+        if (tid == 0) *lastw = fin == a.peer.total - 1u ? 1.f : 0.f;
+        barrier_only();
+        if (*lastw != 0.f) {
+            for (int i = tid; i < a.peer.ncount; i += 256 * HV) chain_st64(a.peer_slots + i, 0ull);
+            if (tid == 0) {
+                chain_st(a.peer.words, 0u);
+                chain_st(a.peer.words + 1, 0u);
+            }
+        }
+    }
 }
-template <int C2, int KT, int NTI, int HV, typename ET>
+template <int C2, int KT, int NTI, int HV, int PP, typename ET>
 __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
-    tc2_ln_fwd_body<C2, KT, NTI, HV, ET>(a, (int)blockIdx.x, ChainCtl{nullptr, 0, 0u});
+    tc2_ln_fwd_body<C2, KT, NTI, HV, PP, ET>(a, (int)blockIdx.x, ChainCtl{nullptr, 0, 0u});
 }
 
 // ================================================================================================
@@ -1287,7 +1389,7 @@ __global__ __launch_bounds__(WITH_TC2 ? 1024 : 512) void stblock_fwd_chain_kerne
         if ((int)threadIdx.x >= gc_threads) return;
         gconv_fwd_body<1, 16, ET, 1>(a2, vb - n1, gc_threads, chain);
     } else {
-        if constexpr (WITH_TC2) tc2_ln_fwd_body<64, KT, NTI, 4, ET>(a3, vb - n1 - n2, chain);
+        if constexpr (WITH_TC2) tc2_ln_fwd_body<64, KT, NTI, 4, 1, ET>(a3, vb - n1 - n2, chain);
     }
     chain_exit(chain);
 }

@@ -235,7 +235,14 @@ class STConvBlock(nn.Module):
             offset = self._site + DropoutStream.CHAIN_STRIDE * ops.current_chain()   # static per block and chain; the device counter supplies the step
         else:
             offset = DropoutStream.next_offset() if training else 0
+        self._last_call = (int(x.shape[0]), int(x.shape[2]), x.dtype)      # (what chain_status needs to find the control words again)
         return ops.st_conv_block(x, gp, gt, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)
+
+    def chain_status(self) -> int:
+        """0, or 1 + the (b, t) slab whose LayerNorm statistics a workgroup of the last forward gave up waiting for (its outputs are NaN);
+        synchronises the stream (``ops.block_chain_status``)."""
+        last = getattr(self, "_last_call", None)
+        return 0 if last is None else ops.block_chain_status(self.cfg, last[0], last[1], self._ws, dtype=last[2])
 
 
 class OutputBlock(nn.Module):
@@ -271,4 +278,11 @@ class OutputBlock(nn.Module):
             offset = self._site + DropoutStream.CHAIN_STRIDE * ops.current_chain()
         else:
             offset = DropoutStream.next_offset() if training else 0
+        self._last_call = (int(x.shape[0]), int(x.shape[2]), x.dtype)
         return ops.output_block(x, self.cfg, self._params(), training, DropoutStream.seed, offset, self._ws, counter)
+
+    def chain_status(self) -> int:
+        """0, or 1 + the window whose row statistics a tile of the last forward gave up waiting for (its predictions are NaN);
+        synchronises the stream (``ops.head_chain_status``)."""
+        last = getattr(self, "_last_call", None)
+        return 0 if last is None else ops.head_chain_status(self.cfg, last[0], last[1], self._ws, dtype=last[2])

@@ -194,6 +194,12 @@ def set_tc1_bwd_wgs(n: int) -> int:
     return prev
 
 
+def set_tc2ln_peers(n: int) -> int:
+    """Workgroups per (b, t) slab of the fused tmp_conv2 + LayerNorm + dropout forward: 0 = by the device, 1 / 2 / 4 force a form
+    (test / tuning knob, ``stgcn_set_tc2ln_peers``); returns the previous value."""
+    return int(_lib.lib().dll.stgcn_set_tc2ln_peers(int(n)))
+
+
 def set_chain_spin_ticks(ticks: int) -> int:
     """Bound of one in-launch wait of the head's one-launch forward, in ticks of the device's 100 MHz clock (default 2 s); negative (test
     setting): bound |ticks| and the first tile of every launch withholds its arrival, so its peers' waits run out for certain.  0 only
@@ -799,6 +805,20 @@ class _OutBlockFn(torch.autograd.Function):
             ctx.wsc.pending_sink = sink
             grads = [None] * len(grads)
         return (dx, None, None, None, None, None, None, *grads)
+
+
+def block_chain_status(cfg: BlockConfig, B: int, T: int, wsc: WorkspaceCache, dtype=torch.float32) -> int:
+    """Sticky word of an ST block's forward (``stgcn_stblock_chain_status``): 0 if every in-launch wait of the last forward on ``wsc``
+    completed, else 1 + the (b, t) slab of tmp_conv2 + LayerNorm whose peer statistics a workgroup gave up waiting for (that part's outputs
+    are NaN).  Synchronises the current stream."""
+    L = _lib.lib()
+    ws = wsc.buf
+    if ws is None:
+        return 0
+    desc = make_desc(cfg, B, T, False, False, dtype=dtype)
+    w = C.c_uint32(0)
+    L.check(L.dll.stgcn_stblock_chain_status(C.byref(desc), ws.data_ptr(), C.byref(w), _stream_of(ws)), "stgcn_stblock_chain_status")
+    return int(w.value)
 
 
 def head_chain_status(cfg: HeadConfig, B: int, T: int, wsc: WorkspaceCache, dtype=torch.float32) -> int:

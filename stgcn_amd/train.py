@@ -195,6 +195,21 @@ def fwd_loss_bwd(model, x, y):
     return ops.mse_backward(y_pred, y)[0]
 
 
+def check_in_launch_waits(model) -> None:
+    """Raise if a fused operator's last forward had an in-launch wait that gave up (the tiles of a LayerNorm slab / window wait for each
+    other inside ONE launch; a wait is bounded, and a starved tile writes NaN and sets a sticky word instead of hanging the device).  The
+    NaN reaches the loss anyway -- this names the operator and the slab / window.  Synchronises the stream: call it where the loss is read
+    (once per epoch, after a timed loop), not inside the step."""
+    from .layers import OutputBlock, STConvBlock
+    for name, m in model.named_modules():
+        if isinstance(m, (STConvBlock, OutputBlock)):
+            w = m.chain_status()
+            if w:
+                what = "(b, t) slab" if isinstance(m, STConvBlock) else "window"
+                raise RuntimeError(f"{name or type(m).__name__}: an in-launch wait of the last forward gave up on {what} {w - 1} -- its outputs are NaN "
+                                   f"(the device was not this launch's alone for stgcn_set_chain_spin_ticks; the next weight pack re-arms the words)")
+
+
 def fused_tail_supported(model, live_params) -> bool:
     """The fused step tail (``GradSink`` / ``stgcn_grad_flush``) writes the gradient of every parameter OWNED BY A FUSED OPERATOR
     (``STConvBlock``, a supported ``OutputBlock``) and nothing else.  A live parameter outside of them (the two ``nn.Linear`` of the
@@ -506,6 +521,10 @@ class GraphedTrainStep:
         # still fall back to eager launches of the same kernels), not inside a timed loop
         self(x_example, y_example)
         torch.cuda.synchronize(dev)
+
+    def check(self) -> None:
+        """``check_in_launch_waits`` on the step's model (synchronises: for the places where the loss is read)."""
+        check_in_launch_waits(self.model)
 
     def close(self):
         """Undo the process-global state a captured step leaves behind (device dropout counter, step counters on the model's pack

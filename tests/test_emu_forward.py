@@ -112,3 +112,66 @@ def test_tc1_fwd_ranges_cut_inside_items(wgs):
         test_block_forward_stages(32, (64, 16, 64), 3, 1, "cheb_graph_conv", "gtu", 16, 1, 5)
     finally:
         ops.set_tc1_bwd_wgs(prev)
+
+
+PEER_CASES = [
+    (64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 130, 1, 6),     # 9 node tiles: 5 + 4 (PP = 2), 2 + 2 + 2 + 3 (PP = 4)
+    (16, (64, 16, 64), 2, 2, "cheb_graph_conv", "gtu", 150, 2, 5),     # 10 tiles, ragged last tile, two taps, GTU
+    (64, (64, 16, 64), 3, 2, "cheb_graph_conv", "glu", 300, 1, 5),     # 19 tiles: the instances of 257 .. 384 nodes (3 / 2 tiles per wave)
+]
+
+
+@pytest.mark.parametrize("pp", [1, 2, 4])
+@pytest.mark.parametrize("case", PEER_CASES)
+def test_tc2_ln_fwd_workgroups_per_slab(case, pp):
+    """tc2_ln_fwd_kernel with PP workgroups per (b, t) slab (``stgcn_set_tc2ln_peers``): slab and part from a start-order ticket, the parts'
+    LayerNorm statistics exchanged inside the launch and merged in part order -- every stage against the oracle, for every PP, and the
+    same bits launch after launch (the merge order is fixed)."""
+    bind_emulator()
+    prev = ops.set_tc2ln_peers(pp)
+    try:
+        test_block_forward_stages(*case)
+    finally:
+        ops.set_tc2ln_peers(prev)
+
+
+def tc2_ln_peer_give_up_case(dev):
+    """The bounded wait of the slab's parts (the head's ``head_wait_give_up_case`` for the ST block): with the test setting of the spin bound
+    the launch's first workgroup withholds its statistics word, the other parts of ITS slab give up, write NaN and set the sticky word
+    (1 + slab index); every other slab is untouched; the next forward is clean.  Shared by the emulator test and tests/test_gpu_block.py."""
+    N, B, T = 130, 2, 6
+    cfg, p = block_case(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", N, B, T)
+    bcfg = ops.BlockConfig(Kt=3, Ks=3, n_vertex=N, c_in=64, channels=(64, 16, 64), act_func="glu", graph_conv_type="cheb_graph_conv", droprate=0.5)
+    gp, gt = ops.gso_prepare(torch.from_numpy(nonsym_gso(N, 5)).to(dev), ops.graph_terms(bcfg))
+    params = [None if t is None else t.clone().to(dev) for t in params_in_field_order(p, "st_blocks.0.", "cheb_graph_conv")]
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((B, 64, T, N)).astype(np.float32)).to(dev)
+    wsc = ops.WorkspaceCache()
+    prev_pp = ops.set_tc2ln_peers(2)
+    try:
+        good = ops.st_conv_block(x, gp, gt, bcfg, params, False, 1, 0, wsc)
+        assert ops.block_chain_status(bcfg, B, T, wsc) == 0 and bool(torch.isfinite(good).all())
+        prev = ops.set_chain_spin_ticks(-2000)      # test setting: waits bounded by 20 us, the first workgroup withholds its word
+        try:
+            bad = ops.st_conv_block(x, gp, gt, bcfg, params, False, 1, 0, wsc)
+            word = ops.block_chain_status(bcfg, B, T, wsc)
+        finally:
+            ops.set_chain_spin_ticks(prev)
+        assert word == 1, word                                  # 1 + slab 0
+        # slab 0 = (b 0, t 0): part 0 (node tiles 0 .. 3, rows 0 .. 63) was normalised with its peer's real statistics, part 1 (rows 64 ..) gave up
+        nan = torch.isnan(bad)                                  # logical (B, C, T2, N)
+        assert bool(nan[0, :, 0, 64:].all()) and not bool(nan[0, :, 0, :64].any())
+        nan[0, :, 0, 64:] = False
+        assert not bool(nan.any())
+        keep = torch.ones_like(bad, dtype=torch.bool)
+        keep[0, :, 0, 64:] = False
+        assert torch.equal(bad[keep], good[keep])
+        again = ops.st_conv_block(x, gp, gt, bcfg, params, False, 1, 0, wsc)
+        assert ops.block_chain_status(bcfg, B, T, wsc) == 0 and torch.equal(again, good)
+    finally:
+        ops.set_tc2ln_peers(prev_pp)
+
+
+def test_tc2_ln_peer_wait_give_up_is_loud_and_not_sticky_across_launches():
+    bind_emulator()
+    tc2_ln_peer_give_up_case("cpu")
+

@@ -41,6 +41,21 @@ def test_c3_full_size_bf16(blk):
     assert_bf16_errors(*run_block_case_bf16("cuda:0", c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 325, 64, T, True, gso=gso))
 
 
+@pytest.mark.parametrize("pp", [2, 4])
+def test_c3_full_size_bf16_workgroups_per_slab(pp):
+    """tc2_ln_fwd_kernel with 2 / 4 workgroups per slab (``stgcn_set_tc2ln_peers``; C3's own launches run 1) on the bf16 instances at the
+    full C3 size, block 1."""
+    from stgcn_amd import ops
+    from tests.bf16_util import assert_bf16_errors, run_block_case_bf16
+    _bind()
+    gso = real_gso("pems_bay.cheb_sym_norm_lap")
+    prev = ops.set_tc2ln_peers(pp)
+    try:
+        assert_bf16_errors(*run_block_case_bf16("cuda:0", 64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 325, 64, 8, True, gso=gso))
+    finally:
+        ops.set_tc2ln_peers(prev)
+
+
 def test_c3_head_bf16():
     """The output head at the C3 size (B 64, N 325) with bf16 activations."""
     from tests.bf16_util import assert_bf16_errors, run_head_case_bf16

@@ -37,6 +37,47 @@ def test_c2_full_size(blk, training):
     assert_errors(run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, training, gso=gso))
 
 
+@pytest.mark.parametrize("blk", [0, 1])
+@pytest.mark.parametrize("pp", [1, 2, 4])
+def test_c2_full_size_every_workgroups_per_slab(blk, pp):
+    """tc2_ln_fwd_kernel with 1 / 2 / 4 workgroups per (b, t) slab (round 6, ``stgcn_set_tc2ln_peers``; by default block 1 of C2 runs 2, small
+    batches 4) at the full C2 size, training: every stage of the block against the fp64 stage oracle.  At PP = 4 block 0 is 1024 workgroups on
+    512 resident slots: parts wait for peers that only start when earlier workgroups end (the ticket order makes that safe)."""
+    from stgcn_amd import ops
+    from tests.gpu_util import assert_errors, bind_hip, run_block_case
+    bind_hip()
+    gso = real_gso("metr_la.cheb_sym_norm_lap")
+    c_in, T = ((1, 12), (64, 8))[blk]
+    prev = ops.set_tc2ln_peers(pp)
+    try:
+        assert_errors(run_block_case(c_in, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 207, 32, T, True, gso=gso))
+    finally:
+        ops.set_tc2ln_peers(prev)
+
+
+@pytest.mark.parametrize("pp", [2, 4])
+def test_c3_shapes_fp32_workgroups_per_slab(pp):
+    """The peer instances of 257 .. 384 nodes (3 / 2 node tiles per wave) at the C3 shapes: 325 nodes = 21 node tiles, bs 64, fp32."""
+    from stgcn_amd import ops
+    from tests.gpu_util import assert_errors, bind_hip, run_block_case
+    bind_hip()
+    gso = real_gso("pems_bay.cheb_sym_norm_lap")
+    prev = ops.set_tc2ln_peers(pp)
+    try:
+        assert_errors(run_block_case(64, (64, 16, 64), 3, 3, "cheb_graph_conv", "glu", 325, 64, 8, True, gso=gso))
+    finally:
+        ops.set_tc2ln_peers(prev)
+
+
+def test_tc2_ln_peer_wait_give_up_on_the_device():
+    """The bounded in-launch wait of a slab's parts on the hardware: NaN for the starved part only, the sticky word names the slab, the next
+    launch is clean and bitwise equal to the first (tests/test_emu_forward.py::tc2_ln_peer_give_up_case)."""
+    from tests.gpu_util import bind_hip
+    from tests.test_emu_forward import tc2_ln_peer_give_up_case
+    bind_hip()
+    tc2_ln_peer_give_up_case("cuda:0")
+
+
 def test_thin_first_layer_row_tile_kernels_on_the_device(monkeypatch):
     """STGCN_THIN=0: the thin first layer on the row-tile kernels of rounds 1 - 4 (still in the library as the A/B form of the round-5
     wave-per-tile kernels, which every other test of a 1-channel block runs): full C2 block 0 and a small K = 4 case."""

@@ -22,6 +22,8 @@ from tests.emu_util import block_case, params_in_field_order  # noqa: E402
 from tests.helpers import real_gso  # noqa: E402
 
 L = _lib.lib()
+if os.environ.get("STGCN_BENCH_TC2LN_PP"):
+    ops.set_tc2ln_peers(int(os.environ["STGCN_BENCH_TC2LN_PP"]))
 dev = "cuda:0"
 NAMES = {1: "tconv_fwd", 2: "tconv_bwd_data", 3: "tconv_bwd_weight", 4: "gconv_fwd", 6: "align_gate_bwd", 7: "tconv_fwd(tc2, v3)",
          8: "tc2_bwd", 9: "tc2_ln_fwd", 10: "tc1_bwd", 11: "tc1_fwd"}

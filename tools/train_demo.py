@@ -84,6 +84,7 @@ def main():
             acc += step()                       # loss stays on the device: no per-step host sync (main.py:170 does .item())
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        step.check()                            # (once per epoch, where the loss is read: names the operator if an in-launch wait gave up)
         sched.step()
         opt.sync_lr()                           # the captured AdamW reads its learning rate from device memory
         val_loss = data.evaluate_model(model, mse, val_s.batches(BS))
