@@ -250,9 +250,16 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* desc, const stgcn_stblock_pa
                           const float* gso_pad, float* y, float* saved, float* ws, uint64_t seed, uint64_t offset,
                           const uint64_t* offset_dev, void* stream);
 
-/* dy: (B, T2, N, c2); y: the output the matching forward wrote (read only when desc.dy_rowstats_ready == 0: the LayerNorm-backward row
- * partials are then formed from dy and y); dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the matching
- * forward call filled; seed/offset must be the forward's.                                            */
+/* dy: (B, T2, N, c2); y: the output the matching forward wrote; dx: (B, T, N, c_in) or NULL.  `saved`/`ws` must be the buffers the
+ * matching forward call filled; seed/offset must be the forward's.
+ * BIT-LEVEL CONTRACT ON y (training mode): y must be the forward's output buffer BIT FOR BIT -- the dropout mask travels in the sign of
+ * zero.  The forward stores a DROPPED element as -0.0 and a kept element whose LayerNorm output is an exact zero as +0.0, and the backward
+ * (and the stgcn_ln_hook epilogues of whichever operator consumes y) reads "dropped iff y is -0.0" instead of regenerating the Philox mask.
+ * A numerically equal copy whose -0.0 was canonicalised (y + 0.0, a recomputation, a serialisation round trip through text) makes every
+ * dropped element count as kept, without an error.  (bf16 outputs: a kept value below 2^-134 in magnitude rounds to -0.0 and counts as
+ * dropped -- its gradient contribution is below 2^-134 as well.)  Callers that cannot guarantee the bits run the library with
+ * STGCN_HOOK_MASK=philox in the environment: the mask is then regenerated from seed / offset (about 100 VALU instructions per 4 elements
+ * in the consumers' time steps).  y is also read for the LayerNorm-backward row partials when desc.dy_rowstats_ready == 0.            */
 int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_params* params, const float* x,
                            const float* gso_t_pad, const float* dy, const float* y, const float* saved, float* ws,
                            const stgcn_stblock_grads* grads, float* dx, uint64_t seed, uint64_t offset,
@@ -269,7 +276,8 @@ int stgcn_stblock_backward(const stgcn_stblock_desc* desc, const stgcn_stblock_p
  *      stgcn_*_backward.                                                                                                        */
 typedef struct stgcn_ln_hook {
     float* rowstat;            /* [B*T2*N][2] destination (inside the block's ws)                                     */
-    const float* y;            /* [B*T2*N][c2] the block's output (dtype below)                                       */
+    const float* y;            /* [B*T2*N][c2] the block's output (dtype below), BIT FOR BIT as the forward wrote it: in training
+                                  mode the dropout mask is read off it (dropped iff -0.0; see stgcn_stblock_backward)       */
     const float *gamma, *beta; /* tc2_ln.weight / .bias (N, c2)                                                       */
     int32_t N, C, reserved, training;
     float droprate;
@@ -358,9 +366,13 @@ int stgcn_outblock_forward(const stgcn_outblock_desc* desc, const stgcn_outblock
  * window counter it waited on), which stays until the next weight pack of this module re-arms the control words.  This call SYNCHRONISES
  * `stream` and returns that word (0: every wait of the last forward completed).  For tests and for callers that want more than the NaN loss. */
 int stgcn_outblock_chain_status(const stgcn_outblock_desc* desc, const float* ws, uint32_t* sticky, void* stream);
-/* Bound of one in-launch wait in ticks of the device's 100 MHz wall clock (default 200 000 000 = 2 s).  ticks < 0 is a TEST setting: the
- * bound is |ticks| and the first tile of every launch withholds its arrival, so that the waits of its window's other tiles run out for
- * certain (exercises the NaN / sticky-word path on the device); ticks == 0 only queries.  Returns the previous value.                  */
+/* Bound of one in-launch wait in ticks of the device's 100 MHz wall clock (default 200 000 000 = 2 s); ticks == 0 only queries.  Returns
+ * the previous value.  Process-global (an atomic word read at launch time): it applies to every later forward on any stream or thread.
+ * ticks < 0 is a TEST setting and must never be left in force: the bound is |ticks| and the first tile / workgroup of every launch that
+ * exchanges statistics withholds its arrival, so that its peers' waits run out for certain (the NaN / sticky-word path on the device) --
+ * every forward made under it produces NaN for those rows until the previous value is restored.
+ * The sticky words are zeroed by the weight pack that opens a forward (stgcn_prepack or the forward's own): a status read reports the
+ * LAST forward of that module only if it happens before the module's next forward.                                                      */
 int64_t stgcn_set_chain_spin_ticks(int64_t ticks);
 int stgcn_outblock_backward(const stgcn_outblock_desc* desc, const stgcn_outblock_params* params, const float* x,
                             const float* dout, const float* saved, float* ws, const stgcn_outblock_grads* grads, float* dx,

@@ -2,6 +2,7 @@
 // Declarations and the reference call sites each entry replaces: include/stgcn_hip.h.
 #include "../../include/stgcn_hip.h"
 
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,7 +27,7 @@ thread_local bool g_bf16 = false;
 // fits, so a graph-conv workgroup (73 VGPRs, ~5 per CU on its own) cannot start beside a tmp_conv1 workgroup at all and runs one per CU
 // afterwards.  The protocol itself is sound (0 wrong words in 600 launches of tools/ubench/chain_probe.hip, all GPU tests green with it).
 constexpr int kChainDefault = 0;   // (see fwd_chain_mode)
-long long g_chain_spin_ticks = kChainSpinTicks;   // bound of one in-launch wait (stgcn_set_chain_spin_ticks)
+std::atomic<long long> g_chain_spin_ticks{kChainSpinTicks};   // bound of one in-launch wait (stgcn_set_chain_spin_ticks; read at launch time by any thread)
 int g_gemm_big_nt = 0;   // stgcn_set_gemm_big_nt: forced column extent of the big bf16 operator GEMM's tiles (0 = heuristic)
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -36,11 +37,9 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // exact (round 4's "kept iff y != 0" lost a kept zero: ADVICE r4) -- or regenerated (Philox: ~100 VALU instructions per 4 elements in the
 // consumers' time steps; measured on C2 fp32, pass r5-01: tc2_bwd 29.1 + 21.1 -> 28.3 + 20.2 us, tc1_bwd 61.7 -> 60.1, step 0.3756 -> 0.3679 ms).
 // STGCN_HOOK_MASK=philox / y forces one (tests run both forms of both types).
-inline bool hook_mask_from_y(bool is_bf16) {
+inline bool hook_mask_from_y() {   // (the default is the same for fp32 and bf16 activations since round 5)
     const char* e = getenv("STGCN_HOOK_MASK");
     if (e && e[0] == 'p') return false;
-    if (e && e[0] == 'y') return true;
-    (void)is_bf16;
     return true;
 }
 int fail(int code, const char* fmt, ...) {
@@ -236,15 +235,10 @@ int check_desc(const stgcn_stblock_desc* d) {
     return STGCN_OK;
 }
 
-// The thin first layer (K = Kt * c_in <= 4) as wave-per-tile kernels (round 5, stgcn_kernels_thin.hip.h); STGCN_THIN=0 selects the row-tile
-// kernels of rounds 1 - 4 (A/B runs; the stage tests run both).  Read per call: the tests switch it.
-inline bool thin_wave_tiles() {
-    const char* e = getenv("STGCN_THIN");
-    return !(e && e[0] == '0');
-}
 // workgroups (4 waves) of the forward: two 16-row tiles per wave, at most four workgroups per CU
 inline int thin_fwd_wgs(int64_t rows) {
-    static const int tpw = getenv("STGCN_THIN_FWD_TPW") ? atoi(getenv("STGCN_THIN_FWD_TPW")) : 2;   // tiles per wave (sweep knob)
+    static const int tpw_env = STGCN_EXP_ENV("STGCN_THIN_FWD_TPW") ? atoi(STGCN_EXP_ENV("STGCN_THIN_FWD_TPW")) : 2;   // tiles per wave (sweep knob, experiments build)
+    const int tpw = tpw_env < 1 ? 1 : tpw_env;   // (0 or a non-numeric value used to divide by zero)
     const int64_t tiles = (rows + 15) / 16, want = (tiles + 4 * tpw - 1) / (4 * tpw), cap = 4L * device_cus();
     return (int)(want < 1 ? 1 : want < cap ? want : cap);
 }
@@ -440,7 +434,7 @@ inline bool tconv4_ok(const TconvFwdArgs& a) {
 // 18.6 to 20.4 us (its 256 KB weight stream per workgroup does not shrink with the tile) -- so the fc kernels default to 16 rows, the
 // conv / transposed conv to 32.  STGCN_HEAD_FC_TILE / STGCN_HEAD_TILE = 16 | 32 override.
 inline int head_tile_rows() {
-    static const int t = getenv("STGCN_HEAD_TILE") ? atoi(getenv("STGCN_HEAD_TILE")) : 32;
+    static const int t = STGCN_EXP_ENV("STGCN_HEAD_TILE") ? atoi(STGCN_EXP_ENV("STGCN_HEAD_TILE")) : 32;
     return t == 16 ? 16 : 32;
 }
 inline int head_fc_tile_rows() {
@@ -573,8 +567,8 @@ int launch_gso_gemm_bf16(const char* label, const float* Mpad, OperandBuf x, flo
     const int bk = force_bk == 32 || force_bk == 64 ? force_bk : kGbDefaultBK;
     const int split = g_gc_precision == 1 && !g_bf16;   // (bf16 activations: operands are bf16 numbers already, one MFMA per product)
     {   // 256 x (32 * NT) tiles, one workgroup per CU (gso_gemm_bf16_big_kernel); STGCN_GEMM_BIG=0: the 128 x 128 kernel
-        static const int off = getenv("STGCN_GEMM_BIG") ? atoi(getenv("STGCN_GEMM_BIG")) == 0 : 0;
-        static const int env_nt = getenv("STGCN_GEMM_BIG_NT") ? atoi(getenv("STGCN_GEMM_BIG_NT")) : 0;
+        static const int off = STGCN_EXP_ENV("STGCN_GEMM_BIG") ? atoi(STGCN_EXP_ENV("STGCN_GEMM_BIG")) == 0 : 0;
+        static const int env_nt = STGCN_EXP_ENV("STGCN_GEMM_BIG_NT") ? atoi(STGCN_EXP_ENV("STGCN_GEMM_BIG_NT")) : 0;
         const int force_nt = g_gemm_big_nt ? g_gemm_big_nt : env_nt;   // stgcn_set_gemm_big_nt (tests force every instance) before the environment
         static const int big_bk = getenv("STGCN_GEMM_BIG_BK") && atoi(getenv("STGCN_GEMM_BIG_BK")) == 32 ? 32 : 64;   // r3-17: 64-deep steps 6 % faster
         if (!off && !split && NP % kGbBigBM == 0) {
@@ -767,7 +761,7 @@ int launch_gconv_fwd(GconvFwdArgs a, hipStream_t st) {
     }
 #endif
     {   // bf16 activations: the operator products from the operator's bf16 fragment plane on 32-deep MFMAs (gconv_fwd_body B16P; STGCN_GC_B16P=0: the 16-deep form)
-        const char* e = getenv("STGCN_GC_B16P");
+        const char* e = STGCN_EXP_ENV("STGCN_GC_B16P");
         if (g_bf16 && a.Ks > 1 && g.maxq <= 2 && !(e && e[0] == '0')) {
             const size_t ldsp = gconv_fwd_b16p_lds_bytes(a.NP, a.N);
             if (g.maxq <= 1) STGCN_LAUNCH("gconv_fwd", st, (gconv_fwd_b16p_kernel<1, 16>), grid, blk, ldsp, a);
@@ -837,12 +831,12 @@ int launch_gconv_bwd(GconvBwdArgs a, hipStream_t st) {
     int pf = 0, pb = 1;
     gc_parts_override(pf, pb);
     {   // round 3: slab split over parts, parameter-gradient jobs on their own waves (gconv_bwd2_kernel); STGCN_GCBWD2=0: the one-workgroup-per-slab kernel
-        static const int off = getenv("STGCN_GCBWD2") ? atoi(getenv("STGCN_GCBWD2")) == 0 : 0;
+        static const int off = STGCN_EXP_ENV("STGCN_GCBWD2") ? atoi(STGCN_EXP_ENV("STGCN_GCBWD2")) == 0 : 0;
         const int force_parts = getenv("STGCN_GCBWD2_PARTS") ? atoi(getenv("STGCN_GCBWD2_PARTS")) : 0;   // (read per call: the tests force geometries)
         // One node tile per tile wave (<= 8 tile waves per workgroup), and the whole grid resident in ONE round: every part re-stages the
         // slab's dY and re-forms all G_k, so a grid of SEVERAL parts that needs more rounds than the slab kernel costs more than it returns
         // (measured at the C3 size, 640 slabs x 3 parts on 512 slots: 120 us against 76 us; at C2, 320 x 2 on 768 slots: 27.2 against 30.0 us).
-        const char* eb = getenv("STGCN_GC_B16P");
+        const char* eb = STGCN_EXP_ENV("STGCN_GC_B16P");
         const bool b16p = g_bf16 && a.Ks > 1 && !(eb && eb[0] == '0');   // bf16 activations: G_k as bf16 planes, products from the operator's bf16 plane (32-deep MFMAs)
         const size_t lds2 = gconv_bwd2_lds_bytes(a.NP, a.N, a.Ks, b16p);   // (G_k tiles + dY rows + the job waves' transposition tiles)
         if (!off && lds2 <= 150 * 1024 && HT <= 64) {
@@ -914,7 +908,7 @@ int launch_bwd_weight(const char* label, const TconvBwdWeightArgs& a, const Wgra
 
 // two independent weight gradients (the head's conv and fc1) in ONE launch when both take the <4 m-tiles> variants
 inline bool wgrad_pair_ok(const TconvBwdWeightArgs& a1, const WgradGeom& w1, const TconvBwdWeightArgs& a2, const WgradGeom& w2) {
-    static const int off = getenv("STGCN_WGRAD_PAIR") ? atoi(getenv("STGCN_WGRAD_PAIR")) == 0 : 0;   // A/B knob
+    static const int off = STGCN_EXP_ENV("STGCN_WGRAD_PAIR") ? atoi(STGCN_EXP_ENV("STGCN_WGRAD_PAIR")) == 0 : 0;   // A/B knob
     return !off && a1.NC == 256 && w1.MTW == 4 && a2.NC == 128 && w2.MTW == 4 && (a1.ts.C & 3) == 0 && (a2.ts.C & 3) == 0;
 }
 int launch_wgrad_pair(const char* label, const TconvBwdWeightArgs& a1, const WgradGeom& w1, const TconvBwdWeightArgs& a2, const WgradGeom& w2,
@@ -1020,7 +1014,7 @@ LnRowstatOut rowstat_out(const stgcn_ln_hook* h) {
     o.N = h->N; o.C = h->C; o.training = h->training && h->droprate > 0.f;
     o.keep_scale = 1.0f / (1.0f - h->droprate); o.thresh = drop_thresh(h->droprate); o.seed = h->seed; o.offset = h->offset;
     o.offset_dev = h->offset_dev;
-    o.mask_from_y = hook_mask_from_y(h->dtype == STGCN_DTYPE_BF16) ? 1 : 0;
+    o.mask_from_y = hook_mask_from_y() ? 1 : 0;
     return o;
 }
 }  // namespace
@@ -1137,9 +1131,8 @@ int stgcn_set_debug_stages(int32_t on) {
 }
 
 int64_t stgcn_set_chain_spin_ticks(int64_t ticks) {
-    const long long prev = g_chain_spin_ticks;
-    if (ticks != 0) g_chain_spin_ticks = ticks;
-    return prev;
+    if (ticks == 0) return g_chain_spin_ticks.load();
+    return g_chain_spin_ticks.exchange(ticks);
 }
 
 int stgcn_set_tc1_bwd_wgs(int32_t n) {
@@ -1442,7 +1435,7 @@ after_gconv:
         f.peer_slots = reinterpret_cast<unsigned long long*>(ws + pl.ws_chain + kChainHdr + 2 * v.slabs1);
         const dim3 grid((unsigned)(v.slabs2 * pp));
         // 16 waves (4 tile groups) when the grid leaves room for it: at most ~2 workgroups per CU (measured at C2: 25.8 -> ?? us)
-        static const int hv_force = getenv("STGCN_TC2LN_HV") ? atoi(getenv("STGCN_TC2LN_HV")) : 0;
+        static const int hv_force = STGCN_EXP_ENV("STGCN_TC2LN_HV") ? atoi(STGCN_EXP_ENV("STGCN_TC2LN_HV")) : 0;
         // (up to 384 nodes = 6 tiles per wave of a four-group workgroup: C3's 325-node slabs ran on 8 waves, one workgroup per CU, two rounds)
         // (the 6-tile form only for bf16 activations: with fp32 fragments it needs more than the 128 registers of a 16-wave workgroup)
         const bool wide = d->N <= (g_bf16 ? 384 : 256) && (hv_force ? hv_force == 4 : v.slabs2 <= 2L * device_cus());

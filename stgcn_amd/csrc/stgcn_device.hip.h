@@ -53,6 +53,14 @@ __device__ int stgcn_phase_kid;
 #define STGCN_ACC2_STORE(kid, i, cond) ((void)0)
 #endif
 
+// Tuning knobs whose A/B runs are over (each lost or tied at least twice, profiles/HISTORY_*): read from the environment only in
+// -DSTGCN_EXPERIMENTS builds; the product build compiles their defaults in (every live knob doubles a tested surface).
+#ifdef STGCN_EXPERIMENTS
+#define STGCN_EXP_ENV(name) getenv(name)
+#else
+#define STGCN_EXP_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace stgcn {
 
 constexpr int kThreads = 256;   // 4 waves per workgroup, one per SIMD

