@@ -392,7 +392,12 @@ int stgcn_outblock_backward_loss(const stgcn_outblock_desc* desc, const stgcn_ou
  *      head_desc may be NULL (no fused head).  Packs the backward-data operands regardless of need_dx.
  *      counters (nullable, <= 4): device-side int64 step counters advanced by this first launch of the step,
  *      *ptr = (*ptr + inc) % mod (mod 0: no wrap) -- the dropout stream position, the optimizer's step count (main.py:169) and the
- *      like ride on the pack launch instead of costing one tiny launch each inside a captured step.                    */
+ *      like ride on the pack launch instead of costing one tiny launch each inside a captured step.
+ *      Round 6: the call PARKS its job list (per host thread) instead of launching it; the next entry point of the library on that
+ *      thread launches it first -- except the forward of a block whose first layer is the thin one (Kt * c_in <= 4: STGCN's first block)
+ *      on the same stream with prepacked = 1, which sends pack and layer out as ONE launch.  Nothing changes for the caller as long as
+ *      the packed workspaces are only consumed through this library (they are its private layouts); a caller that reads `ws` itself, or
+ *      that ends a stream capture right after stgcn_prepack, must call any entry point (e.g. stgcn_stblock_chain_status) to flush.      */
 typedef struct stgcn_prepack_block {
     const stgcn_stblock_desc* desc;
     const stgcn_stblock_params* params;

@@ -362,6 +362,36 @@ int launch_pack(const stgcn_stblock_desc* d, const stgcn_stblock_params* P, cons
     return launch_pack_list("pack", L, st);
 }
 
+// ---- the model's weight pack rides on the first launch that follows it (round 6) ------------------------------------------------------
+// stgcn_prepack does not launch its (last) job list at once: it parks it here, and the next entry point decides.  If that is the forward of a
+// block whose first layer is the thin one (K = Kt * c_in <= 4: STGCN's first block), pack and layer go out as ONE launch
+// (pack_thin_fwd_kernel: 6.4 + 8.0 us and a kernel boundary -> ~9 us at C2); every other entry point launches the parked list first, as
+// stgcn_prepack used to (flush_pending_pack: called at the top of every entry that reads a workspace).  Per host thread.
+struct PendingPack {
+    bool valid = false;
+    PackList L;
+    hipStream_t st = nullptr;
+};
+thread_local PendingPack g_pending_pack;
+inline bool pack_fusion_on() {
+    static const int off = STGCN_EXP_ENV("STGCN_PACK_FUSE") ? atoi(STGCN_EXP_ENV("STGCN_PACK_FUSE")) == 0 : 0;   // (A/B knob, experiments build)
+    return !off;
+}
+int flush_pending_pack() {
+    if (!g_pending_pack.valid) return STGCN_OK;
+    g_pending_pack.valid = false;
+    const int tag = g_prof_tag;
+    g_prof_tag = 0;
+    const int rc = launch_pack_list("prepack", g_pending_pack.L, g_pending_pack.st);
+    g_prof_tag = tag;
+    return rc;
+}
+#define STGCN_FLUSH_PENDING_PACK()                     \
+    do {                                               \
+        const int rc_pp_ = flush_pending_pack();       \
+        if (rc_pp_) return rc_pp_;                     \
+    } while (0)
+
 int launch_ln_fwd(const char* label, LnFwdArgs ln, int64_t slabs, hipStream_t st) {
     const int n4 = ln.n / 4;
     ln.per = 1024;                                   // float4 columns per workgroup (4 per thread)
@@ -1258,6 +1288,7 @@ int stgcn_stblock_ln_hook(const stgcn_stblock_desc* d, const stgcn_stblock_param
 }
 
 int stgcn_stblock_chain_status(const stgcn_stblock_desc* d, const float* ws, uint32_t* sticky, void* stream) {
+    STGCN_FLUSH_PENDING_PACK();
     stgcn_stblock_plan pl;
     int rc = stgcn_stblock_plan_query(d, &pl);
     if (rc) return rc;
@@ -1286,6 +1317,12 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
     g_prof_tag = d->reserved;
     g_bf16 = d->dtype == STGCN_DTYPE_BF16;
 
+    // a parked model-level pack (stgcn_prepack): fused with this block's thin first layer when that is what comes next, else launched now
+    const bool thin_first = pl.thin_tc1 && thin_wave_tiles() &&
+                            !(!pl.recompute_tc1 && !d->x_bstride && !d->x_index_dev && tc1_fwd_shape_ok(d->c_in, d->c0, d->c1, d->Kt));
+    const bool fuse_pack = g_pending_pack.valid && d->prepacked && thin_first && g_pending_pack.st == st && pack_fusion_on() &&
+                           d->c0 == 64 && d->c1 == 16 && d->c_in < d->c0;
+    if (!fuse_pack) STGCN_FLUSH_PENDING_PACK();
     rc = d->prepacked ? STGCN_OK : launch_pack(d, P, pl, ws, st);
     if (rc) return rc;
 
@@ -1387,6 +1424,22 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         f.ts.src = x; f.ts.C = d->c_in; f.ts.taps = d->Kt; f.ts.N = d->N; f.ts.Tsrc = d->T; f.ts.Tdst = v.T1; f.ts.dir = 1; f.ts.rows = v.rows1;
         f.ts.bstride = d->x_bstride; f.ts.idx_dev = reinterpret_cast<const long*>(d->x_index_dev); f.ts.idx_stride = d->x_index_stride;
         f.Wd = ws + pl.ws_W1dense; f.bias = ws + pl.ws_b1; f.Wap = ws + pl.ws_Wap; f.ba = ws + pl.ws_ba; f.A = saved + pl.sv_A;
+        if (fuse_pack) {
+            // ONE launch: the layer (operands straight from the parameters) + the parked pack jobs (pack_thin_fwd_kernel)
+            f.native = 1; f.cw = P->tc1_w; f.cb = P->tc1_b; f.aw = P->al_w; f.ab = P->al_b;
+            PackList& PL = g_pending_pack.L;
+            PL.pa.njobs = PL.nj;
+            const int n_thin = thin_fwd_wgs(v.rows1);
+            PackSync sy{0, nullptr, 0u, 0, 0};
+            for (int k = 0; k < PL.pa.ncounters; ++k)
+                if (f.ts.idx_dev && PL.pa.cptr[k] == f.ts.idx_dev) {   // the window index of a captured step is one of the pack's counters
+                    sy.on = 1; sy.idx_ptr = f.ts.idx_dev; sy.expected = (unsigned)(4 * n_thin); sy.inc = PL.pa.cinc[k]; sy.mod = PL.pa.cmod[k];
+                }
+            g_pending_pack.valid = false;
+            const dim3 gridf((unsigned)(n_thin + PL.pa.start[PL.nj]));
+            if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (pack_thin_fwd_kernel<ET, 0>), gridf, dim3(256), 0, PL.pa, f, n_thin, sy);
+            else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (pack_thin_fwd_kernel<ET, 1>), gridf, dim3(256), 0, PL.pa, f, n_thin, sy);
+        } else
         if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (thin_tc1_fwd_kernel<ET, 0>), dim3(thin_fwd_wgs(v.rows1)), dim3(256), 0, f);
         else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (thin_tc1_fwd_kernel<ET, 1>), dim3(thin_fwd_wgs(v.rows1)), dim3(256), 0, f);
     } else

@@ -53,16 +53,46 @@ __device__ __forceinline__ float tconv_weff(const PackJob& j, int tap, int i, in
     return v;
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+// counts of first-layer waves that have read the window index in a launch shared with the pack role (PackSync, stgcn_kernels_thin.hip.h):
+// kPackSyncWords words 256 bytes apart -- device-scope atomics on ONE address retire at ~15 ns each on MI355X (2072 waves: 31 us, measured,
+// pass r6-12), on 32 addresses of different L2 channels the same reports take ~1 us.  Zero between launches (the pack role's counter wave
+// re-arms them).  One array per process: two models stepping CONCURRENTLY on different streams of one process would share it -- not a
+// configuration of this path (one process per GPU, one step at a time).
+constexpr int kPackSyncWords = 32, kPackSyncStride = 64;
+__device__ unsigned g_pack_readers[kPackSyncWords * kPackSyncStride];
+// bid = workgroup index within the pack role; sy: see PackSync (on == 0: a launch of its own)
+template <typename SY>
+__device__ __forceinline__ void pack_body(const PackArgs& a, const int bid, const SY& sy) {
+    if (bid == 0 && threadIdx.x < 64) {   // the counter wave
         for (int k = 0; k < a.ncounters; ++k) {
-            const long v = *a.cptr[k] + a.cinc[k];
-            *a.cptr[k] = a.cmod[k] > 0 ? v % a.cmod[k] : v;
+            if (sy.on && a.cptr[k] == sy.idx_ptr) {
+                // the first-layer role of this launch reads this counter: bump it only when all of its waves have the old value (bounded:
+                // 2 s of the 100 MHz wall clock -- a device that cannot start ~500 small workgroups in that time has other problems).
+                // Lane l < kPackSyncWords polls word l; the wave sums.
+                const int l = (int)threadIdx.x;
+                unsigned* const word = g_pack_readers + (l < kPackSyncWords ? l : 0) * kPackSyncStride;
+#if defined(__HIP_DEVICE_COMPILE__)
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    unsigned c = l < kPackSyncWords ? chain_ld(word) : 0u;
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+                    if (c >= sy.expected || wall_clock64() - t0 > kChainSpinTicks) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#endif
+                if (l < kPackSyncWords) chain_st(word, 0u);
+            }
+            if (threadIdx.x == 0) {
+                const long v = *a.cptr[k] + a.cinc[k];
+                *a.cptr[k] = a.cmod[k] > 0 ? v % a.cmod[k] : v;
+            }
         }
+    }
     int jb = 0;
-    while (jb + 1 < a.njobs && (int)blockIdx.x >= a.start[jb + 1]) ++jb;
+    while (jb + 1 < a.njobs && bid >= a.start[jb + 1]) ++jb;
     const PackJob& j = a.job[jb];
-    const int e = ((int)blockIdx.x - a.start[jb]) * kThreads + (int)threadIdx.x;
+    const int e = (bid - a.start[jb]) * kThreads + (int)threadIdx.x;
     if (e >= j.n) return;
     const int NC = j.gated ? 2 * j.Cout : j.Cout;
     float v = 0.f;
@@ -101,6 +131,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     }
     j.dst[e] = v;
 }
+struct PackNoSync { int on; const long* idx_ptr; unsigned expected; };
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) { pack_body(a, (int)blockIdx.x, PackNoSync{0, nullptr, 0u}); }
 
 // The graph shift operator is constant, so the Chebyshev polynomials T_k(L) (T_0 = I, T_1 = L, T_k = 2 L T_{k-1} - T_{k-2},
 // layers.py:153-161 applied to the operator instead of the activations) are formed ONCE per model and rewritten into MFMA

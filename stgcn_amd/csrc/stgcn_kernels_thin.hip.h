@@ -30,6 +30,16 @@ __device__ __forceinline__ size_t thin_row_base(const TapSrc& ts, long R, unsign
     return (size_t)b * xbs + rem;
 }
 
+// W_eff[k][o] of the thin layer from the reference's own parameter (what pack_kernel's PK_TCONV_DENSE writes, tconv_weff with C < 64: the
+// zero-padding Align adds the input channel to output channel o = ch of the P half at the last tap); k >= Kt * C: 0
+__device__ __forceinline__ float thin_weff(const float* cw, int C, int Kt, int k, int o) {
+    if (k >= Kt * C) return 0.f;
+    const int tap = k / C, ch = k - tap * C;
+    float v = cw[((size_t)o * C + ch) * Kt + tap];
+    if (tap == Kt - 1 && o == ch) v += 1.0f;   // (o < 64 always holds for o == ch < C <= 4)
+    return v;
+}
+
 // conv operands of the 8 output-channel tiles (P: 0..3, Q: 4..7) and the product itself, by storage type:
 //   float / f32x storage: exact fp32, one 4-deep MFMA per tile (lane group g holds tap g);  bf16: one 16-deep bf16 MFMA (group 0 holds all taps)
 template <typename ET> struct ThinConv {
@@ -37,6 +47,11 @@ template <typename ET> struct ThinConv {
     __device__ __forceinline__ void load(const float* Wd, int K, int g, int l15) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) w[mt] = g < K ? Wd[(size_t)g * 128 + 16 * mt + l15] : 0.f;
+    }
+    // the same operands straight from the reference's conv weight (128, C, Kt, 1): W_eff[k = tap * C + ch][o] (thin_weff)
+    __device__ __forceinline__ void load_native(const float* cw, int C, int Kt, int g, int l15) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) w[mt] = thin_weff(cw, C, Kt, g, 16 * mt + l15);
     }
     // xk: the K taps of this lane's row (zeros beyond K)
     __device__ __forceinline__ void run(const f32x4& xk, int g, f32x4 (&acc)[8]) const {
@@ -57,6 +72,15 @@ template <> struct ThinConv<bf16> {
             w[mt] = Mma<bf16>::cvt(v);
         }
     }
+    __device__ __forceinline__ void load_native(const float* cw, int C, int Kt, int g, int l15) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = thin_weff(cw, C, Kt, 4 * g + s, 16 * mt + l15);
+            w[mt] = Mma<bf16>::cvt(v);
+        }
+    }
     __device__ __forceinline__ void run(const f32x4& xk, int g, f32x4 (&acc)[8]) const {
         const Mma<bf16>::frag xb = Mma<bf16>::cvt(g == 0 ? xk : zero4());
 #pragma unroll
@@ -74,29 +98,63 @@ struct ThinFwdArgs {
     const float* Wap;    // PK_ALIGN_FWD fragments: K = 64 (4 chunks), 16 columns
     const float* ba;     // [16]
     float* A;            // [rows][16]
+    // native = 1 (round 6, the launch fused with the model's weight pack: pack_thin_fwd_kernel): the operands come straight from the
+    // reference's parameters -- nothing this kernel reads is written by the pack role of the same launch
+    int native;
+    const float* cw;     // tmp_conv1.causal_conv.weight (128, C, Kt, 1)
+    const float* cb;     // tmp_conv1.causal_conv.bias (128) or null
+    const float* aw;     // graph_conv.align.align_conv.weight (16, 64, 1, 1)
+    const float* ab;     // graph_conv.align.align_conv.bias (16) or null
+};
+// pack role and first-layer role of ONE launch share the window index of a captured step (TapSrc.idx_dev = one of the pack's step counters):
+// every first-layer wave reads the OLD index, forms old + inc itself and reports in; the pack role's counter thread bumps the word in place
+// once `expected` waves have reported in g_pack_readers (and re-arms the counts).  on == 0: not fused / no shared counter.
+struct PackSync {
+    int on;
+    const long* idx_ptr;
+    unsigned expected;
+    long inc, mod;
 };
 
+// vb / nb: index and count of the workgroups of this role (a launch of its own: blockIdx.x / gridDim.x)
 template <typename ET, int ACT>
-__global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
+__device__ __forceinline__ void thin_tc1_fwd_body(const ThinFwdArgs& a, const int vb, const int nb, const PackSync& sy) {
     typedef Mma<ET> MM;
     const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const long wave_id = (long)vb * 4 + (threadIdx.x >> 6), nwaves = (long)nb * 4;
     const long rows = a.ts.rows, tiles = (rows + 15) >> 4;
     const int K = a.ts.taps * a.ts.C, C = a.ts.C, N = a.ts.N;
     const unsigned per_b = (unsigned)(a.ts.Tdst * N);
     const size_t xbs = (size_t)tap_bstride(a.ts);
-    const ET* const xsrc = tap_base<ET>(a.ts);
+    const ET* xsrc = tap_base<ET>(a.ts);
+    if (sy.on && a.ts.idx_dev == sy.idx_ptr) {   // (uniform) the window index is bumped by the pack role of THIS launch: see PackSync
+        const long old = (long)chain_ld64(reinterpret_cast<const unsigned long long*>(a.ts.idx_dev));
+        chain_drain_stores();                       // (s_waitcnt vmcnt(0): the index has arrived before this wave reports in)
+        if (lane == 0) chain_add(g_pack_readers + (int)(wave_id & (kPackSyncWords - 1)) * kPackSyncStride, 1u);
+        const long v = old + sy.inc;
+        xsrc = et_ptr<ET>(a.ts.src) + (sy.mod > 0 ? v % sy.mod : v) * a.ts.idx_stride;
+    }
     ET* const A_ = et_ptr<ET>(a.A);
 
     ThinConv<ET> cw;
-    cw.load(a.Wd, K, g, l15);
     f32x4 bz[8];          // bias of the lane's channels 16 mt + 4 g + r, P then Q: the C operand of the conv
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) bz[mt] = ld4(a.bias + 16 * mt + 4 * g);
     typename MM::frag waf[4];   // Align: A[m = j = l15][k = c = 16 kc + 4 g + s] = Wa[c][j]
+    f32x4 ba4;
+    if (a.native) {       // (uniform) what pack_kernel writes for this layer, read off the parameters themselves
+        cw.load_native(a.cw, C, a.ts.taps, g, l15);
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) waf[kc] = MM::cvt(ld4(a.Wap + ((size_t)kc * 64 + lane) * 4));
-    const f32x4 ba4 = ld4(a.ba + 4 * g);
+        for (int mt = 0; mt < 8; ++mt) bz[mt] = a.cb ? ld4(a.cb + 16 * mt + 4 * g) : zero4();
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) waf[kc] = MM::cvt(ld4(a.aw + (size_t)l15 * 64 + 16 * kc + 4 * g));
+        ba4 = a.ab ? ld4(a.ab + 4 * g) : zero4();
+    } else {
+        cw.load(a.Wd, K, g, l15);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) bz[mt] = ld4(a.bias + 16 * mt + 4 * g);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) waf[kc] = MM::cvt(ld4(a.Wap + ((size_t)kc * 64 + lane) * 4));
+        ba4 = ld4(a.ba + 4 * g);
+    }
 
     // the K taps of row (tile, l15): scalar loads, raw, requested one tile ahead
     auto request = [&](long t, Raw1<ET> (&xr)[kThinTaps]) __attribute__((always_inline)) {
@@ -130,6 +188,21 @@ __global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
         const long R = t * 16 + l15;
         if (R < rows) stx4_wt(A_ + (size_t)R * 16 + 4 * g, out + ba4);   // D[m = j = 4 g + r][n = row]: 16 contiguous bytes
     }
+}
+
+template <typename ET, int ACT>
+__global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
+    thin_tc1_fwd_body<ET, ACT>(a, (int)blockIdx.x, (int)gridDim.x, PackSync{0, nullptr, 0u, 0, 0});
+}
+// The model's weight pack and the thin first layer of its first block as ONE launch (round 6): the two are independent once the layer
+// reads its operands off the parameters (ThinFwdArgs.native), both are latency chains on a mostly idle device (6.4 + 8.0 us at C2), and a
+// kernel boundary of their own costs another 1.8 us.  Workgroups [0, n_thin) run the layer, [n_thin, ..) the pack jobs (the layer first:
+// the pack role's counter thread waits for the layer's waves to have read the window index, PackSync -- and the CPU emulator, which runs
+// workgroups in index order, then finds them done).
+template <typename ET, int ACT>
+__global__ __launch_bounds__(256) void pack_thin_fwd_kernel(PackArgs p, ThinFwdArgs t, int n_thin, PackSync sy) {
+    if ((int)blockIdx.x < n_thin) thin_tc1_fwd_body<ET, ACT>(t, (int)blockIdx.x, n_thin, sy);   // (uniform per workgroup)
+    else pack_body(p, (int)blockIdx.x - n_thin, sy);
 }
 
 // ================================================================================================
