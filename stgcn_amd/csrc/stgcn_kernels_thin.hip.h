@@ -126,14 +126,6 @@ __device__ __forceinline__ void thin_tc1_fwd_body(const ThinFwdArgs& a, const in
     const int K = a.ts.taps * a.ts.C, C = a.ts.C, N = a.ts.N;
     const unsigned per_b = (unsigned)(a.ts.Tdst * N);
     const size_t xbs = (size_t)tap_bstride(a.ts);
-    const ET* xsrc = tap_base<ET>(a.ts);
-    if (sy.on && a.ts.idx_dev == sy.idx_ptr) {   // (uniform) the window index is bumped by the pack role of THIS launch: see PackSync
-        const long old = (long)chain_ld64(reinterpret_cast<const unsigned long long*>(a.ts.idx_dev));
-        chain_drain_stores();                       // (s_waitcnt vmcnt(0): the index has arrived before this wave reports in)
-        if (lane == 0) chain_add(g_pack_readers + (int)(wave_id & (kPackSyncWords - 1)) * kPackSyncStride, 1u);
-        const long v = old + sy.inc;
-        xsrc = et_ptr<ET>(a.ts.src) + (sy.mod > 0 ? v % sy.mod : v) * a.ts.idx_stride;
-    }
     ET* const A_ = et_ptr<ET>(a.A);
 
     ThinConv<ET> cw;
@@ -156,6 +148,16 @@ __device__ __forceinline__ void thin_tc1_fwd_body(const ThinFwdArgs& a, const in
         ba4 = ld4(a.ba + 4 * g);
     }
 
+    // (the operand loads above are in flight while the index arrives: one wait covers both)
+    const bool shared_idx = sy.on && a.ts.idx_dev == sy.idx_ptr;   // (uniform)
+    const ET* xsrc = shared_idx ? et_ptr<ET>(a.ts.src) : tap_base<ET>(a.ts);
+    if (shared_idx) {   // the window index is bumped by the pack role of THIS launch: see PackSync
+        const long old = (long)chain_ld64(reinterpret_cast<const unsigned long long*>(a.ts.idx_dev));
+        chain_drain_stores();                       // (s_waitcnt vmcnt(0): the index has arrived before this wave reports in)
+        if (lane == 0) chain_add(g_pack_readers + (int)(wave_id & (kPackSyncWords - 1)) * kPackSyncStride, 1u);
+        const long v = old + sy.inc;
+        xsrc = et_ptr<ET>(a.ts.src) + (sy.mod > 0 ? v % sy.mod : v) * a.ts.idx_stride;
+    }
     // the K taps of row (tile, l15): scalar loads, raw, requested one tile ahead
     auto request = [&](long t, Raw1<ET> (&xr)[kThinTaps]) __attribute__((always_inline)) {
         const long R0 = (t < tiles ? t : tiles - 1) * 16 + l15, R = R0 < rows ? R0 : rows - 1;
@@ -201,6 +203,10 @@ __global__ __launch_bounds__(256) void thin_tc1_fwd_kernel(ThinFwdArgs a) {
 // workgroups in index order, then finds them done).
 template <typename ET, int ACT>
 __global__ __launch_bounds__(256) void pack_thin_fwd_kernel(PackArgs p, ThinFwdArgs t, int n_thin, PackSync sy) {
+#ifdef STGCN_DIAG_FUSE   // (timing experiments only: 1 = the pack role returns at once, 2 = the layer role does)
+    if (STGCN_DIAG_FUSE == 1 && (int)blockIdx.x >= n_thin) return;
+    if (STGCN_DIAG_FUSE == 2 && (int)blockIdx.x < n_thin) return;
+#endif
     if ((int)blockIdx.x < n_thin) thin_tc1_fwd_body<ET, ACT>(t, (int)blockIdx.x, n_thin, sy);   // (uniform per workgroup)
     else pack_body(p, (int)blockIdx.x - n_thin, sy);
 }
