@@ -70,8 +70,9 @@ inline size_t tc2_bwd_lds_bytes(int C2, int Kt, int T1, int T2, bool recomp = tr
 // (profiles/r3-02_*): with fp32 products the CUs that hold two workgroups become MFMA-bound (C2: 27.3 -> 34.0 us, 18.2 -> 21.6 us per
 // launch, more than tc2_ln_fwd and the hooks gain), with bf16 products the step gains 5 % (C3: 0.790 -> 0.753 ms).  The host therefore
 // recomputes for bf16 activations and reads the stored gate inputs for fp32 (STGCN_TC2_RECOMP=0/1 overrides).
-// The matrix pipe and the VALU of a SIMD are separate: with one wave of each kind on it they run side by side, which a single wave
-// walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  The ring has a
+// With one wave of each kind on a SIMD the E wave's memory / LDS latencies are covered by the M wave's instructions and vice versa, which a single
+// wave walking E then M cannot do (phase stamps of the one-role version: 3.7 k cycles per step for 1.5 k cycles of MFMAs).  (Round 6, tools/ubench/overlap.hip:
+// the fp32 MFMA and the VALU of a SIMD do NOT execute side by side -- the gain is latency hiding, the SIMD's time is the sum of both streams.)  The ring has a
 // spare slot so that E(t + 1) never overwrites a tile M(t) still reads; ONE barrier per step.
 // (Round 5, pass r5-02: the C2 instance sat at exactly 128 VGPRs -- two workgroups per CU, which the launch geometry counts on -- and an
 //  unrelated edit moved it to 129: one workgroup per CU, two rounds, 26.0 + 18.0 -> 31.3 + 22.4 us.  The instances the stated configurations

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ long long run(int role, int iters, uint32_t& sink) {
     f32x4 acc[8];
     uint32_t x[8];
@@ -38,6 +40,21 @@ __device__ __forceinline__ long long run(int role, int iters, uint32_t& sink) {
             asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[(i + 3) & 7]) : "v"(0xD2511F53u));
         }
     }
+    if (role == 6) {   // back-to-back v_mfma_f32_16x16x16_bf16
+        s16x4 a4 = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80}, b4 = a4;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, acc[i], 0, 0, 0);
+        }
+    }
+    if (role == 7) {   // back-to-back v_mfma_f32_16x16x32_bf16
+        bf16x8 a8, b8;
+        for (int i = 0; i < 8; ++i) { a8[i] = (__bf16)1.0f; b8[i] = (__bf16)0.5f; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
+        }
+    }
     const long long t1 = clock64();
     f32x4 s = acc[0];
     for (int i = 1; i < 8; ++i) s += acc[i];
@@ -58,8 +75,8 @@ int main() {
     uint32_t* out; long long* cyc;
     hipMalloc(&out, 4 << 20); hipMalloc(&cyc, 256 * 16 * 8);
     const int iters = 2000;
-    const char* rn = "-MVTD5";
-    const int cases[][4] = {{1,0,0,0},{2,0,0,0},{4,0,0,0},{5,0,0,0},{2,2,0,0},{2,2,2,2},{1,1,0,0},{1,2,0,0},{1,3,0,0},{1,2,2,0},{1,2,2,2},{1,1,2,2},{5,5,0,0},{5,5,5,5},{3,3,3,3}};
+    const char* rn = "-MVTD5BW";   // B = bf16 16x16x16 MFMAs, W = bf16 16x16x32 MFMAs
+    const int cases[][4] = {{1,0,0,0},{2,0,0,0},{4,0,0,0},{5,0,0,0},{2,2,0,0},{2,2,2,2},{1,1,0,0},{1,2,0,0},{1,3,0,0},{1,2,2,0},{1,2,2,2},{1,1,2,2},{5,5,0,0},{5,5,5,5},{3,3,3,3},{6,0,0,0},{6,2,0,0},{6,2,2,2},{7,0,0,0},{7,2,0,0},{7,2,2,2},{6,6,0,0}};
     for (auto& c : cases) {
         int wps = 0; for (int i = 0; i < 4; ++i) if (c[i]) wps = i + 1;
         long long h[256 * 16];
