@@ -373,6 +373,11 @@ struct PendingPack {
     hipStream_t st = nullptr;
 };
 thread_local PendingPack g_pending_pack;
+// "bf16x6" product form of the fp32 blocks (Frag3, stgcn_device.hip.h): STGCN_MFMA_X6=1 (read per call: tests and A/B runs switch it)
+inline bool mfma_x6() {
+    const char* e = getenv("STGCN_MFMA_X6");
+    return e && e[0] == '1';
+}
 inline bool pack_fusion_on() {
     static const int off = STGCN_EXP_ENV("STGCN_PACK_FUSE") ? atoi(STGCN_EXP_ENV("STGCN_PACK_FUSE")) == 0 : 0;   // (A/B knob, experiments build)
     return !off;
@@ -1409,10 +1414,13 @@ int stgcn_stblock_forward(const stgcn_stblock_desc* d, const stgcn_stblock_param
         const long want = (long)device_cus() * fwd_per_cu;                                    // (stgcn_set_tc1_bwd_wgs overrides the CU count in tests)
         const long by_steps = items * (long)v.T1 / tc1_min_steps(), most = items > by_steps ? items : by_steps;   // (small batches: ranges cut inside items)
         const dim3 grid((unsigned)(most < want ? most : want)), blk(512);                     // equal (item, step) ranges, one workgroup per CU
-        const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt);
+        const bool x6 = mfma_x6() && !g_bf16;
+        const size_t lds = tc1_fwd_lds_bytes(d->c_in, d->Kt, x6);
 #define STGCN_TC1_FWD(CIN_)                                                                                   \
         do {                                                                                                  \
-            if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0, ET>), grid, blk, lds, f);   \
+            if (x6 && d->act == STGCN_ACT_GLU) STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_x6_kernel<64, CIN_, 3, 0>), grid, blk, lds, f);   \
+            else if (x6) STGCN_LAUNCH("tconv_fwd.tc1", st, (tc1_fwd_x6_kernel<64, CIN_, 3, 1>), grid, blk, lds, f);      \
+            else if (d->act == STGCN_ACT_GLU) STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 0, ET>), grid, blk, lds, f);   \
             else STGCN_LAUNCH_ET("tconv_fwd.tc1", st, (tc1_fwd_kernel<64, CIN_, 3, 1, ET>), grid, blk, lds, f);      \
         } while (0)
         if (d->c_in == 64) STGCN_TC1_FWD(64); else if (d->c_in == 32) STGCN_TC1_FWD(32); else STGCN_TC1_FWD(16);
@@ -1479,7 +1487,8 @@ after_gconv:
         f.T1 = v.T1; f.T2 = v.T2; f.N = d->N; f.NPR = (int)rup(d->N, 16); f.act = d->act; f.training = d->training && d->droprate > 0.f;
         f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
         f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;
-        const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N);
+        const bool x6 = mfma_x6() && !g_bf16 && d->N <= 256 && v.slabs2 <= 2L * device_cus();   // "bf16x6" products: the 16-wave forms of up to 256 nodes
+        const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N, x6);
         // workgroups per slab (round 6): a slab is one serial chain of ~15 us whatever the batch, so a launch that leaves compute units idle
         // (block 1 of C2: 128 slabs; every small batch) cuts the slab's node tiles over PP workgroups that exchange their statistics
         const int pp = tc2_ln_peers(d->N, v.slabs2);
@@ -1495,7 +1504,10 @@ after_gconv:
         const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (pp == 2 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 2, ET>), grid, dim3(1024), lds, f); \
+            if (x6 && pp == 2) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 2, 4, 2>), grid, dim3(1024), lds, f); \
+            else if (x6 && pp == 4) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 1, 4, 4>), grid, dim3(1024), lds, f); \
+            else if (x6 && wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 4, 4, 1>), grid, dim3(1024), lds, f); \
+            else if (pp == 2 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 2, ET>), grid, dim3(1024), lds, f); \
             else if (pp == 4 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 1, 4, 4, ET>), grid, dim3(1024), lds, f); \
             else if (pp == 2) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 3, 4, 2, ET>), grid, dim3(1024), lds, f); \
             else if (pp == 4) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 4, ET>), grid, dim3(1024), lds, f); \

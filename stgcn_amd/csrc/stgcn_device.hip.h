@@ -776,6 +776,62 @@ template <typename ET> __device__ __forceinline__ Raw4<ET> ldraw4_sc1(const ET* 
     return r;
 }
 
+// ---- "bf16x6": fp32-accurate matrix products on the bf16 matrix pipe (round 6) -----------------------------------------------------------
+// An fp32 value splits EXACTLY into three bf16 numbers, x = h + m + l (8 + 8 + 8 significand bits; each residual is exact in fp32).  A product
+// of two such values is 9 terms; the three smallest (m l, l m, l l: below 2^-32 of the product) are dropped, the other six are formed EXACTLY
+// by bf16 multiplies and accumulated in fp32 by the matrix pipe: the same 2^-24-per-product accuracy class as v_mfma_f32_16x16x4_f32, at
+// 3 x 17.5 cycles per 16-deep step instead of 4 x 32 -- and a bf16 MFMA does not exclude the SIMD's VALU (profiles/r6-01_valu_mfma_overlap.txt).
+// Two terms share one 32-deep instruction: slots 0..3 / 4..7 of a lane's operand hold a lane's 4 k values of two PLANES,
+//     (Ah|Al)(Bl|Bh) = Ah Bl + Al Bh ,  (Ah|Am)(Bm|Bm) = Ah Bm + Am Bm ,  (Ah|Am)(Bh|Bh) = Ah Bh + Am Bh      (small terms first).
+// Round 4's "bf16x6" split every streamed fragment at its CONSUMER and lost to the split's VALU time; here operands are split ONCE where
+// they are produced (stationary weights at kernel start, activation tiles when they are staged into LDS) and read back as planes.
+struct Frag3 { s16x4 h, m, l; };
+__device__ __forceinline__ Frag3 split3(f32x4 v) {
+    Frag3 f;
+    const u32x2_t hp = pack_bf16x4(v);
+    const f32x4 r1 = v - unpack_bf16x4(hp);
+    const u32x2_t mp = pack_bf16x4(r1);
+    const f32x4 r2 = r1 - unpack_bf16x4(mp);
+    f.h = __builtin_bit_cast(s16x4, hp);
+    f.m = __builtin_bit_cast(s16x4, mp);
+    f.l = __builtin_bit_cast(s16x4, pack_bf16x4(r2));
+    return f;
+}
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 cat8(s16x4 a, s16x4 b) {
+    const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ f32x4 mma3(const Frag3& a, const Frag3& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a.h, a.l), cat8(b.l, b.h), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a.h, a.m), cat8(b.m, b.m), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a.h, a.m), cat8(b.h, b.h), c, 0, 0, 0);
+}
+// two A operands against one B (P and Q half of a gated conv): the B-side operands are formed once
+__device__ __forceinline__ void mma3_a2(const Frag3& a0, const Frag3& a1, const Frag3& b, f32x4& c0, f32x4& c1) {
+    const bf16x8 blh = cat8(b.l, b.h), bmm = cat8(b.m, b.m), bhh = cat8(b.h, b.h);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a0.h, a0.l), blh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a1.h, a1.l), blh, c1, 0, 0, 0);
+    const bf16x8 a0hm = cat8(a0.h, a0.m), a1hm = cat8(a1.h, a1.m);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0hm, bmm, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1hm, bmm, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0hm, bhh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1hm, bhh, c1, 0, 0, 0);
+}
+// one plane triple of 4 consecutive k values in LDS: planes `pstride` shorts apart, 8-byte accesses
+__device__ __forceinline__ void st_frag3(short* p, int pstride, const Frag3& f) {
+    *reinterpret_cast<s16x4*>(p) = f.h;
+    *reinterpret_cast<s16x4*>(p + pstride) = f.m;
+    *reinterpret_cast<s16x4*>(p + 2 * pstride) = f.l;
+}
+__device__ __forceinline__ Frag3 ld_frag3(const short* p, int pstride) {
+    Frag3 f;
+    f.h = *reinterpret_cast<const s16x4*>(p);
+    f.m = *reinterpret_cast<const s16x4*>(p + pstride);
+    f.l = *reinterpret_cast<const s16x4*>(p + 2 * pstride);
+    return f;
+}
+
 // ---- block-wide sum of two values (256 threads) ----------------------------------------------
 // red must point to >= 8 floats of LDS.  All threads must call.
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {

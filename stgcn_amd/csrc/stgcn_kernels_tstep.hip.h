@@ -450,8 +450,13 @@ struct Tc1BwdArgs {
     LnRowstatOut rs;          // hook: row partials of the LayerNorm in front of x (rs.rowstat == null: none)
     int B, T, T1, N, node_tiles;
 };
-inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt) {
-    return ((size_t)(Kt + 1) * 16 * (2 * C0 + 4) + (size_t)(Kt + 1) * CIN * 20 + (size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4)) * sizeof(float);
+inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt, bool x6 = false) {
+    // x tiles (transposed): fp32 [CIN][20], or (X6) three bf16 planes [CIN][20] in the same place (15 instead of 10 floats' worth per row)
+    const size_t xt = x6 ? (size_t)(Kt + 1) * 3 * CIN * 20 * sizeof(short) : (size_t)(Kt + 1) * CIN * 20 * sizeof(float);
+    const size_t zt = x6 ? (size_t)(Kt + 1) * 3 * 16 * (2 * C0 + 8) * sizeof(short) : (size_t)(Kt + 1) * 16 * (2 * C0 + 4) * sizeof(float);   // dZ1 tiles: fp32, or three bf16 planes
+    const size_t rest = ((size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4)) * sizeof(float);
+    // X6: + the low plane of the transposed conv's stationary weights (4 waves x Kt * 2 C0 / 16 fragments x 64 lanes x 8 bytes; hi / mid stay in registers)
+    return zt + xt + rest + (x6 ? (size_t)4 * Kt * (2 * C0 / 16) * 64 * 4 * sizeof(short) : 0);
 }
 inline int tc1_bwd_part_floats(int C0, int CIN, int Kt) { return Kt * CIN * 2 * C0 + 2 * C0 + C0 * 16 + 16; }
 
@@ -464,9 +469,14 @@ __host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CI
     return w;
 }
 
-template <int C0, int CIN, int KT, int ACT, typename ET>
-__global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
+// X6 (round 6, fp32 blocks): the weight-gradient and transposed-conv products (Mw and Md waves) as "bf16x6" -- fp32-accurate
+// products on the bf16 matrix pipe (Frag3, stgcn_device.hip.h).  Both operands are tiles the E waves produce: x tiles (staged once, read
+// by four waves for KT steps) and dZ1 tiles (formed once); E splits them into three bf16 planes where it writes them.  The transposed conv
+// (Md waves) keeps its fp32 MFMAs: its 24 stationary weight fragments would be 144 registers as plane triples.
+template <int C0, int CIN, int KT, int ACT, typename ET, bool X6 = false>
+__device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    static_assert(!X6 || std::is_same<ET, float>::value, "bf16x6 is a product form of the fp32 blocks");
     typedef Mma<ET> MM;
     const ET* const dA_ = et_ptr<ET>(a.dA);
     const ET* const U_ = et_ptr<ET>(a.U);
@@ -477,10 +487,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     constexpr int NC = 2 * C0, LDZ = NC + 4, RING = KT + 1, LDX = 20, LDH = C0 + 4, LDO = CIN + 4, MI = CIN / 16, QD = NC / 16;
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
-    float* const XT = Zt + RING * 16 * LDZ;            // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row])
-    float* const dAe = XT + RING * CIN * LDX;          // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
+    constexpr int LDZH = NC + 8, ZPL = 16 * LDZH, LDXH = 20, XPL = CIN * LDXH;   // (X6) plane row / plane strides in shorts
+    float* const XT = Zt + (X6 ? RING * 3 * ZPL / 2 : RING * 16 * LDZ);   // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row]); X6: three bf16 planes of them instead (XTh)
+    float* const dAe = XT + (X6 ? RING * 3 * CIN * 20 / 2 : RING * CIN * LDX);   // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
     float* const Ht = dAe + RING * 16 * 16;            // [2][16][LDH]      H = act(U) * S tiles (owned tiles only)
     float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
+    short* const Zh = reinterpret_cast<short*>(Zt);                  // (X6) [RING][3][16][LDZH]   bf16 planes of the dZ1 tiles (instead of the fp32 tiles)
+    short* const XTh = reinterpret_cast<short*>(XT);                 // (X6) [RING][3][CIN][LDXH]  bf16 planes of the transposed x tiles
+    short* const Wl = reinterpret_cast<short*>(Xo + 2 * 16 * LDO);   // (X6) [4 waves][KT * QD][64 lanes][4]  low plane of the Md waves' stationary weights
     const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int N = a.N, T = a.T, T1 = a.T1;
@@ -555,9 +569,20 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
             auto put_x = [&](int xt, const Raw4<ET>& raw) {
                 const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
                 if (cq < CIN / 4) {
-                    float* d = XT + (size_t)(xt % RING) * CIN * LDX + (4 * cq) * LDX + r;
+                    if constexpr (X6) {   // three bf16 planes, transposed like XT (the weight-gradient waves read 4 consecutive rows of a channel: 8 bytes)
+                        const Frag3 f = split3(v);
+                        short* d = XTh + (size_t)(xt % RING) * 3 * XPL + (4 * cq) * LDXH + r;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) d[e * LDX] = v[e];
+                        for (int e = 0; e < 4; ++e) {
+                            d[e * LDXH] = f.h[e];
+                            d[XPL + e * LDXH] = f.m[e];
+                            d[2 * XPL + e * LDXH] = f.l[e];
+                        }
+                    } else {
+                        float* d = XT + (size_t)(xt % RING) * CIN * LDX + (4 * cq) * LDX + r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e * LDX] = v[e];
+                    }
                 }
             };
             // E(t): dH = dA Wa^T, gate backward, dZ1 tile -> ring; owned tiles (t >= sb) also leave their H tile for the Align gradient and
@@ -575,9 +600,15 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     dq[i] = dq_;
                     h[i] = gate_fwd(tu[i], tsv[i], ACT);
                 }
-                float* const Zs = Zt + (t % RING) * 16 * LDZ + er * LDZ;
-                st4(Zs + 4 * ecq, du);
-                st4(Zs + C0 + 4 * ecq, dq);
+                if constexpr (X6) {   // the tile as three bf16 planes: split ONCE, where it is formed
+                    short* const Zp = Zh + (size_t)(t % RING) * 3 * ZPL + er * LDZH;
+                    st_frag3(Zp + 4 * ecq, ZPL, split3(du));
+                    st_frag3(Zp + C0 + 4 * ecq, ZPL, split3(dq));
+                } else {
+                    float* const Zs = Zt + (t % RING) * 16 * LDZ + er * LDZ;
+                    st4(Zs + 4 * ecq, du);
+                    st4(Zs + C0 + 4 * ecq, dq);
+                }
                 if (t >= sb) {                         // uniform
                     dbu += du;
                     dbq += dq;
@@ -765,6 +796,35 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                 __syncthreads();   // (B)
                 STGCN_ACC_BEGIN();
                 if (i < T1) {
+                  if constexpr (X6) {
+                    // B[k = row 4g + s][n = o]: the lane's 4 rows of one column, gathered from each plane (2-byte reads)
+                    const short* const Zp = Zh + (size_t)(i % RING) * 3 * ZPL + (4 * g) * LDZH + (2 * w) * 16 + l15;
+                    Frag3 fz0, fz1;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        fz0.h[s] = Zp[s * LDZH]; fz0.m[s] = Zp[ZPL + s * LDZH]; fz0.l[s] = Zp[2 * ZPL + s * LDZH];
+                        fz1.h[s] = Zp[s * LDZH + 16]; fz1.m[s] = Zp[ZPL + s * LDZH + 16]; fz1.l[s] = Zp[2 * ZPL + s * LDZH + 16];
+                    }
+                    const bf16x8 z0lh = cat8(fz0.l, fz0.h), z0mm = cat8(fz0.m, fz0.m), z0hh = cat8(fz0.h, fz0.h);
+                    const bf16x8 z1lh = cat8(fz1.l, fz1.h), z1mm = cat8(fz1.m, fz1.m), z1hh = cat8(fz1.h, fz1.h);
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const short* xt = XTh + (size_t)((i + k) % RING) * 3 * XPL + l15 * LDXH + 4 * g;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {   // A[m = ch][k = row]
+                            const Frag3 fa = ld_frag3(xt + mi * 16 * LDXH, XPL);
+                            const bf16x8 ahl = cat8(fa.h, fa.l), ahm = cat8(fa.h, fa.m);
+                            f32x4& c0 = accw[k * MI + mi][0];
+                            f32x4& c1 = accw[k * MI + mi][1];
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl, z0lh, c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl, z1lh, c1, 0, 0, 0);
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, z0mm, c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, z1mm, c1, 0, 0, 0);
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, z0hh, c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahm, z1hh, c1, 0, 0, 0);
+                        }
+                    }
+                  } else {
                     const float* const Zs = Zt + (i % RING) * 16 * LDZ;
                     f32x4 bz[2];
 #pragma unroll
@@ -780,6 +840,7 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                         for (int mi = 0; mi < MI; ++mi)   // A[m = ch][k = row]
                             MM::mma_b2(MM::cvt(ld4(xt + mi * 16 * LDX)), fz0, fz1, accw[k * MI + mi][0], accw[k * MI + mi][1]);
                     }
+                  }
                     // dWa[i0 = 16w + ..][j] += H^T dA : A[m = ch][k = row] = Ht[row][16w + l15], B[k = row][n = j] = dA[row][j]
                     const float* hh = Ht + (i & 1) * 16 * LDH + (4 * g) * LDH + 16 * w + l15;
                     const float* dd = dAe + (i % RING) * 256 + (4 * g) * 16 + l15;
@@ -803,12 +864,22 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
     } else {
         // =========================================== Md waves: transposed conv ===========================================
         // wave w < MI owns input channels 16w .. 16w+15: A[m = ci][k = o] = W_eff1[(tap, ci)][o], the whole K = KT * NC in registers
-        typename MM::frag Wr[KT][QD];
+        typename MM::frag Wr[X6 ? 1 : KT][X6 ? 1 : QD];
+        s16x8 Whm[X6 ? KT : 1][X6 ? QD : 1];   // (X6) hi | mid planes in registers (one 32-deep A operand as is), the low plane in this wave's LDS region
+        short* const Wlw = Wl + (size_t)w * KT * QD * 256 + lane * 4;
 #pragma unroll
         for (int k = 0; k < KT; ++k)
 #pragma unroll
-            for (int q = 0; q < QD; ++q)
-                Wr[k][q] = MM::cvt(w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4());
+            for (int q = 0; q < QD; ++q) {
+                const f32x4 wv = w < MI ? ld4(a.Wd + (size_t)(k * CIN + 16 * w + l15) * NC + 16 * q + 4 * g) : zero4();
+                if constexpr (X6) {
+                    const Frag3 f = split3(wv);
+                    Whm[k][q] = s16x8{f.h[0], f.h[1], f.h[2], f.h[3], f.m[0], f.m[1], f.m[2], f.m[3]};
+                    *reinterpret_cast<s16x4*>(Wlw + (k * QD + q) * 256) = f.l;   // (wave-private, lane-linear: read back by the same lane)
+                } else {
+                    Wr[k][q] = MM::cvt(wv);
+                }
+            }
         STGCN_ACC_DECL();
         for (long item = item0; item <= item1 && item < items; ++item) {
             const int sb = item == item0 ? s0 : 0, se = item == item1 ? s1 : T;
@@ -823,11 +894,30 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
                     for (int k = 0; k < KT; ++k) {
                         const int ts = i - k;
                         if (ts >= 0 && ts < T1) {   // uniform
+                          if constexpr (X6) {
+                            const short* zr = Zh + (size_t)(ts % RING) * 3 * ZPL + l15 * LDZH + 4 * g;
+#pragma unroll
+                            for (int q = 0; q < QD; ++q) {   // B[k = o][n = row]; two independent accumulator chains
+                                // (Ah|Al)(Bl|Bh) + (Ah|Am)(Bm|Bh) + (Ah|Am)(Bh|Bm) = the six products; the B operands are read from the planes in the
+                                // order each instruction wants them (8-byte reads into neighbouring registers: no copies), A = Whm as it stands
+                                const s16x4 bh = *reinterpret_cast<const s16x4*>(zr + 16 * q), bm = *reinterpret_cast<const s16x4*>(zr + 16 * q + ZPL);
+                                const s16x4 bl = *reinterpret_cast<const s16x4*>(zr + 16 * q + 2 * ZPL);
+                                const s16x4 wl = *reinterpret_cast<const s16x4*>(Wlw + (k * QD + q) * 256);
+                                const s16x8 whm = Whm[k][q];
+                                const s16x8 whl = {whm[0], whm[1], whm[2], whm[3], wl[0], wl[1], wl[2], wl[3]};
+                                f32x4& c = accd[q & 1];
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whl), cat8(bl, bh), c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), cat8(bm, bh), c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), cat8(bh, bm), c, 0, 0, 0);
+                                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // (bounds the live range of the operand temporaries: 24 unrolled fragments spilled)
+                            }
+                          } else {
                             const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + 4 * g;
 #pragma unroll
                             for (int q = 0; q < QD; ++q) {
                                 MM::mma_split(Wr[k][q], MM::cvt(ld4(zr + 16 * q)), accd[0], accd[1]);   // B[k = o][n = row]
                             }
+                          }
                         }
                     }
                     st4(Xo + (i & 1) * 16 * LDO + l15 * LDO + 16 * w + 4 * g, accd[0] + accd[1]);   // D[m = ci = 16w + 4g + r][n = row]
@@ -840,6 +930,14 @@ __global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
         __syncthreads();           // (D)
         __syncthreads();           // (E)
     }
+}
+template <int C0, int CIN, int KT, int ACT, typename ET>
+__global__ __launch_bounds__(768) void tc1_bwd_kernel(Tc1BwdArgs a) {
+    tc1_bwd_body<C0, CIN, KT, ACT, ET>(a);
+}
+template <int C0, int CIN, int KT, int ACT>
+__global__ __launch_bounds__(768) void tc1_bwd_x6_kernel(Tc1BwdArgs a) {
+    tc1_bwd_body<C0, CIN, KT, ACT, float, true>(a);
 }
 
 // ================================================================================================
@@ -867,13 +965,22 @@ struct Tc1FwdArgs {
     int B, T, T1, N, node_tiles;
     int chain_out;            // chained launch: counter chain_out + b * T1 + t counts the node tiles of A[b][t] written (-1: none)
 };
-inline size_t tc1_fwd_lds_bytes(int CIN, int Kt) { return ((size_t)(Kt + 1) * 16 * (CIN + 8) + 2 * 4 * 16 * 20) * sizeof(float); }
+inline size_t tc1_fwd_lds_bytes(int CIN, int Kt, bool x6 = false) {
+    // x tiles: fp32 rows, or (X6) three bf16 planes per tile; then the partial Align tiles
+    const size_t ring = x6 ? (size_t)(Kt + 1) * 3 * 16 * (CIN + 4) * sizeof(short) : (size_t)(Kt + 1) * 16 * (CIN + 8) * sizeof(float);
+    return ring + (size_t)2 * 4 * 16 * 20 * sizeof(float);
+}
 
 // bid / nb: this workgroup's index among the nb workgroups of the role (the kernel's own grid, or the role's share of a chained launch);
 // chain.words != null: every A tile is published on counter chain_out + b * T1 + t (node_tiles arrivals complete a slab)
-template <int C0, int CIN, int KT, int ACT, typename ET>
+// X6 (round 6, fp32 blocks only): the conv product as "bf16x6" -- fp32-accurate products on the bf16 matrix pipe (Frag3, stgcn_device.hip.h).
+// The E waves split every x tile into three bf16 planes when they stage it (once per tile: it then serves KT taps of four M waves); the M
+// waves split their stationary weights once; the product loop reads plane triples and issues 3 x v_mfma_f32_16x16x32_bf16 per 16-deep step
+// instead of 4 x v_mfma_f32_16x16x4_f32, with no conversion in the loop.  The small Align product stays on fp32 MFMAs.
+template <int C0, int CIN, int KT, int ACT, typename ET, bool X6 = false>
 __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid, const int nb, const ChainCtl& chain) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
+    static_assert(!X6 || std::is_same<ET, float>::value, "bf16x6 is a product form of the fp32 blocks");
     typedef Mma<ET> MM;
     const ET* const x_ = et_ptr<ET>(a.x);
     ET* const U_ = et_ptr<ET>(a.U);
@@ -881,8 +988,10 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
     ET* const A_ = et_ptr<ET>(a.A);
     constexpr int RING = KT + 1, LDXS = CIN + 8, CC = CIN / 16, KCH = KT * CC, MT = C0 / 16, RED = 4 * 16 * 20;
     extern __shared__ float stgcn_smem[];
+    constexpr int LDH = CIN + 4, PST = 16 * LDH, SLOT3 = 3 * PST;   // (X6) row stride / plane stride / ring-slot stride in shorts
     float* const Xs = stgcn_smem;                      // [RING][16][LDXS]  x tiles, row major
-    float* const red = Xs + RING * 16 * LDXS;          // [2][4 waves][16 rows][20]  partial Align tiles, double buffered
+    short* const Xh = reinterpret_cast<short*>(stgcn_smem);   // (X6) [RING][3 planes][16][LDH] bf16
+    float* const red = X6 ? reinterpret_cast<float*>(Xh + RING * SLOT3) : Xs + RING * 16 * LDXS;   // [2][4 waves][16 rows][20]  partial Align tiles, double buffered
     const bool roleM = threadIdx.x < 256;              // wave-uniform
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int N = a.N, T = a.T, T1 = a.T1;
@@ -899,11 +1008,18 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
 
     if (roleM) {
         // stationary weights: A[m = o][k] fragments of o-tiles w (P half) and w + MT (Q half)
-        typename MM::frag wP[KCH], wQ[KCH];
+        typename MM::frag wP[X6 ? 1 : KCH], wQ[X6 ? 1 : KCH];
+        Frag3 wP3[X6 ? KCH : 1], wQ3[X6 ? KCH : 1];
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) {
-            wP[kc] = MM::cvt(ld4(a.Wp + ((size_t)(w * KCH + kc) * 64 + lane) * 4));
-            wQ[kc] = MM::cvt(ld4(a.Wp + ((size_t)((w + MT) * KCH + kc) * 64 + lane) * 4));
+            const f32x4 vp = ld4(a.Wp + ((size_t)(w * KCH + kc) * 64 + lane) * 4), vq = ld4(a.Wp + ((size_t)((w + MT) * KCH + kc) * 64 + lane) * 4);
+            if constexpr (X6) {
+                wP3[kc] = split3(vp);
+                wQ3[kc] = split3(vq);
+            } else {
+                wP[kc] = MM::cvt(vp);
+                wQ[kc] = MM::cvt(vq);
+            }
         }
         const int c = 16 * w + 4 * g;                  // this lane's 4 channels
         const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C0 + c);
@@ -934,7 +1050,8 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
                 for (int kc = 0; kc < KCH; ++kc) {
                     const int tap = kc / CC, cc = kc % CC;
                     // B[k = ci][n = row]
-                    MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g)), accP, accQ);
+                    if constexpr (X6) mma3_a2(wP3[kc], wQ3[kc], ld_frag3(Xh + (size_t)((i + tap) % RING) * SLOT3 + l15 * LDH + cc * 16 + 4 * g, PST), accP, accQ);
+                    else MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Xs + (size_t)((i + tap) % RING) * 16 * LDXS + l15 * LDXS + cc * 16 + 4 * g)), accP, accQ);
                 }
 #ifdef STGCN_PHASE_TIMING
                 __builtin_amdgcn_sched_barrier(0);
@@ -996,7 +1113,11 @@ __device__ __forceinline__ void tc1_fwd_body(const Tc1FwdArgs& a, const int bid,
             };
             auto put_x = [&](int xt, const Raw4<ET>& raw) {
                 const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
-                if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);
+                if constexpr (X6) {
+                    if (cq < CIN / 4) st_frag3(Xh + (size_t)(xt % RING) * SLOT3 + r * LDH + 4 * cq, PST, split3(v));   // split ONCE, where the tile is staged
+                } else {
+                    if (cq < CIN / 4) st4(Xs + (size_t)(xt % RING) * 16 * LDXS + r * LDXS + 4 * cq, v);
+                }
             };
             // A[t] = sum of the 4 waves' partial tiles + bias: ONE wave, 16 bytes per lane, written through (round 3: 256 scalar stores).  In a
             // chained launch the wave then drains its stores and bumps the slab's arrival counter: the graph conv of slab (b, t) starts when
@@ -1040,6 +1161,10 @@ template <int C0, int CIN, int KT, int ACT, typename ET>
 __global__ __launch_bounds__(512) void tc1_fwd_kernel(Tc1FwdArgs a) {
     tc1_fwd_body<C0, CIN, KT, ACT, ET>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
 }
+template <int C0, int CIN, int KT, int ACT>
+__global__ __launch_bounds__(512) void tc1_fwd_x6_kernel(Tc1FwdArgs a) {
+    tc1_fwd_body<C0, CIN, KT, ACT, float, true>(a, (int)blockIdx.x, (int)gridDim.x, ChainCtl{nullptr, 0, 0u});
+}
 // (Round 4, pass r4-06: the same body under __launch_bounds__(512, 4) -- 128 VGPRs, two workgroups REALLY sharing a CU; the plain fp32
 //  CIN = 64 instance takes 133 VGPRs = 3 waves per SIMD, so "two per CU" had been two rounds of one -- measured 28.5 -> 30.5 us: the fp32
 //  matrix pipe of the CU is the limit, a second chain only doubles the prologues.  The instance was removed again;
@@ -1080,7 +1205,11 @@ struct Tc2LnFwdArgs {
     unsigned long long* peer_slots;   // PP > 1: [slabs][PP] exchange words (peer_word), zero at launch start
 };
 constexpr int kLdG = 24;   // row stride of the staged G tiles: stride / 4 = 6 spreads the 16 lanes of a ds_read_b128 service group over all banks
-inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 15) / 16 * 16) * kLdG + 64) * sizeof(float); }
+constexpr int kLdGh = 20;  // (X6) row stride, in shorts, of a staged bf16 plane of G (16 channels + 4: 8-byte rows 40 bytes apart)
+inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N, bool x6 = false) {
+    const size_t NPR = (size_t)(N + 15) / 16 * 16;
+    return (x6 ? (size_t)Kt * 3 * NPR * kLdGh * sizeof(short) : (size_t)Kt * NPR * kLdG * sizeof(float)) + 64 * sizeof(float);
+}
 
 // bid = the (b, t2) slab of this workgroup; chained launch: the KT input slabs G[b][t2 + tap] are awaited on counters chain_in + b * T1 + t2 + tap
 // PP > 1 (round 6): PP workgroups share a slab, each owns a contiguous range of its node tiles (the per-slab chain -- staging, tile passes,
@@ -1088,9 +1217,13 @@ inline size_t tc2_ln_fwd_lds_bytes(int Kt, int N) { return ((size_t)Kt * ((N + 1
 // when block 1 offers 128 slabs).  Slab and part come from a start-order TICKET (peers hold consecutive tickets: a workgroup only ever
 // waits for workgroups that have started or are next to start -- no residency assumption); the parts' (mean, M2) meet through one 64-bit
 // word each (peer_word) and are merged in part order by every peer: bitwise the same statistics in all of them, run to run.
-template <int C2, int KT, int NTI, int HV, int PP, typename ET>
+// X6 (round 6, fp32 blocks): the conv product as "bf16x6" (Frag3, stgcn_device.hip.h) -- the G rows are split into three bf16 planes when they
+// are staged (once per slab; every row then serves the four channel-tile waves), the weights once per wave; on a SIMD whose time is the SUM
+// of its fp32 MFMA and VALU cycles this takes the matrix part off the VALU lanes (a bf16 MFMA runs beside them).
+template <int C2, int KT, int NTI, int HV, int PP, typename ET, bool X6 = false>
 __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int bid, const ChainCtl& chain) {
     static_assert(C2 == 64, "wave pairing below assumes 4 channel tiles per half");
+    static_assert(!X6 || std::is_same<ET, float>::value, "bf16x6 is a product form of the fp32 blocks");
     typedef Mma<ET> MM;
     ET* const U_ = et_ptr<ET>(a.U);
     ET* const S_ = et_ptr<ET>(a.S);
@@ -1098,15 +1231,24 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
     constexpr int NC = 2 * C2, MT = C2 / 16;
     extern __shared__ float stgcn_smem[];
     float* const Gs = stgcn_smem;                          // [KT][NPR][kLdG]  (NPR = this workgroup's rows)
-    float* const red = Gs + (size_t)KT * a.NPR * kLdG;     // [3 * 4 * HV] wave statistics | [2 * PP] peers' (mean, M2) | ticket word
+    short* const Gh = reinterpret_cast<short*>(stgcn_smem);   // (X6) [KT][3 planes][NPR][kLdGh] bf16
+    float* const red = X6 ? reinterpret_cast<float*>(Gh + (size_t)KT * 3 * a.NPR * kLdGh)
+                          : Gs + (size_t)KT * a.NPR * kLdG;   // [3 * 4 * HV] wave statistics | [2 * PP] peers' (mean, M2) | ticket word
     const int tid = threadIdx.x, wv = tid >> 6, p = wv & (MT - 1), hf = wv >> 2, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     STGCN_PHASE(9, 0);
     // stationary weights: A[m = o][k] fragments of o-tiles p (P half) and p + MT (Q half)  (requested before the ticket: one wait covers both)
-    typename MM::frag wP[KT], wQ[KT];
+    typename MM::frag wP[X6 ? 1 : KT], wQ[X6 ? 1 : KT];
+    Frag3 wP3[X6 ? KT : 1], wQ3[X6 ? KT : 1];
 #pragma unroll
     for (int kc = 0; kc < KT; ++kc) {
-        wP[kc] = MM::cvt(ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4));
-        wQ[kc] = MM::cvt(ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4));
+        const f32x4 vp = ld4(a.Wp + ((size_t)(p * KT + kc) * 64 + lane) * 4), vq = ld4(a.Wp + ((size_t)((p + MT) * KT + kc) * 64 + lane) * 4);
+        if constexpr (X6) {
+            wP3[kc] = split3(vp);
+            wQ3[kc] = split3(vq);
+        } else {
+            wP[kc] = MM::cvt(vp);
+            wQ[kc] = MM::cvt(vq);
+        }
     }
     int vb = bid;
     if constexpr (PP > 1) vb = chain_enter_peer(a.peer, reinterpret_cast<unsigned*>(red + 3 * 4 * HV + 2 * PP));
@@ -1127,12 +1269,15 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
             const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR, gr = row0 + rr;
             const int eo = (tap * N + (gr < N ? gr : N - 1)) * 16 + 4 * q;
             const f32x4 v = cvt4(ldraw4_sc1(Gb, (long)KT * N * 16, eo));
-            st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, gr < N ? v : zero4());
+            if constexpr (X6) st_frag3(Gh + ((size_t)tap * 3 * NPR + rr) * kLdGh + 4 * q, NPR * kLdGh, split3(gr < N ? v : zero4()));
+            else st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, gr < N ? v : zero4());
         }
     } else
     for (int idx = tid; idx < KT * NPR * 4; idx += 256 * HV) {
         const int q = idx & 3, rr = (idx >> 2) % NPR, tap = (idx >> 2) / NPR, gr = row0 + rr;
-        st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, gr < N ? ldx4(Gb + ((size_t)tap * N + gr) * 16 + 4 * q) : zero4());
+        const f32x4 v = gr < N ? ldx4(Gb + ((size_t)tap * N + gr) * 16 + 4 * q) : zero4();
+        if constexpr (X6) st_frag3(Gh + ((size_t)tap * 3 * NPR + rr) * kLdGh + 4 * q, NPR * kLdGh, split3(v));   // split ONCE, where the row is staged
+        else st4(Gs + ((size_t)tap * NPR + rr) * kLdG + 4 * q, v);
     }
     const int c = 16 * p + 4 * g;   // this lane's 4 channels
     const f32x4 bp = ld4(a.bias + c), bq = ld4(a.bias + C2 + c);
@@ -1175,7 +1320,8 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
 #pragma unroll
         for (int kc = 0; kc < KT; ++kc) {
             // B[k = 4g + s][n = row]
-            MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g)), accP, accQ);
+            if constexpr (X6) mma3_a2(wP3[kc], wQ3[kc], ld_frag3(Gh + ((size_t)kc * 3 * NPR + nt * 16 + l15) * kLdGh + 4 * g, NPR * kLdGh), accP, accQ);
+            else MM::mma_a2(wP[kc], wQ[kc], MM::cvt(ld4(Gs + ((size_t)kc * NPR + nt * 16 + l15) * kLdG + 4 * g)), accP, accQ);
         }
     };
     auto tile_valu = [&](int j, int row, const f32x4& accP, const f32x4& accQ) __attribute__((always_inline)) {
@@ -1368,6 +1514,10 @@ __device__ __forceinline__ void tc2_ln_fwd_body(const Tc2LnFwdArgs& a, const int
 template <int C2, int KT, int NTI, int HV, int PP, typename ET>
 __global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_kernel(Tc2LnFwdArgs a) {
     tc2_ln_fwd_body<C2, KT, NTI, HV, PP, ET>(a, (int)blockIdx.x, ChainCtl{nullptr, 0, 0u});
+}
+template <int C2, int KT, int NTI, int HV, int PP>
+__global__ __launch_bounds__(256 * HV) void tc2_ln_fwd_x6_kernel(Tc2LnFwdArgs a) {
+    tc2_ln_fwd_body<C2, KT, NTI, HV, PP, float, true>(a, (int)blockIdx.x, ChainCtl{nullptr, 0, 0u});
 }
 
 // ================================================================================================
