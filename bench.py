@@ -413,6 +413,11 @@ def main():
                       **({"replay_ms": replay_ms} if replay_ms else {}),
                       "chains": args.chains if use_graph else 1,
                       "backward_products": ("bf16" if DTYPE == "bf16" else args.bwd_precision),
+                      **({"matrix_products": ("fp32 in, fp32 accumulate; tc1_fwd / tc2_ln_fwd / tc1_bwd form their products as bf16x6 -- both operands split EXACTLY into "
+                                              "three bf16 (8+8+8 significand bits), six of the nine partial products (the others < 2^-32) on v_mfma_f32_16x16x32_bf16; error "
+                                              "against the fp64 stage oracle equal to v_mfma_f32_16x16x4_f32's (profiles/r6-29_x6_errors.txt); every other product on "
+                                              "v_mfma_f32_16x16x4_f32" if os.environ.get("STGCN_MFMA_X6", "1") != "0" else "v_mfma_f32_16x16x4_f32 for every product (STGCN_MFMA_X6=0)")}
+                         if DTYPE == "f32" else {}),
                       "operator_products": ("bf16" if DTYPE == "bf16" else args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32"),
                       "input": (f"device-side windows (n_his 12, n_pred {N_PRED}) of a resident (time, N) series, batch position on the device"
                                 if (resident and use_graph) else "(num, 1, n_his, N) window tensors, one batch copied per step")}}
@@ -479,6 +484,27 @@ def main():
             out["config"]["secondary_bwd_bf16x3"] = {"error": repr(e)}
         ops.set_bwd_precision("fp32")
         graphed = None
+        # second secondary: every matrix product of the fp32 blocks on v_mfma_f32_16x16x4_f32 (STGCN_MFMA_X6=0) instead of the default
+        # "bf16x6" form of tc1_fwd / tc2_ln_fwd / tc1_bwd (fp32-accurate products on the bf16 matrix pipe)
+        os.environ["STGCN_MFMA_X6"] = "0"
+        try:
+            g3 = GraphedTrainStep(model, opt, *batch(0), world=world, chains=args.chains, series=series, n_his=N_HIS, n_pred=N_PRED, rank=rank)
+            for _ in range(args.warmup):
+                g3()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l3 = g3()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t1
+            out["config"]["secondary_fp32_mfma"] = {"value": round(B_LOCAL * args.steps / el3, 2), "unit": "windows/s", "ms_per_step": round(1e3 * el3 / args.steps, 4),
+                                                    "final_loss": round(float(l3.item()), 5),
+                                                    "what": "same step with every matrix product on v_mfma_f32_16x16x4_f32 (STGCN_MFMA_X6=0: the form of rounds 1-5)"}
+            g3.close()
+        except Exception as e:  # noqa: BLE001
+            out["config"]["secondary_fp32_mfma"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("STGCN_MFMA_X6", None)
     if rank == 0 and not args.no_profile:
         # per-kernel durations with hipEvents on the launch stream, over the same K steps (second pass)
         # (eager launches: hipEvents cannot be recorded inside a graph replay; the kernels and shapes are the same)

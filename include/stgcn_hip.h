@@ -30,7 +30,7 @@ extern "C" {
 
 /* ABI revision: bumped whenever an entry point changes its argument list or a struct its layout (round 3 added `y` to the
  * backward entry points and `stored_US2` to the plan: 1 -> 2 in effect, never recorded; round 4: stgcn_set_gemm_big_nt, the
- * chained-launch control words in `ws`: 3, then 4; round 5: stgcn_set_chain_spin_ticks, stgcn_outblock_chain_status: 5; round 6: stgcn_set_tc2ln_peers, stgcn_stblock_chain_status, the exchange words of tmp_conv2 + LayerNorm in `ws`: 6).  stgcn_version() returns the value the LIBRARY was built with; a binding built
+ * chained-launch control words in `ws`: 3, then 4; round 5: stgcn_set_chain_spin_ticks, stgcn_outblock_chain_status: 5; round 6: stgcn_set_tc2ln_peers, stgcn_stblock_chain_status, stgcn_prepack_park / _flush, the exchange words of tmp_conv2 + LayerNorm in `ws`: 6).  stgcn_version() returns the value the LIBRARY was built with; a binding built
  * against another header must refuse to run (stgcn_amd/_lib.py does).                                                  */
 #define STGCN_ABI_VERSION 6
 
@@ -393,11 +393,11 @@ int stgcn_outblock_backward_loss(const stgcn_outblock_desc* desc, const stgcn_ou
  *      counters (nullable, <= 4): device-side int64 step counters advanced by this first launch of the step,
  *      *ptr = (*ptr + inc) % mod (mod 0: no wrap) -- the dropout stream position, the optimizer's step count (main.py:169) and the
  *      like ride on the pack launch instead of costing one tiny launch each inside a captured step.
- *      Round 6: the call PARKS its job list (per host thread) instead of launching it; the next entry point of the library on that
- *      thread launches it first -- except the forward of a block whose first layer is the thin one (Kt * c_in <= 4: STGCN's first block)
- *      on the same stream with prepacked = 1, which sends pack and layer out as ONE launch.  Nothing changes for the caller as long as
- *      the packed workspaces are only consumed through this library (they are its private layouts); a caller that reads `ws` itself, or
- *      that ends a stream capture right after stgcn_prepack, must call any entry point (e.g. stgcn_stblock_chain_status) to flush.      */
+ *      stgcn_prepack_park (round 6; same arguments): for callers whose NEXT call into the library is the forward of the model's first block
+ *      (stgcn_amd/models.py).  It PARKS the job list (per host thread) instead of launching it: the next entry point on that thread launches
+ *      it first -- except the forward of a block whose first layer is the thin one (Kt * c_in <= 4: STGCN's first block) on the same stream
+ *      with prepacked = 1, which sends pack and layer out as ONE launch.  The parked list holds the pointers of the call: parameters and
+ *      workspaces must stay alive until that next entry point (they are the modules' own buffers).  stgcn_prepack itself launches at once. */
 typedef struct stgcn_prepack_block {
     const stgcn_stblock_desc* desc;
     const stgcn_stblock_params* params;
@@ -410,6 +410,12 @@ typedef struct stgcn_step_counter {
 int stgcn_prepack(int32_t n_blocks, const stgcn_prepack_block* blocks, const stgcn_outblock_desc* head_desc,
                   const stgcn_outblock_params* head_params, float* head_ws, int32_t n_counters, const stgcn_step_counter* counters,
                   void* stream);
+int stgcn_prepack_park(int32_t n_blocks, const stgcn_prepack_block* blocks, const stgcn_outblock_desc* head_desc,
+                  const stgcn_outblock_params* head_params, float* head_ws, int32_t n_counters, const stgcn_step_counter* counters,
+                  void* stream);
+/* Launches a job list that stgcn_prepack_park left parked on the calling thread (no-op otherwise): for callers whose first-block forward may not
+ * happen after all (an exception between the two calls) -- the parked list holds pointers that must not outlive their tensors.            */
+int stgcn_prepack_flush(void);
 
 /* ---- Optimizer step: torch.optim.AdamW(lr, weight_decay) as main.py:148 configures it (betas (0.9, 0.999), eps 1e-8,
  *      amsgrad False), applied by optimizer.step() at main.py:169.  `tensors` is a HOST array of `count` entries (device

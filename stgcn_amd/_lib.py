@@ -197,6 +197,11 @@ class _Lib:
         d.stgcn_prepack.argtypes = [C.c_int32, C.POINTER(PrepackBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p,
                                     C.c_int32, C.POINTER(StepCounter), C.c_void_p]
         d.stgcn_prepack.restype = C.c_int
+        d.stgcn_prepack_park.argtypes = [C.c_int32, C.POINTER(PrepackBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockParams), C.c_void_p,
+                                    C.c_int32, C.POINTER(StepCounter), C.c_void_p]
+        d.stgcn_prepack_park.restype = C.c_int
+        d.stgcn_prepack_flush.argtypes = []
+        d.stgcn_prepack_flush.restype = C.c_int
         d.stgcn_grad_flush.argtypes = [C.c_int32, C.POINTER(FlushBlock), C.POINTER(OutblockDesc), C.POINTER(OutblockGrads), C.c_void_p,
                                        C.POINTER(AdamwTensor), C.c_int32, C.POINTER(AdamwHyper), C.c_void_p]
         d.stgcn_grad_flush.restype = C.c_int
@@ -248,4 +253,4 @@ EXPORTED_SYMBOLS = ["stgcn_version", "stgcn_backend", "stgcn_last_error", "stgcn
                     "stgcn_set_gc_precision", "stgcn_set_gc_ld_pad", "stgcn_set_debug_stages",
                     "stgcn_stblock_ln_hook", "stgcn_stblock_backward_hook", "stgcn_outblock_backward_hook", "stgcn_set_tc1_bwd_wgs",
                     "stgcn_set_slab_gc_precision", "stgcn_outblock_backward_loss", "stgcn_set_bwd_precision", "stgcn_set_gemm_big_nt",
-                    "stgcn_set_chain_spin_ticks", "stgcn_outblock_chain_status", "stgcn_set_tc2ln_peers", "stgcn_stblock_chain_status"]
+                    "stgcn_set_chain_spin_ticks", "stgcn_outblock_chain_status", "stgcn_set_tc2ln_peers", "stgcn_stblock_chain_status", "stgcn_prepack_park", "stgcn_prepack_flush"]

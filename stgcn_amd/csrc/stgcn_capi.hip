@@ -373,10 +373,13 @@ struct PendingPack {
     hipStream_t st = nullptr;
 };
 thread_local PendingPack g_pending_pack;
-// "bf16x6" product form of the fp32 blocks (Frag3, stgcn_device.hip.h): STGCN_MFMA_X6=1 (read per call: tests and A/B runs switch it)
+// "bf16x6" product form of the fp32 blocks (Frag3, stgcn_device.hip.h): fp32-accurate products on the bf16 matrix pipe, operands split once at
+// their producer -- the default of tc1_fwd / tc2_ln_fwd / tc1_bwd since round 6 (measured error against the fp64 stage oracle equal to the
+// fp32-MFMA path's, profiles/r6-29_x6_errors.txt).  STGCN_MFMA_X6=0 selects v_mfma_f32_16x16x4_f32 for every product (read per call: bench.py
+// reports that step as config.secondary_fp32_mfma, the stage tests run both).
 inline bool mfma_x6() {
     const char* e = getenv("STGCN_MFMA_X6");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
 }
 inline bool pack_fusion_on() {
     static const int off = STGCN_EXP_ENV("STGCN_PACK_FUSE") ? atoi(STGCN_EXP_ENV("STGCN_PACK_FUSE")) == 0 : 0;   // (A/B knob, experiments build)
@@ -1487,7 +1490,7 @@ after_gconv:
         f.T1 = v.T1; f.T2 = v.T2; f.N = d->N; f.NPR = (int)rup(d->N, 16); f.act = d->act; f.training = d->training && d->droprate > 0.f;
         f.eps = d->ln_eps; f.keep_scale = 1.0f / (1.0f - d->droprate); f.thresh = drop_thresh(d->droprate);
         f.seed = seed; f.offset = offset; f.offset_dev = offset_dev;
-        const bool x6 = mfma_x6() && !g_bf16 && d->N <= 256 && v.slabs2 <= 2L * device_cus();   // "bf16x6" products: the 16-wave forms of up to 256 nodes
+        const bool x6 = mfma_x6() && !g_bf16 && d->N <= 256 && v.slabs2 <= 2L * device_cus() && d->Kt <= 3;   // "bf16x6" products: the 16-wave forms of up to 256 nodes (4 taps: 8 weight plane triples spill)
         const size_t lds = tc2_ln_fwd_lds_bytes(d->Kt, d->N, x6);
         // workgroups per slab (round 6): a slab is one serial chain of ~15 us whatever the batch, so a launch that leaves compute units idle
         // (block 1 of C2: 128 slabs; every small batch) cuts the slab's node tiles over PP workgroups that exchange their statistics
@@ -1504,9 +1507,9 @@ after_gconv:
         const bool small = d->N <= 224;   // 7 row tiles per wave of a two-group workgroup
 #define STGCN_TC2LN(KT_)                                                                                  \
         do {                                                                                              \
-            if (x6 && pp == 2) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 2, 4, 2>), grid, dim3(1024), lds, f); \
-            else if (x6 && pp == 4) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 1, 4, 4>), grid, dim3(1024), lds, f); \
-            else if (x6 && wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, KT_, 4, 4, 1>), grid, dim3(1024), lds, f); \
+            if (x6 && pp == 2) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, (KT_ <= 3 ? KT_ : 3), 2, 4, 2>), grid, dim3(1024), lds, f); \
+            else if (x6 && pp == 4) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, (KT_ <= 3 ? KT_ : 3), 1, 4, 4>), grid, dim3(1024), lds, f); \
+            else if (x6 && wide) STGCN_LAUNCH("tc2_ln_fwd", st, (tc2_ln_fwd_x6_kernel<64, (KT_ <= 3 ? KT_ : 3), 4, 4, 1>), grid, dim3(1024), lds, f); \
             else if (pp == 2 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 2, 4, 2, ET>), grid, dim3(1024), lds, f); \
             else if (pp == 4 && d->N <= 256) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 1, 4, 4, ET>), grid, dim3(1024), lds, f); \
             else if (pp == 2) STGCN_LAUNCH_ET("tc2_ln_fwd", st, (tc2_ln_fwd_kernel<64, KT_, 3, 4, 2, ET>), grid, dim3(1024), lds, f); \

@@ -57,7 +57,7 @@ class _STGCNBase(nn.Module):
             head = (self.output.cfg, T, self.output._params(), self.output._ws)
         # step counters a trainer asked to advance with the first launch of each TRAINING forward (train.GraphedTrainStep)
         counters = getattr(self, "_step_counters", None) if self.training else None
-        ops.prepack_modules(blocks, head, x.shape[0], x.device, counters, dtype=x.dtype)
+        ops.prepack_modules(blocks, head, x.shape[0], x.device, counters, dtype=x.dtype, park=True)      # (forward() runs the first block next)
         return [b[3] for b in blocks] + ([head[3]] if head is not None else [])
 
     def set_compute_dtype(self, dtype):
@@ -86,6 +86,9 @@ class _STGCNBase(nn.Module):
         finally:
             for wsc in marked:      # a module that did not run (exception) must pack by itself next time
                 wsc.prepacked = False
+            if marked:              # (a pack still parked -- the first block never reached the library -- goes out now, while its tensors live)
+                from . import ops
+                ops.prepack_flush()
         return x if x.dtype == torch.float32 else x.float()      # (Ko == 1 hands the last block's output through)
 
 

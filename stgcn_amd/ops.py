@@ -194,6 +194,13 @@ def set_tc1_bwd_wgs(n: int) -> int:
     return prev
 
 
+def prepack_flush() -> None:
+    """Launch a weight pack that ``prepack_modules(..., park=True)`` left parked (no-op otherwise): ``models.STGCN*.forward`` calls it when it
+    leaves, so that a forward that raised before its first block ran cannot leave pointers to its tensors behind."""
+    L = _lib.lib()
+    L.check(L.dll.stgcn_prepack_flush(), "stgcn_prepack_flush")
+
+
 def set_tc2ln_peers(n: int) -> int:
     """Workgroups per (b, t) slab of the fused tmp_conv2 + LayerNorm + dropout forward: 0 = by the device, 1 / 2 / 4 force a form
     (test / tuning knob, ``stgcn_set_tc2ln_peers``); returns the previous value."""
@@ -626,7 +633,7 @@ def st_conv_block(x: torch.Tensor, gso_pad: torch.Tensor, gso_t_pad: torch.Tenso
     return y_cl.permute(0, 3, 1, 2)
 
 
-def prepack_modules(blocks, head, B: int, device, counters=None, dtype: torch.dtype = torch.float32) -> None:
+def prepack_modules(blocks, head, B: int, device, counters=None, dtype: torch.dtype = torch.float32, park: bool = False) -> None:
     """One pack launch for a whole model step (stgcn_prepack): ``blocks`` is a list of (cfg, T_in, params, wsc) of the ST
     blocks in order, ``head`` is (cfg, T_in, params, wsc) or None.  Marks every workspace so that the module's next forward
     skips its own pack launch.  Parameters only change in optimizer.step(), so this runs once per forward of the model."""
@@ -660,7 +667,10 @@ def prepack_modules(blocks, head, B: int, device, counters=None, dtype: torch.dt
         for i, (t, inc, mod) in enumerate(counters):
             assert t.dtype == torch.int64 and t.numel() == 1
             carr[i].ptr, carr[i].inc, carr[i].mod = t.data_ptr(), int(inc), int(mod)
-    L.check(L.dll.stgcn_prepack(len(blocks), arr, hd, hp, hws, 0 if carr is None else len(counters), carr, stream), "stgcn_prepack")
+    # (stgcn_prepack_park: the caller -- models.STGCN*.forward -- runs the first block right after this call; the library then sends the pack
+    #  out together with that block's first layer when it is the thin one, or first thing in the next call otherwise)
+    fn = L.dll.stgcn_prepack_park if park else L.dll.stgcn_prepack
+    L.check(fn(len(blocks), arr, hd, hp, hws, 0 if carr is None else len(counters), carr, stream), "stgcn_prepack")
     for _, _, _, wsc in blocks:
         wsc.prepacked = True
     if head is not None:
