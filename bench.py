@@ -50,8 +50,8 @@ CONFIGS = {
                         "dropout 0.5, AdamW; full step"),
 }
 # (named explicitly: they have to be re-measured whenever a kernel's traffic changes; keyed by (config, dtype))
-PMC_TRAFFIC_FILES = {("c2", "f32"): "r6-20_pmc_traffic.json", ("c3", "bf16"): "r6-20_pmc_traffic_c3_bf16.json",
-                     ("c5", "bf16"): "r6-20_pmc_traffic_c5_bf16.json"}
+PMC_TRAFFIC_FILES = {("c2", "f32"): "r6-40_pmc_traffic.json", ("c3", "bf16"): "r6-40_pmc_traffic_c3_bf16.json",
+                     ("c5", "bf16"): "r6-40_pmc_traffic_c5_bf16.json"}
 B_OVERRIDE = os.environ.get("STGCN_BENCH_B")       # (env: batch-size sweeps of tools/, not the headline)
 
 
