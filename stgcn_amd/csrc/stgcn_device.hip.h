@@ -818,6 +818,16 @@ __device__ __forceinline__ void mma3_a2(const Frag3& a0, const Frag3& a1, const 
     c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0hm, bhh, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1hm, bhh, c1, 0, 0, 0);
 }
+// the same triple as one 16-byte (h | m) group + an 8-byte l group (two LDS planes): a consumer gets (h | m) -- one 32-deep operand as it stands --
+// with ONE ds_read_b128, and the compiler cannot fuse the reads of neighbouring planes into ds_read2_b64 (half the LDS rate, 32 banks)
+__device__ __forceinline__ void st_frag3_hml(short* phm, short* pl, const Frag3& f) {
+    *reinterpret_cast<s16x8*>(phm) = s16x8{f.h[0], f.h[1], f.h[2], f.h[3], f.m[0], f.m[1], f.m[2], f.m[3]};
+    *reinterpret_cast<s16x4*>(pl) = f.l;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// LDS byte address of a pointer into shared memory (the operand of a hand-written ds_read)
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+#endif
 // one plane triple of 4 consecutive k values in LDS: planes `pstride` shorts apart, 8-byte accesses
 __device__ __forceinline__ void st_frag3(short* p, int pstride, const Frag3& f) {
     *reinterpret_cast<s16x4*>(p) = f.h;

@@ -469,6 +469,97 @@ __host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CI
     return w;
 }
 
+// One tap of the X6 transposed conv (Md waves of tc1_bwd), hand-scheduled: 8 fragments of 16 dZ1 columns, per fragment
+//     ds_read_b128 (h | m) + ds_read_b64 l of the dZ1 tile, ds_read_b64 of the weight's low plane  ->  v[B .. B+11] = [bl bh bm bh' | ah' al]
+//     (Ah'|Al)(Bl|Bh) -> ca ,  (Ah|Am)(Bh|Bm) -> cb ,  (Ah|Am)(Bm|Bh') -> cc        (the six products; three independent accumulators)
+// The operands of the three instructions are OVERLAPPING windows of one register tuple, which the compiler cannot express (it copied ~13
+// registers per fragment, fused plane reads into ds_read2_b64 and waited for every fragment's loads right after issuing them: the Md waves
+// were the critical role of the kernel, profiles/r6-43_tc1_bwd_timing_only.txt).  Here: two v_mov_b64 per fragment, loads two fragments ahead
+// in two register sets (v144 - v155, v156 - v167: clobbers), in-order LDS returns counted by lgkmcnt.  The trailing s_nop cover the
+// MFMA-write -> VALU-read hazard the compiler cannot see.
+#define STGCN_TC1BWD_MD_TAP_ASM \
+    "ds_read_b128 v[146:149], %[zh] offset:0\n\t" \
+    "ds_read_b64 v[144:145], %[zl] offset:0\n\t" \
+    "ds_read_b64 v[154:155], %[wl] offset:0\n\t" \
+    "ds_read_b128 v[158:161], %[zh] offset:64\n\t" \
+    "ds_read_b64 v[156:157], %[zl] offset:32\n\t" \
+    "ds_read_b64 v[166:167], %[wl] offset:512\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[150:151], v[146:147]\n\t" \
+    "v_mov_b64 v[152:153], %[l0]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[152:155], v[144:147], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w0], v[146:149], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w0], v[148:151], %[cc]\n\t" \
+    "ds_read_b128 v[146:149], %[zh] offset:128\n\t" \
+    "ds_read_b64 v[144:145], %[zl] offset:64\n\t" \
+    "ds_read_b64 v[154:155], %[wl] offset:1024\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[162:163], v[158:159]\n\t" \
+    "v_mov_b64 v[164:165], %[l1]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[164:167], v[156:159], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w1], v[158:161], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w1], v[160:163], %[cc]\n\t" \
+    "ds_read_b128 v[158:161], %[zh] offset:192\n\t" \
+    "ds_read_b64 v[156:157], %[zl] offset:96\n\t" \
+    "ds_read_b64 v[166:167], %[wl] offset:1536\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[150:151], v[146:147]\n\t" \
+    "v_mov_b64 v[152:153], %[l2]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[152:155], v[144:147], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w2], v[146:149], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w2], v[148:151], %[cc]\n\t" \
+    "ds_read_b128 v[146:149], %[zh] offset:256\n\t" \
+    "ds_read_b64 v[144:145], %[zl] offset:128\n\t" \
+    "ds_read_b64 v[154:155], %[wl] offset:2048\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[162:163], v[158:159]\n\t" \
+    "v_mov_b64 v[164:165], %[l3]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[164:167], v[156:159], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w3], v[158:161], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w3], v[160:163], %[cc]\n\t" \
+    "ds_read_b128 v[158:161], %[zh] offset:320\n\t" \
+    "ds_read_b64 v[156:157], %[zl] offset:160\n\t" \
+    "ds_read_b64 v[166:167], %[wl] offset:2560\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[150:151], v[146:147]\n\t" \
+    "v_mov_b64 v[152:153], %[l4]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[152:155], v[144:147], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w4], v[146:149], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w4], v[148:151], %[cc]\n\t" \
+    "ds_read_b128 v[146:149], %[zh] offset:384\n\t" \
+    "ds_read_b64 v[144:145], %[zl] offset:192\n\t" \
+    "ds_read_b64 v[154:155], %[wl] offset:3072\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[162:163], v[158:159]\n\t" \
+    "v_mov_b64 v[164:165], %[l5]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[164:167], v[156:159], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w5], v[158:161], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w5], v[160:163], %[cc]\n\t" \
+    "ds_read_b128 v[158:161], %[zh] offset:448\n\t" \
+    "ds_read_b64 v[156:157], %[zl] offset:224\n\t" \
+    "ds_read_b64 v[166:167], %[wl] offset:3584\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    "v_mov_b64 v[150:151], v[146:147]\n\t" \
+    "v_mov_b64 v[152:153], %[l6]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[152:155], v[144:147], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w6], v[146:149], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w6], v[148:151], %[cc]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_mov_b64 v[162:163], v[158:159]\n\t" \
+    "v_mov_b64 v[164:165], %[l7]\n\t" \
+    "s_nop 1\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[ca], v[164:167], v[156:159], %[ca]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cb], %[w7], v[158:161], %[cb]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[cc], %[w7], v[160:163], %[cc]\n\t" \
+    "s_nop 7\n\t" \
+    "s_nop 7\n\t"
 // X6 (round 6, fp32 blocks): the weight-gradient and transposed-conv products (Mw and Md waves) as "bf16x6" -- fp32-accurate
 // products on the bf16 matrix pipe (Frag3, stgcn_device.hip.h).  Both operands are tiles the E waves produce: x tiles (staged once, read
 // by four waves for KT steps) and dZ1 tiles (formed once); E splits them into three bf16 planes where it writes them.  The transposed conv
@@ -487,12 +578,14 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
     constexpr int NC = 2 * C0, LDZ = NC + 4, RING = KT + 1, LDX = 20, LDH = C0 + 4, LDO = CIN + 4, MI = CIN / 16, QD = NC / 16;
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
-    constexpr int LDZH = NC + 8, ZPL = 16 * LDZH, LDXH = 20, XPL = CIN * LDXH;   // (X6) plane row / plane strides in shorts
-    float* const XT = Zt + (X6 ? RING * 3 * ZPL / 2 : RING * 16 * LDZ);   // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row]); X6: three bf16 planes of them instead (XTh)
+    // (X6) dZ1 tiles as a (h | m) plane of 16-byte groups + an l plane of 8-byte groups (row strides = 8 / 4 dwords mod 64: the b128 / b64 reads of
+    // 16 rows are conflict-free); x tiles as three planes, transposed
+    constexpr int LDZHM = 2 * NC + 16, LDZL = NC + 8, ZLOFS = 16 * LDZHM, ZSLOT = 16 * (LDZHM + LDZL), LDXH = 20, XPL = CIN * LDXH;
+    float* const XT = Zt + (X6 ? RING * ZSLOT / 2 : RING * 16 * LDZ);   // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row]); X6: three bf16 planes of them instead (XTh)
     float* const dAe = XT + (X6 ? RING * 3 * CIN * 20 / 2 : RING * CIN * LDX);   // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
     float* const Ht = dAe + RING * 16 * 16;            // [2][16][LDH]      H = act(U) * S tiles (owned tiles only)
     float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
-    short* const Zh = reinterpret_cast<short*>(Zt);                  // (X6) [RING][3][16][LDZH]   bf16 planes of the dZ1 tiles (instead of the fp32 tiles)
+    short* const Zh = reinterpret_cast<short*>(Zt);                  // (X6) [RING]{[16][LDZHM], [16][LDZL]}  bf16 form of the dZ1 tiles (instead of the fp32 tiles)
     short* const XTh = reinterpret_cast<short*>(XT);                 // (X6) [RING][3][CIN][LDXH]  bf16 planes of the transposed x tiles
     short* const Wl = reinterpret_cast<short*>(Xo + 2 * 16 * LDO);   // (X6) [4 waves][KT * QD][64 lanes][4]  low plane of the Md waves' stationary weights
     const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
@@ -601,9 +694,9 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                     h[i] = gate_fwd(tu[i], tsv[i], ACT);
                 }
                 if constexpr (X6) {   // the tile as three bf16 planes: split ONCE, where it is formed
-                    short* const Zp = Zh + (size_t)(t % RING) * 3 * ZPL + er * LDZH;
-                    st_frag3(Zp + 4 * ecq, ZPL, split3(du));
-                    st_frag3(Zp + C0 + 4 * ecq, ZPL, split3(dq));
+                    short* const Zp = Zh + (size_t)(t % RING) * ZSLOT;
+                    st_frag3_hml(Zp + er * LDZHM + 8 * ecq, Zp + ZLOFS + er * LDZL + 4 * ecq, split3(du));
+                    st_frag3_hml(Zp + er * LDZHM + 8 * (C0 / 4 + ecq), Zp + ZLOFS + er * LDZL + C0 + 4 * ecq, split3(dq));
                 } else {
                     float* const Zs = Zt + (t % RING) * 16 * LDZ + er * LDZ;
                     st4(Zs + 4 * ecq, du);
@@ -798,12 +891,14 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                 if (i < T1) {
                   if constexpr (X6) {
                     // B[k = row 4g + s][n = o]: the lane's 4 rows of one column, gathered from each plane (2-byte reads)
-                    const short* const Zp = Zh + (size_t)(i % RING) * 3 * ZPL + (4 * g) * LDZH + (2 * w) * 16 + l15;
+                    const int o0 = (2 * w) * 16 + l15;   // column o of a row: element o & 3 of the h quad of group o >> 2 (m: + 4); columns o0 and o0 + 16
+                    const short* const Zp = Zh + (size_t)(i % RING) * ZSLOT + (4 * g) * LDZHM + 8 * (o0 >> 2) + (o0 & 3);
+                    const short* const Zl = Zh + (size_t)(i % RING) * ZSLOT + ZLOFS + (4 * g) * LDZL + o0;
                     Frag3 fz0, fz1;
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        fz0.h[s] = Zp[s * LDZH]; fz0.m[s] = Zp[ZPL + s * LDZH]; fz0.l[s] = Zp[2 * ZPL + s * LDZH];
-                        fz1.h[s] = Zp[s * LDZH + 16]; fz1.m[s] = Zp[ZPL + s * LDZH + 16]; fz1.l[s] = Zp[2 * ZPL + s * LDZH + 16];
+                        fz0.h[s] = Zp[s * LDZHM]; fz0.m[s] = Zp[s * LDZHM + 4]; fz0.l[s] = Zl[s * LDZL];
+                        fz1.h[s] = Zp[s * LDZHM + 32]; fz1.m[s] = Zp[s * LDZHM + 36]; fz1.l[s] = Zl[s * LDZL + 16];
                     }
                     const bf16x8 z0lh = cat8(fz0.l, fz0.h), z0mm = cat8(fz0.m, fz0.m), z0hh = cat8(fz0.h, fz0.h);
                     const bf16x8 z1lh = cat8(fz1.l, fz1.h), z1mm = cat8(fz1.m, fz1.m), z1hh = cat8(fz1.h, fz1.h);
@@ -890,27 +985,42 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                 STGCN_ACC_BEGIN();
                 if (w < MI) {
                     f32x4 accd[2] = {zero4(), zero4()};
+                    f32x4 accx = zero4();   // (X6) third accumulator: one per kind of product pair
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const int ts = i - k;
                         if (ts >= 0 && ts < T1) {   // uniform
                           if constexpr (X6) {
-                            const short* zr = Zh + (size_t)(ts % RING) * 3 * ZPL + l15 * LDZH + 4 * g;
+                            static_assert(!X6 || QD == 8, "the hand-scheduled tap covers 8 fragments");
+                            const short* const zh = Zh + (size_t)(ts % RING) * ZSLOT + l15 * LDZHM + 8 * g;          // + 32 q: group 4 q + g of row l15
+                            const short* const zl = Zh + (size_t)(ts % RING) * ZSLOT + ZLOFS + l15 * LDZL + 4 * g;   // + 16 q
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STGCN_LO4(x) __builtin_shufflevector(x, x, 0, 1, 2, 3)
+                            asm volatile(STGCN_TC1BWD_MD_TAP_ASM
+                                         : [ca] "+v"(accd[0]), [cb] "+v"(accd[1]), [cc] "+v"(accx)
+                                         : [zh] "v"(lds_addr(zh)), [zl] "v"(lds_addr(zl)), [wl] "v"(lds_addr(Wlw + k * QD * 256)),
+                                           [w0] "v"(Whm[k][0]), [w1] "v"(Whm[k][1]), [w2] "v"(Whm[k][2]), [w3] "v"(Whm[k][3]),
+                                           [w4] "v"(Whm[k][4]), [w5] "v"(Whm[k][5]), [w6] "v"(Whm[k][6]), [w7] "v"(Whm[k][7]),
+                                           [l0] "v"(STGCN_LO4(Whm[k][0])), [l1] "v"(STGCN_LO4(Whm[k][1])), [l2] "v"(STGCN_LO4(Whm[k][2])), [l3] "v"(STGCN_LO4(Whm[k][3])),
+                                           [l4] "v"(STGCN_LO4(Whm[k][4])), [l5] "v"(STGCN_LO4(Whm[k][5])), [l6] "v"(STGCN_LO4(Whm[k][6])), [l7] "v"(STGCN_LO4(Whm[k][7]))
+                                         : "memory", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155",
+                                           "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+#undef STGCN_LO4
+#else
 #pragma unroll
-                            for (int q = 0; q < QD; ++q) {   // B[k = o][n = row]; two independent accumulator chains
-                                // (Ah|Al)(Bl|Bh) + (Ah|Am)(Bm|Bh) + (Ah|Am)(Bh|Bm) = the six products; the B operands are read from the planes in the
-                                // order each instruction wants them (8-byte reads into neighbouring registers: no copies), A = Whm as it stands
-                                const s16x4 bh = *reinterpret_cast<const s16x4*>(zr + 16 * q), bm = *reinterpret_cast<const s16x4*>(zr + 16 * q + ZPL);
-                                const s16x4 bl = *reinterpret_cast<const s16x4*>(zr + 16 * q + 2 * ZPL);
+                            for (int q = 0; q < QD; ++q) {   // (host emulator: the same products into the same accumulators)
+                                const s16x8 bhm = *reinterpret_cast<const s16x8*>(zh + 32 * q);
+                                const s16x4 bl = *reinterpret_cast<const s16x4*>(zl + 16 * q);
                                 const s16x4 wl = *reinterpret_cast<const s16x4*>(Wlw + (k * QD + q) * 256);
                                 const s16x8 whm = Whm[k][q];
                                 const s16x8 whl = {whm[0], whm[1], whm[2], whm[3], wl[0], wl[1], wl[2], wl[3]};
-                                f32x4& c = accd[q & 1];
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whl), cat8(bl, bh), c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), cat8(bm, bh), c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), cat8(bh, bm), c, 0, 0, 0);
-                                if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // (bounds the live range of the operand temporaries: 24 unrolled fragments spilled)
+                                const s16x8 blh = {bl[0], bl[1], bl[2], bl[3], bhm[0], bhm[1], bhm[2], bhm[3]};
+                                const s16x8 bmh = {bhm[4], bhm[5], bhm[6], bhm[7], bhm[0], bhm[1], bhm[2], bhm[3]};
+                                accd[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whl), __builtin_bit_cast(bf16x8, blh), accd[0], 0, 0, 0);
+                                accd[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), __builtin_bit_cast(bf16x8, bhm), accd[1], 0, 0, 0);
+                                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, whm), __builtin_bit_cast(bf16x8, bmh), accx, 0, 0, 0);
                             }
+#endif
                           } else {
                             const float* zr = Zt + (ts % RING) * 16 * LDZ + l15 * LDZ + 4 * g;
 #pragma unroll
@@ -920,6 +1030,7 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                           }
                         }
                     }
+                    if constexpr (X6) accd[0] += accx;
                     st4(Xo + (i & 1) * 16 * LDO + l15 * LDO + 16 * w + 4 * g, accd[0] + accd[1]);   // D[m = ci = 16w + 4g + r][n = row]
                 }
                 STGCN_ACC_END();
