@@ -825,6 +825,23 @@ __device__ __forceinline__ void st_frag3_hml(short* phm, short* pl, const Frag3&
     *reinterpret_cast<s16x4*>(pl) = f.l;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
+#define STGCN_ON_DEVICE 1   // (constant of `if constexpr` choices between a hand-scheduled device form and the portable form the host emulator runs)
+#else
+#define STGCN_ON_DEVICE 0
+#endif
+// A[m][k = 4 consecutive rows] fragment of a ROW-MAJOR bf16 tile in LDS (element (row, col) at p0[row * ld + col]): lane (l15, g) receives column
+// col0 + l15 of rows 4g .. 4g + 3.  On the device one ds_read_b64_tr_b16: every lane supplies the address of 4 contiguous elements -- lane i of a
+// 16-lane group: row 4g + (i >> 2), columns col0 + 4 (i & 3) .. + 3 -- and receives element (c & 3) of the lanes 4j + (c >> 2), j = 0 .. 3
+// (tools/ubench/tr_read.hip).  Conflict-free when ld is an odd multiple of 8 dwords (8 rows x 8 dwords = the 64 banks).
+__device__ __forceinline__ s16x4 ld_tr4(const short* p0, int ld, int g, int l15) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + (4 * g + (l15 >> 2)) * ld + 4 * (l15 & 3)));
+#else
+    return s16x4{p0[(4 * g) * ld + l15], p0[(4 * g + 1) * ld + l15], p0[(4 * g + 2) * ld + l15], p0[(4 * g + 3) * ld + l15]};
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
 // LDS byte address of a pointer into shared memory (the operand of a hand-written ds_read)
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 #endif

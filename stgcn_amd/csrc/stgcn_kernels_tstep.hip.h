@@ -451,8 +451,8 @@ struct Tc1BwdArgs {
     int B, T, T1, N, node_tiles;
 };
 inline size_t tc1_bwd_lds_bytes(int C0, int CIN, int Kt, bool x6 = false) {
-    // x tiles (transposed): fp32 [CIN][20], or (X6) three bf16 planes [CIN][20] in the same place (15 instead of 10 floats' worth per row)
-    const size_t xt = x6 ? (size_t)(Kt + 1) * 3 * CIN * 20 * sizeof(short) : (size_t)(Kt + 1) * CIN * 20 * sizeof(float);
+    // x tiles: fp32, transposed [CIN][20]; or (X6) three ROW-MAJOR bf16 planes [16][CIN + 16] (the weight-gradient waves read them through the transposing LDS read)
+    const size_t xt = x6 ? (size_t)(Kt + 1) * 3 * 16 * (CIN + 16) * sizeof(short) : (size_t)(Kt + 1) * CIN * 20 * sizeof(float);
     const size_t zt = x6 ? (size_t)(Kt + 1) * 3 * 16 * (2 * C0 + 8) * sizeof(short) : (size_t)(Kt + 1) * 16 * (2 * C0 + 4) * sizeof(float);   // dZ1 tiles: fp32, or three bf16 planes
     const size_t rest = ((size_t)(Kt + 1) * 16 * 16 + 2 * 16 * (C0 + 4) + 2 * 16 * (CIN + 4)) * sizeof(float);
     // X6: + the low plane of the transposed conv's stationary weights (4 waves x Kt * 2 C0 / 16 fragments x 64 lanes x 8 bytes; hi / mid stay in registers)
@@ -560,6 +560,154 @@ __host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CI
     "v_mfma_f32_16x16x32_bf16 %[cc], %[w7], v[160:163], %[cc]\n\t" \
     "s_nop 7\n\t" \
     "s_nop 7\n\t"
+// One output step of the X6 weight-gradient waves (Mw) of tc1_bwd at CIN = 64, KT = 3, hand-scheduled like the tap above.  Every operand comes out of
+// a ROW-MAJOR bf16 tile through the transposing LDS read (ds_read_b64_tr_b16, ld_tr4): the two dZ1 fragments of the step as [l h m h'] tuples
+// (v136 - v151), the 12 x fragments as [h m h' l] tuples in two register sets (v152 - v159 / v160 - v167), loads two fragments ahead; six MFMAs per
+// x fragment with overlapping operand windows, no VALU instruction at all (the compiler's form: 24 two-byte gathers + packing per step and ~10
+// register copies per fragment).  x planes: 16 * 80 shorts apart (2560 bytes), m-tiles 32 bytes apart.
+#define STGCN_TC1BWD_MW_STEP_ASM \
+    "ds_read_b64_tr_b16 v[136:137], %[zl] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[138:139], %[zh] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[140:141], %[zh] offset:8\n\t" \
+    "ds_read_b64_tr_b16 v[142:143], %[zh] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[144:145], %[zl] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[146:147], %[zh] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[148:149], %[zh] offset:72\n\t" \
+    "ds_read_b64_tr_b16 v[150:151], %[zh] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x0] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x0] offset:2560\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x0] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x0] offset:5120\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x0] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x0] offset:2592\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x0] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x0] offset:5152\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_0], v[156:159], v[136:139], %[c0_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_1], v[156:159], v[144:147], %[c0_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_0], v[152:155], v[138:141], %[c0_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_1], v[152:155], v[146:149], %[c0_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_0], v[152:155], v[140:143], %[c0_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c0_1], v[152:155], v[148:151], %[c0_1]\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x0] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x0] offset:2624\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x0] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x0] offset:5184\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_0], v[164:167], v[136:139], %[c1_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_1], v[164:167], v[144:147], %[c1_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_0], v[160:163], v[138:141], %[c1_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_1], v[160:163], v[146:149], %[c1_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_0], v[160:163], v[140:143], %[c1_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c1_1], v[160:163], v[148:151], %[c1_1]\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x0] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x0] offset:2656\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x0] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x0] offset:5216\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_0], v[156:159], v[136:139], %[c2_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_1], v[156:159], v[144:147], %[c2_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_0], v[152:155], v[138:141], %[c2_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_1], v[152:155], v[146:149], %[c2_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_0], v[152:155], v[140:143], %[c2_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c2_1], v[152:155], v[148:151], %[c2_1]\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x1] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x1] offset:2560\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x1] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x1] offset:5120\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_0], v[164:167], v[136:139], %[c3_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_1], v[164:167], v[144:147], %[c3_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_0], v[160:163], v[138:141], %[c3_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_1], v[160:163], v[146:149], %[c3_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_0], v[160:163], v[140:143], %[c3_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c3_1], v[160:163], v[148:151], %[c3_1]\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x1] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x1] offset:2592\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x1] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x1] offset:5152\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_0], v[156:159], v[136:139], %[c4_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_1], v[156:159], v[144:147], %[c4_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_0], v[152:155], v[138:141], %[c4_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_1], v[152:155], v[146:149], %[c4_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_0], v[152:155], v[140:143], %[c4_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c4_1], v[152:155], v[148:151], %[c4_1]\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x1] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x1] offset:2624\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x1] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x1] offset:5184\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_0], v[164:167], v[136:139], %[c5_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_1], v[164:167], v[144:147], %[c5_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_0], v[160:163], v[138:141], %[c5_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_1], v[160:163], v[146:149], %[c5_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_0], v[160:163], v[140:143], %[c5_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c5_1], v[160:163], v[148:151], %[c5_1]\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x1] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x1] offset:2656\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x1] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x1] offset:5216\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_0], v[156:159], v[136:139], %[c6_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_1], v[156:159], v[144:147], %[c6_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_0], v[152:155], v[138:141], %[c6_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_1], v[152:155], v[146:149], %[c6_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_0], v[152:155], v[140:143], %[c6_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c6_1], v[152:155], v[148:151], %[c6_1]\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x2] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x2] offset:2560\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x2] offset:0\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x2] offset:5120\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_0], v[164:167], v[136:139], %[c7_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_1], v[164:167], v[144:147], %[c7_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_0], v[160:163], v[138:141], %[c7_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_1], v[160:163], v[146:149], %[c7_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_0], v[160:163], v[140:143], %[c7_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c7_1], v[160:163], v[148:151], %[c7_1]\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x2] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x2] offset:2592\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x2] offset:32\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x2] offset:5152\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_0], v[156:159], v[136:139], %[c8_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_1], v[156:159], v[144:147], %[c8_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_0], v[152:155], v[138:141], %[c8_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_1], v[152:155], v[146:149], %[c8_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_0], v[152:155], v[140:143], %[c8_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c8_1], v[152:155], v[148:151], %[c8_1]\n\t" \
+    "ds_read_b64_tr_b16 v[152:153], %[x2] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[154:155], %[x2] offset:2624\n\t" \
+    "ds_read_b64_tr_b16 v[156:157], %[x2] offset:64\n\t" \
+    "ds_read_b64_tr_b16 v[158:159], %[x2] offset:5184\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_0], v[164:167], v[136:139], %[c9_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_1], v[164:167], v[144:147], %[c9_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_0], v[160:163], v[138:141], %[c9_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_1], v[160:163], v[146:149], %[c9_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_0], v[160:163], v[140:143], %[c9_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c9_1], v[160:163], v[148:151], %[c9_1]\n\t" \
+    "ds_read_b64_tr_b16 v[160:161], %[x2] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[162:163], %[x2] offset:2656\n\t" \
+    "ds_read_b64_tr_b16 v[164:165], %[x2] offset:96\n\t" \
+    "ds_read_b64_tr_b16 v[166:167], %[x2] offset:5216\n\t" \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_0], v[156:159], v[136:139], %[c10_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_1], v[156:159], v[144:147], %[c10_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_0], v[152:155], v[138:141], %[c10_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_1], v[152:155], v[146:149], %[c10_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_0], v[152:155], v[140:143], %[c10_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c10_1], v[152:155], v[148:151], %[c10_1]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_0], v[164:167], v[136:139], %[c11_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_1], v[164:167], v[144:147], %[c11_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_0], v[160:163], v[138:141], %[c11_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_1], v[160:163], v[146:149], %[c11_1]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_0], v[160:163], v[140:143], %[c11_0]\n\t" \
+    "v_mfma_f32_16x16x32_bf16 %[c11_1], v[160:163], v[148:151], %[c11_1]\n\t" \
+    "s_nop 7\n\t" \
+    "s_nop 7\n\t"
 // X6 (round 6, fp32 blocks): the weight-gradient and transposed-conv products (Mw and Md waves) as "bf16x6" -- fp32-accurate
 // products on the bf16 matrix pipe (Frag3, stgcn_device.hip.h).  Both operands are tiles the E waves produce: x tiles (staged once, read
 // by four waves for KT steps) and dZ1 tiles (formed once); E splits them into three bf16 planes where it writes them.  The transposed conv
@@ -579,14 +727,14 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
     extern __shared__ float stgcn_smem[];
     float* const Zt = stgcn_smem;                      // [RING][16][LDZ]   dZ1 tiles
     // (X6) dZ1 tiles as a (h | m) plane of 16-byte groups + an l plane of 8-byte groups (row strides = 8 / 4 dwords mod 64: the b128 / b64 reads of
-    // 16 rows are conflict-free); x tiles as three planes, transposed
-    constexpr int LDZHM = 2 * NC + 16, LDZL = NC + 8, ZLOFS = 16 * LDZHM, ZSLOT = 16 * (LDZHM + LDZL), LDXH = 20, XPL = CIN * LDXH;
+    // 16 rows are conflict-free); x tiles as three row-major planes [16][LDXR] (row stride = an odd multiple of 8 dwords at CIN = 64 / 32)
+    constexpr int LDZHM = 2 * NC + 16, LDZL = NC + 8, ZLOFS = 16 * LDZHM, ZSLOT = 16 * (LDZHM + LDZL), LDXR = CIN + 16, XPL = 16 * LDXR;
     float* const XT = Zt + (X6 ? RING * ZSLOT / 2 : RING * 16 * LDZ);   // [RING][CIN][LDX]  x tiles, transposed (XT[t][ch][row]); X6: three bf16 planes of them instead (XTh)
-    float* const dAe = XT + (X6 ? RING * 3 * CIN * 20 / 2 : RING * CIN * LDX);   // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
+    float* const dAe = XT + (X6 ? RING * 3 * XPL / 2 : RING * CIN * LDX);   // [RING][16][16]    dA tiles (read by the E waves for dH and by the Mw waves for dWa)
     float* const Ht = dAe + RING * 16 * 16;            // [2][16][LDH]      H = act(U) * S tiles (owned tiles only)
     float* const Xo = Ht + 2 * 16 * LDH;               // [2][16][LDO]      dx tiles
     short* const Zh = reinterpret_cast<short*>(Zt);                  // (X6) [RING]{[16][LDZHM], [16][LDZL]}  bf16 form of the dZ1 tiles (instead of the fp32 tiles)
-    short* const XTh = reinterpret_cast<short*>(XT);                 // (X6) [RING][3][CIN][LDXH]  bf16 planes of the transposed x tiles
+    short* const XTh = reinterpret_cast<short*>(XT);                 // (X6) [RING][3][16][LDXR]  bf16 planes of the x tiles, row major
     short* const Wl = reinterpret_cast<short*>(Xo + 2 * 16 * LDO);   // (X6) [4 waves][KT * QD][64 lanes][4]  low plane of the Md waves' stationary weights
     const int role = threadIdx.x >> 8;                 // 0 = E, 1 = Mw, 2 = Md (wave-uniform)
     const int tid = threadIdx.x & 255, w = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -662,15 +810,9 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
             auto put_x = [&](int xt, const Raw4<ET>& raw) {
                 const f32x4 v = (rv && xt < T) ? cvt4(raw) : zero4();
                 if (cq < CIN / 4) {
-                    if constexpr (X6) {   // three bf16 planes, transposed like XT (the weight-gradient waves read 4 consecutive rows of a channel: 8 bytes)
-                        const Frag3 f = split3(v);
-                        short* d = XTh + (size_t)(xt % RING) * 3 * XPL + (4 * cq) * LDXH + r;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            d[e * LDXH] = f.h[e];
-                            d[XPL + e * LDXH] = f.m[e];
-                            d[2 * XPL + e * LDXH] = f.l[e];
-                        }
+                    if constexpr (X6) {   // three bf16 planes, ROW major: three 8-byte stores (transposed they were twelve 2-byte stores with 4-way bank
+                                          // conflicts: 3.8 us of the launch, profiles/r6-50_*); the weight-gradient waves transpose in their LDS read (ld_tr4)
+                        st_frag3(XTh + (size_t)(xt % RING) * 3 * XPL + r * LDXR + 4 * cq, XPL, split3(v));
                     } else {
                         float* d = XT + (size_t)(xt % RING) * CIN * LDX + (4 * cq) * LDX + r;
 #pragma unroll
@@ -889,7 +1031,24 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                 __syncthreads();   // (B)
                 STGCN_ACC_BEGIN();
                 if (i < T1) {
-                  if constexpr (X6) {
+                  if constexpr (X6 && CIN == 64 && KT == 3 && STGCN_ON_DEVICE) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    static_assert(!(X6 && CIN == 64) || (XPL * 2 == 2560 && LDZHM * 2 == 544), "immediate offsets of STGCN_TC1BWD_MW_STEP_ASM");
+                    const int trow = 4 * g + (l15 >> 2), tq = l15 & 3;   // the lane's address in a transposing read: row, 8-byte group
+                    const short* const Zp = Zh + (size_t)(i % RING) * ZSLOT;
+#define STGCN_C2(f) [c##f##_0] "+v"(accw[f][0]), [c##f##_1] "+v"(accw[f][1])
+                    asm volatile(STGCN_TC1BWD_MW_STEP_ASM
+                                 : STGCN_C2(0), STGCN_C2(1), STGCN_C2(2), STGCN_C2(3), STGCN_C2(4), STGCN_C2(5), STGCN_C2(6), STGCN_C2(7), STGCN_C2(8), STGCN_C2(9),
+                                   STGCN_C2(10), STGCN_C2(11)
+                                 : [zh] "v"(lds_addr(Zp + trow * LDZHM + 8 * (8 * w + tq))), [zl] "v"(lds_addr(Zp + ZLOFS + trow * LDZL + 4 * (8 * w + tq))),
+                                   [x0] "v"(lds_addr(XTh + (size_t)(i % RING) * 3 * XPL + trow * LDXR + 4 * tq)),
+                                   [x1] "v"(lds_addr(XTh + (size_t)((i + 1) % RING) * 3 * XPL + trow * LDXR + 4 * tq)),
+                                   [x2] "v"(lds_addr(XTh + (size_t)((i + 2) % RING) * 3 * XPL + trow * LDXR + 4 * tq))
+                                 : "memory", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151",
+                                   "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+#undef STGCN_C2
+#endif
+                  } else if constexpr (X6) {
                     // B[k = row 4g + s][n = o]: the lane's 4 rows of one column, gathered from each plane (2-byte reads)
                     const int o0 = (2 * w) * 16 + l15;   // column o of a row: element o & 3 of the h quad of group o >> 2 (m: + 4); columns o0 and o0 + 16
                     const short* const Zp = Zh + (size_t)(i % RING) * ZSLOT + (4 * g) * LDZHM + 8 * (o0 >> 2) + (o0 & 3);
@@ -904,10 +1063,10 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                     const bf16x8 z1lh = cat8(fz1.l, fz1.h), z1mm = cat8(fz1.m, fz1.m), z1hh = cat8(fz1.h, fz1.h);
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
-                        const short* xt = XTh + (size_t)((i + k) % RING) * 3 * XPL + l15 * LDXH + 4 * g;
+                        const short* xt = XTh + (size_t)((i + k) % RING) * 3 * XPL;
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {   // A[m = ch][k = row]
-                            const Frag3 fa = ld_frag3(xt + mi * 16 * LDXH, XPL);
+                            const Frag3 fa = {ld_tr4(xt + mi * 16, LDXR, g, l15), ld_tr4(xt + XPL + mi * 16, LDXR, g, l15), ld_tr4(xt + 2 * XPL + mi * 16, LDXR, g, l15)};
                             const bf16x8 ahl = cat8(fa.h, fa.l), ahm = cat8(fa.h, fa.m);
                             f32x4& c0 = accw[k * MI + mi][0];
                             f32x4& c1 = accw[k * MI + mi][1];
