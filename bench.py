@@ -50,8 +50,8 @@ CONFIGS = {
                         "dropout 0.5, AdamW; full step"),
 }
 # (named explicitly: they have to be re-measured whenever a kernel's traffic changes; keyed by (config, dtype))
-PMC_TRAFFIC_FILES = {("c2", "f32"): "r6-40_pmc_traffic.json", ("c3", "bf16"): "r6-40_pmc_traffic_c3_bf16.json",
-                     ("c5", "bf16"): "r6-40_pmc_traffic_c5_bf16.json"}
+PMC_TRAFFIC_FILES = {("c2", "f32"): "r6-60_pmc_traffic.json", ("c3", "bf16"): "r6-60_pmc_traffic_c3_bf16.json",
+                     ("c5", "bf16"): "r6-60_pmc_traffic_c5_bf16.json"}
 B_OVERRIDE = os.environ.get("STGCN_BENCH_B")       # (env: batch-size sweeps of tools/, not the headline)
 
 
@@ -415,7 +415,7 @@ def main():
                       "backward_products": ("bf16" if DTYPE == "bf16" else args.bwd_precision),
                       **({"matrix_products": ("fp32 in, fp32 accumulate; tc1_fwd / tc2_ln_fwd / tc1_bwd form their products as bf16x6 -- both operands split EXACTLY into "
                                               "three bf16 (8+8+8 significand bits), six of the nine partial products (the others < 2^-32) on v_mfma_f32_16x16x32_bf16; error "
-                                              "against the fp64 stage oracle equal to v_mfma_f32_16x16x4_f32's (profiles/r6-29_x6_errors.txt); every other product on "
+                                              "against the fp64 stage oracle equal to v_mfma_f32_16x16x4_f32's (profiles/r6-60_x6_errors.txt); every other product on "
                                               "v_mfma_f32_16x16x4_f32" if os.environ.get("STGCN_MFMA_X6", "1") != "0" else "v_mfma_f32_16x16x4_f32 for every product (STGCN_MFMA_X6=0)")}
                          if DTYPE == "f32" else {}),
                       "operator_products": ("bf16" if DTYPE == "bf16" else args.gc_precision if (N > 512 or args.gc_precision == "bf16x3") else "fp32"),

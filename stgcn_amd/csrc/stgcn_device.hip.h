@@ -547,7 +547,7 @@ __device__ __forceinline__ void gate_bwd(float dh, float u, float s, int act, fl
         dq = dh * u * s * (1.0f - s);
     } else {
         const float th = tanh_f(u);
-        du = dh * s * (1.0f - th * th);
+        du = dh * s * __builtin_fmaf(-th, th, 1.0f);   // (explicit: the function is inlined at several call sites that must round alike)
         dq = dh * th * s * (1.0f - s);
     }
 }
@@ -828,6 +828,9 @@ __device__ __forceinline__ void st_frag3_hml(short* phm, short* pl, const Frag3&
 #define STGCN_ON_DEVICE 1   // (constant of `if constexpr` choices between a hand-scheduled device form and the portable form the host emulator runs)
 #else
 #define STGCN_ON_DEVICE 0
+#endif
+#ifndef STGCN_MW_ASM
+#define STGCN_MW_ASM 1
 #endif
 // A[m][k = 4 consecutive rows] fragment of a ROW-MAJOR bf16 tile in LDS (element (row, col) at p0[row * ld + col]): lane (l15, g) receives column
 // col0 + l15 of rows 4g .. 4g + 3.  On the device one ds_read_b64_tr_b16: every lane supplies the address of 4 contiguous elements -- lane i of a

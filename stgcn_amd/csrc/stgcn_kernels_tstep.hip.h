@@ -893,9 +893,12 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                                 }
                             }
 #pragma unroll
+                            // (explicit fused multiply-adds: F is inlined twice -- in the step loop and behind it -- and the two copies must round alike, or the
+                            //  row partials of a range's LAST step differ from the others' by an ulp and the step's result depends on where the ranges were cut,
+                            //  i.e. on the batch size: seen as a 1e-5 drift between chained micro-batches after AdamW had normalised near-zero LayerNorm gradients)
                             for (int i = 0; i < 4; ++i) {
-                                p.x += v[i] * kk[i] * hgam[i];
-                                if (kk[i] > 0.f) p.y += v[i] * (hy[i] - hbks[i]);
+                                p.x = __builtin_fmaf(v[i] * kk[i], hgam[i], p.x);
+                                if (kk[i] > 0.f) p.y = __builtin_fmaf(v[i], hy[i] - hbks[i], p.y);
                             }
                         }
 #pragma unroll
@@ -1031,7 +1034,7 @@ __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
                 __syncthreads();   // (B)
                 STGCN_ACC_BEGIN();
                 if (i < T1) {
-                  if constexpr (X6 && CIN == 64 && KT == 3 && STGCN_ON_DEVICE) {
+                  if constexpr (X6 && CIN == 64 && KT == 3 && STGCN_ON_DEVICE && STGCN_MW_ASM) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     static_assert(!(X6 && CIN == 64) || (XPL * 2 == 2560 && LDZHM * 2 == 544), "immediate offsets of STGCN_TC1BWD_MW_STEP_ASM");
                     const int trow = 4 * g + (l15 >> 2), tq = l15 & 3;   // the lane's address in a transposing read: row, 8-byte group
