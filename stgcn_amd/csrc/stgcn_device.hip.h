@@ -830,7 +830,7 @@ __device__ __forceinline__ void st_frag3_hml(short* phm, short* pl, const Frag3&
 #define STGCN_ON_DEVICE 0
 #endif
 #ifndef STGCN_MW_ASM
-#define STGCN_MW_ASM 1
+#define STGCN_MW_ASM 1   // build-time A/B switch: 0 = tc1_bwd's weight-gradient waves in the compiler-scheduled form (used to bisect pass r6-53, profiles/r6_experiments.md)
 #endif
 // A[m][k = 4 consecutive rows] fragment of a ROW-MAJOR bf16 tile in LDS (element (row, col) at p0[row * ld + col]): lane (l15, g) receives column
 // col0 + l15 of rows 4g .. 4g + 3.  On the device one ds_read_b64_tr_b16: every lane supplies the address of 4 contiguous elements -- lane i of a

@@ -710,8 +710,9 @@ __host__ __device__ inline int tc1_bwd_step_weight(int s, int T1, int KT, int CI
     "s_nop 7\n\t"
 // X6 (round 6, fp32 blocks): the weight-gradient and transposed-conv products (Mw and Md waves) as "bf16x6" -- fp32-accurate
 // products on the bf16 matrix pipe (Frag3, stgcn_device.hip.h).  Both operands are tiles the E waves produce: x tiles (staged once, read
-// by four waves for KT steps) and dZ1 tiles (formed once); E splits them into three bf16 planes where it writes them.  The transposed conv
-// (Md waves) keeps its fp32 MFMAs: its 24 stationary weight fragments would be 144 registers as plane triples.
+// by four waves for KT steps) and dZ1 tiles (formed once); E splits them into bf16 planes where it writes them (x: three row-major planes; dZ1: a
+// (h | m) plane + an l plane).  The transposed conv (Md waves) holds the (h | m) halves of its 24 stationary weight fragments in registers (96) and
+// their l plane in a wave-private LDS region (as triples they would be 144 registers).  Inner loops of both matrix roles: the hand-scheduled blocks above.
 template <int C0, int CIN, int KT, int ACT, typename ET, bool X6 = false>
 __device__ __forceinline__ void tc1_bwd_body(const Tc1BwdArgs& a) {
     static_assert(C0 == 64 && (CIN == 16 || CIN == 32 || CIN == 64), "shapes covered by the role split below");
